@@ -1,0 +1,124 @@
+"""CPU oracle for the STFT / magnitude-phase codec path.  TEST INFRASTRUCTURE ONLY (see oracle/progan.py header).
+
+numpy restatement of /root/reference/music_gan/audio/functions.py:
+  :13-23   diff / unwrap  (== np.unwrap along time incl. the -pi -> +pi correction)
+  :26-35   bark_magn_scale: s = 6*asinh(linspace(20, 22050, F)/600), normalised to unit L2 norm
+  :38-62   wav_to_stft: mono mean, periodic Hann(1024), torchaudio.functional.spectrogram(power=None, normalized=True)
+           (== centre/reflect-padded framed rFFT divided by sqrt(sum w^2)), Nyquist row dropped
+  :65-94   stft_to_phase_magn: abs/angle, bark scale, unwrap, first difference, global min/max -> [-1,1],
+           drop the leading T mod nb_vec frames, split into nb_vec-frame images
+  :97-139  magn_phase_to_wav: inverse codec (its asymmetries kept), cumulative phase, polar -> complex,
+           zero Nyquist row, inverse_spectrogram(normalized=True) (== torch.istft overlap-add / window envelope)
+
+Third-party boundary: torchaudio (requirements.txt:5, unpinned, absent here).  Its two functional wrappers are restated
+from their documented behaviour; the pin is torch.stft/torch.istft in the build container (tools/ref_loader.py stand-in)
+plus the explicit DFT identity below -- "parity pinned on torch.stft, not on torchaudio" (DESIGN.md).
+Golden vectors: tests/golden/audio_codec.npz (tools/gen_golden.py: audio_case).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+N_FFT = 1024
+N_VEC = 512
+STFT_STRIDE = 256
+SAMPLE_RATE = 44100
+
+
+def hann_periodic(n: int = N_FFT) -> np.ndarray:
+    return (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n, dtype=np.float64) / n)).astype(np.float32)
+
+
+def stft(wav: np.ndarray, n_fft: int = N_FFT, hop: int = STFT_STRIDE) -> np.ndarray:
+    """wav (C, L) or (L,) float32 -> complex64 (n_fft/2, 1 + L//hop).   X[k,t] = sum_n w[n] xpad[hop t + n] e^{-2 pi i k n/N} / sqrt(sum w^2)."""
+    wav = np.asarray(wav, dtype=np.float32)
+    mono = wav.mean(axis=0, dtype=np.float32) if wav.ndim == 2 else wav
+    w = hann_periodic(n_fft)
+    xp = np.pad(mono, (n_fft // 2, n_fft // 2), mode="reflect")
+    t = 1 + mono.shape[0] // hop
+    idx = np.arange(n_fft)[None, :] + hop * np.arange(t)[:, None]
+    frames = xp[idx] * w[None, :]
+    spec = np.fft.rfft(frames.astype(np.float64), axis=1).T  # (n_fft/2+1, T)
+    spec = spec / np.sqrt(np.sum(w.astype(np.float64) ** 2))
+    return spec[:-1, :].astype(np.complex64)
+
+
+def bark_scale_vector(nb_freq: int = N_FFT // 2) -> np.ndarray:
+    f = np.linspace(20.0, 44100 // 2, nb_freq, dtype=np.float32)
+    s = (6.0 * np.arcsinh(f / np.float32(600.0))).astype(np.float32)
+    return (s / np.sqrt(np.sum(s.astype(np.float64) ** 2)).astype(np.float32)).astype(np.float32)
+
+
+def unwrap(phi: np.ndarray) -> np.ndarray:
+    phi = np.asarray(phi, dtype=np.float32)
+    dphi = np.zeros_like(phi)
+    dphi[:, 1:] = phi[:, 1:] - phi[:, :-1]
+    pi = np.float32(np.pi)
+    two_pi = np.float32(2 * np.pi)
+    dphi_m = np.mod(dphi + pi, two_pi) - pi
+    dphi_m[(dphi_m == -pi) & (dphi > 0)] = pi
+    adj = dphi_m - dphi
+    adj[np.abs(dphi) < pi] = 0
+    return phi + np.cumsum(adj, axis=1, dtype=np.float32)
+
+
+def stft_to_phase_magn(c: np.ndarray, nb_vec: int = N_VEC):
+    magn = np.abs(c).astype(np.float32)
+    phase = np.angle(c).astype(np.float32)
+    magn = magn * bark_scale_vector(c.shape[0])[:, None]
+    phase = unwrap(phase)
+    phase = phase[:, 1:] - phase[:, :-1]
+    magn = magn[:, 1:]
+    magn = (magn - magn.min()) / (magn.max() - magn.min())
+    phase = (phase - phase.min()) / (phase.max() - phase.min())
+    magn, phase = magn * np.float32(2.0) - np.float32(1.0), phase * np.float32(2.0) - np.float32(1.0)
+    r = magn.shape[1] % nb_vec
+    magn, phase = magn[:, r:], phase[:, r:]
+    s = magn.shape[1] // nb_vec
+    magn = magn.reshape(c.shape[0], s, nb_vec).transpose(1, 0, 2)
+    phase = phase.reshape(c.shape[0], s, nb_vec).transpose(1, 0, 2)
+    return np.ascontiguousarray(magn), np.ascontiguousarray(phase)
+
+
+def istft(z: np.ndarray, n_fft: int = N_FFT, hop: int = STFT_STRIDE) -> np.ndarray:
+    """complex (n_fft/2+1, T) -> float32 (hop*(T-1),), the inverse of the normalized centre-padded STFT."""
+    w = hann_periodic(n_fft).astype(np.float64)
+    z = z.astype(np.complex128) * np.sqrt(np.sum(w ** 2))
+    t = z.shape[1]
+    frames = np.fft.irfft(z.T, n=n_fft, axis=1) * w[None, :]
+    total = n_fft + hop * (t - 1)
+    y = np.zeros(total)
+    env = np.zeros(total)
+    for i in range(t):
+        y[i * hop:i * hop + n_fft] += frames[i]
+        env[i * hop:i * hop + n_fft] += w ** 2
+    y = y[n_fft // 2: total - n_fft // 2]
+    env = env[n_fft // 2: total - n_fft // 2]
+    return (y / env).astype(np.float32)
+
+
+def magn_phase_to_wav(mp: np.ndarray) -> np.ndarray:
+    """(N, 2, 512, W) float32 -> (256*(N*W-1),) float32 waveform (functions.py:97-139 without the file write)."""
+    assert mp.ndim == 4 and mp.shape[1] == 2 and mp.shape[2] == N_FFT // 2
+    mp = np.asarray(mp, dtype=np.float32)
+    flat = mp.transpose(1, 2, 0, 3).reshape(2, mp.shape[2], -1)
+    magn, phase = flat[0].copy(), flat[1].copy()
+    magn = (magn + np.float32(1.0)) / np.float32(2.0)
+    magn = magn / bark_scale_vector(magn.shape[0])[:, None]
+    magn = magn / (magn.max() - magn.min())
+    phase = (phase + np.float32(1.0)) / np.float32(2.0) * np.float32(2.0) * np.float32(np.pi) - np.float32(np.pi)
+    phase = np.cumsum(phase, axis=1, dtype=np.float32)
+    phase = np.mod(phase, np.float32(2 * np.pi))
+    real = magn * np.cos(phase)
+    imag = magn * np.sin(phase)
+    z = np.concatenate([real + 1j * imag, np.zeros((1, real.shape[1]), dtype=np.complex64)], axis=0)
+    return istft(z)
+
+
+def dft_bin(wav_mono: np.ndarray, k: int, t: int, n_fft: int = N_FFT, hop: int = STFT_STRIDE) -> complex:
+    """Explicit fp64 DFT of one (bin, frame): the identity the STFT kernel's indexing is checked against."""
+    w = hann_periodic(n_fft).astype(np.float64)
+    xp = np.pad(np.asarray(wav_mono, dtype=np.float64), (n_fft // 2, n_fft // 2), mode="reflect")
+    n = np.arange(n_fft)
+    seg = xp[hop * t: hop * t + n_fft] * w
+    return complex(np.sum(seg * np.exp(-2j * np.pi * k * n / n_fft)) / np.sqrt(np.sum(w ** 2)))

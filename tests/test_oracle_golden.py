@@ -1,0 +1,147 @@
+"""CPU: the oracle (oracle/progan.py, oracle/audio.py) is pinned against golden vectors captured from the reference."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import PROGAN_CASES, build_oracle_states, check_tensor, load, sha
+from oracle import audio as OA
+from oracle import progan as O
+
+
+@pytest.mark.parametrize("case", PROGAN_CASES)
+def test_oracle_init_is_bit_exact(case):
+    g = load(f"progan_{case}.npz")
+    gs, ds = build_oracle_states(g)
+    assert list(gs.params.keys()) == list(g["g_keys"])
+    assert list(ds.params.keys()) == list(g["d_keys"])
+    assert [str(tuple(v.shape)) for v in gs.params.values()] == list(g["g_shapes"])
+    assert [str(tuple(v.shape)) for v in ds.params.values()] == list(g["d_shapes"])
+    assert [sha(v) for v in gs.params.values()] == list(g["g_sha"])
+    assert [sha(v) for v in ds.params.values()] == list(g["d_sha"])
+    assert gs.curr_layer == int(g["g_curr_layer"]) and ds.curr_layer == int(g["d_curr_layer"])
+
+
+@pytest.mark.parametrize("case", PROGAN_CASES)
+def test_oracle_steps_match_reference(case):
+    g = load(f"progan_{case}.npz")
+    gs, ds = build_oracle_states(g)
+    alpha = float(g["alpha"])
+    z, z2 = torch.from_numpy(g["z"]), torch.from_numpy(g["z2"])
+    x_real, eps = torch.from_numpy(g["x_real"]), torch.from_numpy(g["eps"])
+    r = O.d_step(gs, ds, x_real, z, eps, alpha)
+    assert torch.allclose(r["x_fake"], torch.from_numpy(g["x_fake"]), rtol=0, atol=2e-6)
+    assert torch.allclose(r["out_real"], torch.from_numpy(g["out_real"]), rtol=1e-5, atol=1e-7)
+    assert torch.allclose(r["out_fake"], torch.from_numpy(g["out_fake"]), rtol=1e-5, atol=1e-7)
+    assert abs(float(r["disc_loss"]) - float(g["disc_loss"])) < 1e-6
+    assert abs(float(r["grad_pen"]) - float(g["grad_pen"])) < 1e-5
+    assert list(r["d_grads"].keys()) == [k for k in ds.live_keys()]
+    assert sorted(r["d_grads"].keys()) == sorted(g["dstep_d_live"])
+    assert sorted(r["g_grads"].keys()) == sorted(g["dstep_g_live"])
+    for k, v in r["d_grads"].items():
+        check_tensor(g, f"dstep_dgrad|{k}", v, 2e-4)
+    for k, v in r["g_grads"].items():
+        check_tensor(g, f"dstep_ggrad|{k}", v, 2e-4)
+    # Adam on D (step 1 for every live tensor), then the G step against the updated critic
+    for k in ds.live_keys():
+        p = ds.params[k]
+        new, _, _ = O.adam_update(p, r["d_grads"][k], torch.zeros_like(p), torch.zeros_like(p), 1)
+        p.copy_(new)
+    for k, p in ds.params.items():
+        check_tensor(g, f"dstep_dparam|{k}", p, 2e-6)
+    r2 = O.g_step(gs, ds, z2, alpha)
+    assert torch.allclose(r2["x_fake"], torch.from_numpy(g["x_fake2"]), rtol=0, atol=2e-6)
+    assert abs(float(r2["gen_loss"]) - float(g["gen_loss"])) < 1e-6
+    for k, v in r2["g_grads"].items():
+        check_tensor(g, f"gstep_ggrad|{k}", v, 2e-4)
+    for k in gs.live_keys():
+        p = gs.params[k]
+        new, _, _ = O.adam_update(p, r2["g_grads"][k], torch.zeros_like(p), torch.zeros_like(p), 1)
+        p.copy_(new)
+    for k, p in gs.params.items():
+        check_tensor(g, f"gstep_gparam|{k}", p, 2e-6)
+
+
+def test_oracle_detached_d_step_gives_same_d_grads():
+    """Detaching x_fake in the D step (what the product does) leaves every D gradient unchanged."""
+    g = load("progan_l1_rc8_fade.npz")
+    gs, ds = build_oracle_states(g)
+    args = (torch.from_numpy(g["x_real"]), torch.from_numpy(g["z"]), torch.from_numpy(g["eps"]), float(g["alpha"]))
+    a = O.d_step(gs, ds, *args, dtype=torch.float64)
+    b = O.d_step(gs, ds, *args, dtype=torch.float64, detach_fake=True)
+    for k in a["d_grads"]:
+        assert torch.allclose(a["d_grads"][k], b["d_grads"][k], rtol=1e-12, atol=1e-15)
+    assert len(b["g_grads"]) == 0
+
+
+def test_oracle_shapes_walk_and_nonsquare():
+    g = load("progan_shapes.npz")
+    torch.manual_seed(5)
+    gs, ds = O.GenState(8), O.DiscState(7)
+    for i in range(10):
+        z = torch.randn(1, 8, 2, 2)
+        out = O.gen_forward(gs.params, gs.curr_layer, gs.has_last, z, 0.5)
+        dout = O.disc_forward(ds.params, ds.curr_layer, ds.has_last, out, 0.5)
+        assert list(out.shape) == list(g["g_out_shapes"][i])
+        assert list(dout.shape) == list(g["d_out_shapes"][i])
+        assert [int(gs.growing), int(ds.growing)] == list(g["growing"][i])
+        gs.next_layer()
+        ds.next_layer()
+    assert list(gs.params.keys()) == list(g["g_keys_final"])
+    assert list(ds.params.keys()) == list(g["d_keys_final"])
+    torch.manual_seed(6)
+    g2 = O.GenState(8, end_layer=2)
+    assert list(g2.params.keys()) == list(g["ns_keys"])
+    assert [sha(v) for v in g2.params.values()] == list(g["ns_sha"])
+    z = torch.from_numpy(g["ns_z"])
+    y = O.gen_forward(g2.params, 2, True, z, 1.0)
+    assert torch.allclose(y, torch.from_numpy(g["ns_out"]), atol=2e-6, rtol=0)
+    y = O.gen_forward(g2.params, 2, True, z, 0.37)
+    assert torch.allclose(y, torch.from_numpy(g["ns_out_a037"]), atol=2e-6, rtol=0)
+
+
+def test_flop_model_matches_survey():
+    gf, df = O.flops_per_image(32, 5)
+    assert abs(gf / 1e9 - 1.978) < 2e-3 and abs(df / 1e9 - 1.986) < 2e-3
+    gf, df = O.flops_per_image(32, 4)
+    assert abs(gf / 1e9 - 0.767) < 2e-3 and abs(df / 1e9 - 0.775) < 2e-3
+
+
+# ------------------------------------------------------------------ audio
+def test_audio_oracle_stft_matches_reference():
+    g = load("audio_codec.npz")
+    c = OA.stft(g["wav"])
+    ref = g["stft_real"] + 1j * g["stft_imag"]
+    assert c.shape == ref.shape == (512, 553)
+    assert np.max(np.abs(c - ref)) <= 1e-5 * np.max(np.abs(ref))
+    # explicit DFT identity at a few (bin, frame) pairs incl. the reflect-padded edges
+    mono = g["wav"].mean(axis=0)
+    for k, t in [(0, 0), (1, 0), (37, 1), (511, 2), (100, 300), (255, 551), (3, 552)]:
+        assert abs(OA.dft_bin(mono, k, t) - ref[k, t]) <= 2e-5 * np.max(np.abs(ref))
+
+
+def test_audio_oracle_codec_matches_reference():
+    g = load("audio_codec.npz")
+    ref = (g["stft_real"] + 1j * g["stft_imag"]).astype(np.complex64)
+    magn, phase = OA.stft_to_phase_magn(ref)
+    assert magn.shape == g["magn"].shape == (1, 512, 512)
+    assert np.max(np.abs(magn - g["magn"])) <= 2e-6
+    # phase goes through atan2 + a long fp32 cumulative sum: allow 1e-4 of the [-1,1] range
+    assert np.max(np.abs(phase - g["phase"])) <= 1e-4
+    s = OA.bark_scale_vector(512)
+    assert np.allclose(s, g["bark_scale"], rtol=1e-6, atol=0)
+    assert abs(s[0] - 4.27399e-4) < 1e-8 and abs(s[511] - 5.51122e-2) < 1e-6  # SURVEY 8(c) known answers
+    assert np.allclose(OA.unwrap(g["unwrap_in"]), g["unwrap_out"], atol=2e-5)
+    assert np.allclose(OA.unwrap(g["unwrap_in"]), np.unwrap(g["unwrap_in"].astype(np.float64), axis=1), atol=3e-5)
+
+
+def test_audio_oracle_inverse_matches_reference():
+    g = load("audio_codec.npz")
+    wav = OA.magn_phase_to_wav(g["inv_in"])
+    ref = g["inv_wav"].reshape(-1)
+    assert wav.shape == ref.shape == (256 * 63,)
+    assert np.max(np.abs(wav - ref)) <= 2e-3 * np.max(np.abs(ref))
+
+
+def test_stft_known_shape_30s():
+    # notebook cell 7: 30 s mono at 44.1 kHz -> [513, 5168] before the Nyquist drop
+    assert OA.stft(np.zeros(44100 * 30, dtype=np.float32)).shape == (512, 5168)

@@ -1,0 +1,218 @@
+"""Generate tests/golden/*.npz by running the REFERENCE (imported from /root/reference, container only).
+
+Usage:  python tools/gen_golden.py            (writes tests/golden/progan_*.npz and audio_*.npz)
+
+What is stored is data only: seeds, injected inputs, the reference's outputs, losses, gradients (full when small,
+a fixed strided subsample + sum + L2 otherwise), post-Adam weights (same subsampling) and SHA-256 of every
+reference-initialised parameter (so the oracle's same-seed init is checked bit-for-bit without storing 10 MB).
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from ref_loader import load_audio, load_networks, wav_store  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+FULL_MAX = 4096
+NSAMP = 509
+
+
+def sha(t: torch.Tensor) -> str:
+    return hashlib.sha256(t.detach().contiguous().numpy().tobytes()).hexdigest()
+
+
+def sample_idx(numel: int) -> np.ndarray:
+    if numel <= FULL_MAX:
+        return np.arange(numel)
+    return (np.arange(NSAMP, dtype=np.int64) * (numel // NSAMP))
+
+
+def put_tensor(store, name, t):
+    t = t.detach().to(torch.float32).contiguous().reshape(-1)
+    idx = sample_idx(t.numel())
+    store[name + "|samp"] = t.numpy()[idx]
+    store[name + "|sum"] = np.float64(t.double().sum().item())
+    store[name + "|l2"] = np.float64(t.double().norm().item())
+    store[name + "|maxabs"] = np.float64(t.abs().max().item())
+
+
+def progan_case(tag, seed, rand_channels, n_grow, alpha, batch, g_end_layer=0, d_start_layer=7, wscale=1.0):
+    nets = load_networks()
+    torch.manual_seed(seed)
+    gen = nets.Generator(rand_channels, end_layer=g_end_layer)
+    disc = nets.Discriminator(start_layer=d_start_layer)
+    for _ in range(n_grow):
+        gen.next_layer()
+        disc.next_layer()
+    if wscale != 1.0:
+        # leave the near-zero-critic regime of a fresh init (|grad_x D| ~ 0 => GP gradients cancel): scale every
+        # weight (not bias) of both nets in place; the oracle test applies the same scaling after its own init
+        with torch.no_grad():
+            for net in (gen, disc):
+                for k, p in net.named_parameters():
+                    if k.endswith("weight"):
+                        p.mul_(wscale)
+    store = {"seed": seed, "rand_channels": rand_channels, "n_grow": n_grow, "alpha": alpha, "batch": batch,
+             "wscale": wscale,
+             "g_end_layer": g_end_layer, "d_start_layer": d_start_layer,
+             "g_curr_layer": gen.curr_layer, "d_curr_layer": disc.curr_layer}
+    gsd, dsd = gen.state_dict(), disc.state_dict()
+    store["g_keys"] = np.array(list(gsd.keys()))
+    store["d_keys"] = np.array(list(dsd.keys()))
+    store["g_shapes"] = np.array([str(tuple(v.shape)) for v in gsd.values()])
+    store["d_shapes"] = np.array([str(tuple(v.shape)) for v in dsd.values()])
+    store["g_sha"] = np.array([sha(v) for v in gsd.values()])
+    store["d_sha"] = np.array([sha(v) for v in dsd.values()])
+
+    side = 2 * 2 ** (gen.curr_layer + 1)
+    rng = torch.Generator().manual_seed(seed + 1000)
+    z = torch.randn(batch, rand_channels, 2, 2, generator=rng)
+    z2 = torch.randn(batch, rand_channels, 2, 2, generator=rng)
+    x_real = torch.rand(batch, 2, side, side, generator=rng) * 2 - 1
+    eps = torch.rand(batch, 1, 1, 1, generator=rng)
+    store.update(z=z.numpy(), z2=z2.numpy(), x_real=x_real.numpy(), eps=eps.numpy())
+
+    optim_gen = torch.optim.Adam(gen.parameters(), lr=1e-3, betas=(0.0, 0.9))
+    optim_disc = torch.optim.Adam(disc.parameters(), lr=1e-3, betas=(0.0, 0.9))
+
+    # ---- D step, train.py:152-175 (eps injected by seeding the global RNG the way gradient_penalty draws it)
+    x_fake = gen(z, alpha)
+    out_real = disc(x_real, alpha)
+    out_fake = disc(x_fake, alpha)
+    d_loss = nets.wasserstein_discriminator_loss(out_real, out_fake)
+    state = torch.get_rng_state()
+    # gradient_penalty draws th.rand(batch,1,1,1) from the global generator: make that draw == eps
+    torch.manual_seed(seed + 2000)
+    eps_drawn = torch.rand(batch, 1, 1, 1)
+    store["eps"] = eps_drawn.numpy()
+    torch.manual_seed(seed + 2000)
+    gp = disc.gradient_penalty(x_real, x_fake, alpha)
+    torch.set_rng_state(state)
+    gen.zero_grad()
+    disc.zero_grad()
+    (d_loss + gp).backward()
+    store.update(x_fake=x_fake.detach().numpy(), out_real=out_real.detach().numpy(),
+                 out_fake=out_fake.detach().numpy(), disc_loss=np.float64(d_loss.item()),
+                 grad_pen=np.float64(gp.item()))
+    live_d = [k for k, p in disc.named_parameters() if p.grad is not None]
+    live_g = [k for k, p in gen.named_parameters() if p.grad is not None]
+    store["dstep_d_live"] = np.array(live_d)
+    store["dstep_g_live"] = np.array(live_g)
+    for k, p in disc.named_parameters():
+        if p.grad is not None:
+            put_tensor(store, f"dstep_dgrad|{k}", p.grad)
+    for k, p in gen.named_parameters():
+        if p.grad is not None:
+            put_tensor(store, f"dstep_ggrad|{k}", p.grad)
+    optim_disc.step()
+    for k, p in disc.named_parameters():
+        put_tensor(store, f"dstep_dparam|{k}", p)
+
+    # ---- G step, train.py:191-214 (with the updated discriminator)
+    x_fake2 = gen(z2, alpha)
+    out_fake2 = disc(x_fake2, alpha)
+    g_loss = nets.wasserstein_generator_loss(out_fake2)
+    gen.zero_grad()
+    disc.zero_grad()
+    g_loss.backward()
+    store.update(x_fake2=x_fake2.detach().numpy(), out_fake2=out_fake2.detach().numpy(),
+                 gen_loss=np.float64(g_loss.item()))
+    for k, p in gen.named_parameters():
+        if p.grad is not None:
+            put_tensor(store, f"gstep_ggrad|{k}", p.grad)
+    optim_gen.step()
+    for k, p in gen.named_parameters():
+        put_tensor(store, f"gstep_gparam|{k}", p)
+
+    path = os.path.join(OUT, f"progan_{tag}.npz")
+    np.savez_compressed(path, **store)
+    print(f"wrote {path}: L{gen.curr_layer} side {side} d_loss {d_loss.item():.6f} gp {gp.item():.6f} "
+          f"g_loss {g_loss.item():.6f}  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def progan_shapes_case():
+    """The walk of networks/test_networks.py:4-38 (shapes at every level, growing flags), plus a non-square
+    forward as generate.py:47-54 uses it."""
+    nets = load_networks()
+    torch.manual_seed(5)
+    gen, disc = nets.Generator(8), nets.Discriminator(7)
+    shapes, dshapes, flags = [], [], []
+    for _ in range(gen.down_sample + 3):
+        z = torch.randn(1, 8, 2, 2)
+        with torch.no_grad():
+            out = gen(z, 0.5)
+            dout = disc(out, 0.5)
+        shapes.append(list(out.shape))
+        dshapes.append(list(dout.shape))
+        flags.append([int(gen.growing), int(disc.growing)])
+        gen.next_layer()
+        disc.next_layer()
+    store = {"g_out_shapes": np.array(shapes), "d_out_shapes": np.array(dshapes), "growing": np.array(flags),
+             "g_keys_final": np.array(list(gen.state_dict().keys())),
+             "d_keys_final": np.array(list(disc.state_dict().keys()))}
+    # non-square generator forward, directly constructed at end_layer=2 (fresh previous head, generator.py:93-104)
+    torch.manual_seed(6)
+    g2 = nets.Generator(8, end_layer=2)
+    z = torch.randn(2, 8, 2, 6, generator=torch.Generator().manual_seed(66))
+    with torch.no_grad():
+        y = g2(z, 1.0)
+        y37 = g2(z, 0.37)
+    store.update(ns_z=z.numpy(), ns_out=y.numpy(), ns_out_a037=y37.numpy(),
+                 ns_keys=np.array(list(g2.state_dict().keys())),
+                 ns_sha=np.array([sha(v) for v in g2.state_dict().values()]))
+    path = os.path.join(OUT, "progan_shapes.npz")
+    np.savez_compressed(path, **store)
+    print("wrote", path, shapes[:3], "...", shapes[-1])
+
+
+def audio_case():
+    audio = load_audio()
+    fn = sys.modules["music_gan.audio.functions"]
+    rng = torch.Generator().manual_seed(7)
+    sr = 44100
+    # 3.2 s stereo: 552 frames -> one 512-frame sample after dropping the first frame and the remainder
+    wav = (torch.rand(2, 141_312, generator=rng) - 0.5)
+    t = torch.arange(wav.shape[1]) / sr
+    wav[0] += 0.3 * torch.sin(2 * np.pi * 440.0 * t)
+    wav[1] += 0.2 * torch.sin(2 * np.pi * 3000.0 * t + 1.0)
+    wav_store()["in.wav"] = (wav, sr)
+    c = audio.wav_to_stft("in.wav")
+    magn, phase = audio.stft_to_phase_magn(c, nb_vec=512)
+    store = {"wav": wav.numpy(), "stft_real": c.real.numpy().astype(np.float32),
+             "stft_imag": c.imag.numpy().astype(np.float32), "magn": magn.numpy(), "phase": phase.numpy()}
+    # bark scale vector on ones (functions.py:26-35)
+    store["bark_scale"] = audio.bark_magn_scale(torch.ones(512, 1)).numpy()[:, 0]
+    # unwrap on random phases (functions.py:17-23)
+    ph = (torch.rand(16, 300, generator=rng) * 2 - 1) * np.pi
+    store["unwrap_in"] = ph.numpy()
+    store["unwrap_out"] = fn.unwrap(ph.clone()).numpy()
+    # inverse path (functions.py:97-139) on the codec output, restricted to the first 64 frames
+    mp = torch.stack([magn[:, :, :64], phase[:, :, :64]], dim=1)  # (1,2,512,64)
+    audio.magn_phase_to_wav(mp.clone(), "out.wav", sr)
+    out_wav, _ = wav_store()["out.wav"]
+    store["inv_in"] = mp.numpy()
+    store["inv_wav"] = out_wav.numpy()
+    path = os.path.join(OUT, "audio_codec.npz")
+    np.savez_compressed(path, **store)
+    print("wrote", path, "stft", tuple(c.shape), "magn", tuple(magn.shape), "wav out", tuple(out_wav.shape),
+          f"({os.path.getsize(path) / 1024:.0f} KiB)")
+    # notebook cell 7 known answer: 30 s mono -> [513, 5168] before the Nyquist drop
+    wav_store()["k.wav"] = (torch.zeros(1, 44100 * 30), sr)
+    assert tuple(audio.wav_to_stft("k.wav").shape) == (512, 5168)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    progan_case("l0_rc8", seed=11, rand_channels=8, n_grow=0, alpha=1.0, batch=3)
+    progan_case("l1_rc8_fade", seed=12, rand_channels=8, n_grow=1, alpha=0.37, batch=3)
+    progan_case("l3_rc32_fade", seed=13, rand_channels=32, n_grow=3, alpha=0.37, batch=2)
+    progan_case("l2_direct", seed=14, rand_channels=16, n_grow=0, alpha=0.6, batch=2, g_end_layer=2,
+                d_start_layer=5)
+    progan_case("l2_rc16_fade_scaled", seed=15, rand_channels=16, n_grow=2, alpha=0.5, batch=4, wscale=1.7)
+    progan_shapes_case()
+    audio_case()
