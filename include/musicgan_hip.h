@@ -1,0 +1,139 @@
+/*
+ * musicgan_hip.h -- C ABI of libmusicgan_hip.so, the MI355X (gfx950) kernels behind the MusicGAN hot path.
+ *
+ * The reference (Ipsedo/MusicGAN) has no FFI/plugin layer: its hot path is stock torch.nn modules
+ * (music_gan/networks/) and torchaudio/torch.stft calls (music_gan/audio/functions.py).  Each entry point below
+ * names the reference module/ATen op it replaces (file:line relative to /root/reference/music_gan).  A maintainer binds
+ * these with ctypes; musicgan_amd/_lib.py is that binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32, NCHW contiguous, 16-byte aligned (torch allocations are);
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); every call is asynchronous on it;
+ *   - functions return 0 on success, a negative MG_E* code otherwise, never throw; mg_last_error() gives the text of the
+ *     calling thread's last failure; no hidden global state apart from one-time kernel attribute set-up;
+ *   - callable concurrently from several host threads on distinct streams (autograd backward threads do).
+ */
+#ifndef MUSICGAN_HIP_H
+#define MUSICGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mg_stream_t;
+
+#define MG_OK 0
+#define MG_EINVAL (-1)  /* bad shape / flag combination */
+#define MG_ELAUNCH (-2) /* hip launch error */
+#define MG_EWORKSPACE (-3)
+
+int mg_version(void);
+const char* mg_last_error(void);
+
+/* ------------------------------------------------------------------ 3x3 convolution, stride 1, pad 1
+ * Replaces nn.Conv2d(k=3,s=1,p=1) [generator.py:16-22,31-37; discriminator.py:15-21,26-32] fused with what follows it:
+ * LeakyReLU(0.2) [generator.py:23,38; discriminator.py:22,33], PixelNorm [layers.py:11-17], and with what precedes it
+ * in the generator, nn.Upsample(x2, nearest) [generator.py:26-29].  The same kernel evaluates the data gradient
+ * (aten::convolution_backward, input grad) when given weights packed with dgrad=1.
+ */
+#define MG_CONV_UPS_IN 1   /* logical input = nearest-upsample x2 of x (x is N,Cin,H/2,W/2) */
+#define MG_CONV_LRELU 2    /* y = leaky_relu(acc + bias, slope) */
+#define MG_CONV_MASK_AUX 4 /* y = acc * (aux > 0 ? 1 : slope): LeakyReLU backward fused on the output (aux: N,Cout,H,W) */
+#define MG_CONV_PIXNORM 8  /* also emit p = y * rn and rn = 1/sqrt(mean_c(y^2)+1e-8) (needs MG_CONV_LRELU) */
+
+/* number of floats of the packed (LDS-image) weight layout for a Cin->Cout conv */
+size_t mg_conv3x3_packed_floats(int Cin, int Cout);
+/* w is the module weight [Co][Ci][3][3].  dgrad=0: pack for the forward conv Ci->Co.  dgrad=1: pack for the data-gradient
+ * conv Co->Ci (taps flipped, channels transposed). */
+int mg_conv3x3_pack(const float* w, float* wp, int Co, int Ci, int dgrad, mg_stream_t stream);
+/* y[N,Cout,H,W] = epilogue(conv3x3(x, wp) + bias).  bias/aux/p/rn may be NULL when the flag that uses them is unset. */
+int mg_conv3x3(const float* x, const float* wp, const float* bias, const float* aux, float* y, float* p, float* rn,
+               int N, int Cin, int Cout, int H, int W, int flags, float slope, mg_stream_t stream);
+
+/* weight/bias gradient of the same conv (aten::convolution_backward, weight+bias grads):
+ *   gw[Cout][Cin][3][3] (+)= sum_{n,y,x} gy[n,o,y,x] * xin[n,c,y+ky-1,x+kx-1],  gb[Cout] (+)= sum gy   (gb may be NULL)
+ * flags: MG_CONV_UPS_IN as above; accumulate!=0 adds to gw/gb instead of overwriting.  ws: scratch of
+ * mg_conv3x3_wgrad_ws_bytes() bytes (split-K partial slabs, reduced in a fixed order => deterministic). */
+size_t mg_conv3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W);
+int mg_conv3x3_wgrad(const float* x, const float* gy, float* gw, float* gb, void* ws, size_t ws_bytes, int N, int Cin,
+                     int Cout, int H, int W, int flags, int accumulate, mg_stream_t stream);
+
+/* ------------------------------------------------------------------ 1x1 convolutions (stem 2->C, head C->2)
+ * Replaces MagPhaseLayer [discriminator.py:37-50] and ToMagnPhaseLayer [generator.py:43-52].  One of Cin/Cout must be <= 4.
+ */
+#define MG_C1_LRELU 1      /* y = leaky_relu(.) */
+#define MG_C1_TANH 2       /* y = tanh(.) */
+#define MG_C1_MASK_AUX 4   /* Cin<=4: y = acc * (aux > 0 ? 1 : slope), aux is N,Cout,HW (output side);
+                            * Cout<=4 (Cin>4): x is first multiplied by (aux > 0 ? 1 : slope), aux is N,Cin,HW (input side) */
+#define MG_C1_TRANSPOSED 8 /* use w^T: w is [Cin][Cout] in memory (data gradient of the forward conv) */
+#define MG_C1_TANH_BWD_IN 16 /* input is gy*(1-aux_in^2): tanh backward fused on the INPUT side (aux_in: N,Cin,HW) */
+int mg_conv1x1(const float* x, const float* w, const float* bias, const float* aux, float* y, int N, int Cin, int Cout,
+               int HW, int flags, float slope, mg_stream_t stream);
+/* gw[Cout][Cin] (+)= sum gy*x, gb (+)= sum gy; if tanh_y != NULL gy is first multiplied by (1 - tanh_y^2). */
+size_t mg_conv1x1_wgrad_ws_bytes(int N, int Cin, int Cout, int HW);
+int mg_conv1x1_wgrad(const float* x, const float* gy, const float* tanh_y, float* gw, float* gb, void* ws,
+                     size_t ws_bytes, int N, int Cin, int Cout, int HW, int accumulate, mg_stream_t stream);
+
+/* ------------------------------------------------------------------ element-wise / small ops */
+/* PixelNorm forward [layers.py:11-17]: p = y*rn, rn[n,hw] = 1/sqrt(mean_c y^2 + 1e-8) */
+int mg_pixelnorm_fwd(const float* y, float* p, float* rn, int N, int C, int HW, mg_stream_t stream);
+/* backward through PixelNorm then LeakyReLU: gpre = mask(y) * rn * (gp - p * mean_c(gp * p)), p = y*rn */
+int mg_pixelnorm_lrelu_bwd(const float* gp, const float* y, const float* rn, float* gpre, int N, int C, int HW,
+                           float slope, mg_stream_t stream);
+/* nn.Upsample(x2 nearest) forward / backward (sum of each 2x2 block) [generator.py:26-29,99-102] */
+int mg_upsample2x_fwd(const float* x, float* y, int NC, int Hin, int Win, mg_stream_t stream);
+int mg_upsample2x_bwd(const float* gy, float* gx, int NC, int Hin, int Win, mg_stream_t stream);
+/* nn.AvgPool2d(2,2) forward [discriminator.py:24,131]; backward fused with the LeakyReLU mask of the layer below:
+ * gx = 0.25 * gy[.., h/2, w/2] * (act > 0 ? 1 : slope)   (act NULL => no mask) */
+int mg_avgpool2_fwd(const float* x, float* y, int NC, int H, int W, mg_stream_t stream);
+int mg_avgpool2_bwd(const float* gy, const float* act, float* gx, int NC, int H, int W, float slope,
+                    mg_stream_t stream);
+/* out = g * (act > 0 ? 1 : slope) */
+int mg_lrelu_bwd(const float* g, const float* act, float* out, size_t n, float slope, mg_stream_t stream);
+/* out = a*x + b*y (fade-in blend [generator.py:124, discriminator.py:113]); y may be NULL (out = a*x) */
+int mg_axpby(float a, const float* x, float b, const float* y, float* out, size_t n, mg_stream_t stream);
+/* out[n,c,h,w] = a*x[n,c,h,w] + b*up2(y)[n,c,h,w], y is (NC, H/2, W/2) */
+int mg_blend_up(float a, const float* x, float b, const float* y, float* out, int NC, int H, int W,
+                mg_stream_t stream);
+/* Linear(K -> 1) [discriminator.py:103-105]: y[n] = b + sum_k w[k] x[n,k] */
+int mg_linear1_fwd(const float* x, const float* w, const float* b, float* y, int N, int K, mg_stream_t stream);
+/* gx[n,k] = gy[n]*w[k]; gw[k] (+)= sum_n gy[n] x[n,k]; gb (+)= sum_n gy[n]   (gx/gw/gb may be NULL) */
+int mg_linear1_bwd(const float* x, const float* w, const float* gy, float* gx, float* gw, float* gb, int N, int K,
+                   int accumulate, mg_stream_t stream);
+/* gradient-penalty helpers [discriminator.py:166-184] */
+int mg_gp_interp(const float* x_real, const float* x_fake, const float* eps, float* out, int N, size_t chw,
+                 mg_stream_t stream); /* out = eps[n]*real + (1-eps[n])*fake */
+int mg_sumsq_per_sample(const float* g, float* out, int N, size_t chw, mg_stream_t stream);
+int mg_scale_per_sample(const float* g, const float* coef, float* out, int N, size_t chw, mg_stream_t stream);
+/* tiny: from sumsq[N] compute penalty = factor*mean((sqrt(ss)-1)^2) and coef[n] = upstream*factor*2*(norm-1)/(N*norm) */
+int mg_gp_finish(const float* sumsq, float* penalty, float* coef, int N, float factor, float upstream,
+                 mg_stream_t stream);
+/* sum over (n, hw) of a per-channel tensor: out[c] (+)= sum x[n,c,hw] */
+int mg_channel_sum(const float* x, float* out, int N, int C, int HW, int accumulate, mg_stream_t stream);
+
+/* ------------------------------------------------------------------ fused Adam [train.py:64-70,175,214]
+ * Multi-tensor torch.optim.Adam step (amsgrad off, weight_decay 0).  desc is a DEVICE array of n_tensors records. */
+typedef struct {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t numel;
+  float step_size;  /* lr / (1 - beta1^step), step = count AFTER this update (>= 1) */
+  float bc2_sqrt;   /* sqrt(1 - beta2^step) */
+} mg_adam_tensor_t;
+int mg_adam_step(const mg_adam_tensor_t* desc, int n_tensors, float beta1, float beta2, float eps, float grad_scale,
+                 mg_stream_t stream);
+
+/* ------------------------------------------------------------------ STFT [audio/functions.py:38-62]
+ * wav: mono fp32 [L]; out_re/out_im: [512][T] (freq-major, Nyquist row dropped), T = 1 + L/256.  Periodic Hann(1024),
+ * centre reflect padding, hop 256, divided by sqrt(sum w^2).  If out_im == NULL, out_re is interleaved complex64 [512][T][2]. */
+int mg_stft_1024(const float* wav, float* out_re, float* out_im, int64_t L, mg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

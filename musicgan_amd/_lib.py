@@ -1,0 +1,84 @@
+"""ctypes binding of libmusicgan_hip.so (the C ABI declared in include/musicgan_hip.h).
+
+There is NO CPU or eager-PyTorch fallback: if the library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmusicgan_hip.so")
+
+MG_CONV_UPS_IN, MG_CONV_LRELU, MG_CONV_MASK_AUX, MG_CONV_PIXNORM = 1, 2, 4, 8
+MG_C1_LRELU, MG_C1_TANH, MG_C1_MASK_AUX, MG_C1_TRANSPOSED, MG_C1_TANH_BWD_IN = 1, 2, 4, 8, 16
+
+
+class MusicGanHipError(RuntimeError):
+    pass
+
+
+class AdamTensor(Structure):
+    _fields_ = [("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p),
+                ("numel", c_int64), ("step_size", c_float), ("bc2_sqrt", c_float)]
+
+
+_P = c_void_p
+# name -> (restype, argtypes); every entry must be exported by the library (checked by tests/test_abi.py)
+SIGNATURES = {
+    "mg_version": (c_int, []),
+    "mg_last_error": (c_char_p, []),
+    "mg_conv3x3_packed_floats": (c_size_t, [c_int, c_int]),
+    "mg_conv3x3_pack": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "mg_conv3x3": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
+    "mg_conv3x3_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "mg_conv3x3_wgrad": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "mg_conv1x1": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
+    "mg_conv1x1_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "mg_conv1x1_wgrad": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, _P]),
+    "mg_pixelnorm_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
+    "mg_pixelnorm_lrelu_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
+    "mg_upsample2x_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "mg_upsample2x_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "mg_avgpool2_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "mg_avgpool2_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, _P]),
+    "mg_lrelu_bwd": (c_int, [_P, _P, _P, c_size_t, c_float, _P]),
+    "mg_axpby": (c_int, [c_float, _P, c_float, _P, _P, c_size_t, _P]),
+    "mg_blend_up": (c_int, [c_float, _P, c_float, _P, _P, c_int, c_int, c_int, _P]),
+    "mg_linear1_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
+    "mg_linear1_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "mg_gp_interp": (c_int, [_P, _P, _P, _P, c_int, c_size_t, _P]),
+    "mg_sumsq_per_sample": (c_int, [_P, _P, c_int, c_size_t, _P]),
+    "mg_scale_per_sample": (c_int, [_P, _P, _P, c_int, c_size_t, _P]),
+    "mg_gp_finish": (c_int, [_P, _P, _P, c_int, c_float, c_float, _P]),
+    "mg_channel_sum": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "mg_adam_step": (c_int, [_P, c_int, c_float, c_float, c_float, c_float, _P]),
+    "mg_stft_1024": (c_int, [_P, _P, _P, c_int64, _P]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared library (once).  Raises MusicGanHipError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MusicGanHipError(
+            f"{LIB_PATH} not found: build it with `python -m musicgan_amd._build` (hipcc, gfx950). "
+            "musicgan_amd has no CPU / eager fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == ABI mismatch, fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().mg_last_error()
+        raise MusicGanHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

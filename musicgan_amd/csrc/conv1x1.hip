@@ -1,0 +1,349 @@
+// 1x1 convolutions where one side has <= 4 channels: the discriminator stem MagPhaseLayer (2 -> C, + LeakyReLU)
+// [/root/reference/music_gan/networks/discriminator.py:37-50] and the generator head ToMagnPhaseLayer (C -> 2, + tanh)
+// [generator.py:43-52], their data gradients (weights used transposed) and weight/bias gradients.
+// These are HBM-bound streams (2 <-> 48..160 channels per pixel): one thread owns 4 consecutive pixels (16-byte
+// accesses), channel loops run in registers, weights come through the scalar cache.
+#include "mg_common.h"
+
+namespace {
+
+constexpr int FEW = 4;
+
+struct C1Args {
+  const float* x;
+  const float* w;
+  const float* bias;
+  const float* aux;
+  float* y;
+  int N, Cin, Cout, HW;
+  int so, sc;  // weight element (o,c) at w[o*so + c*sc]
+  int flags;
+  float slope;
+};
+
+template <int V>
+__device__ __forceinline__ void load_v(const float* p, float (&out)[V]) {
+  if constexpr (V == 4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    out[0] = t[0]; out[1] = t[1]; out[2] = t[2]; out[3] = t[3];
+  } else {
+#pragma unroll
+    for (int v = 0; v < V; ++v) out[v] = p[v];
+  }
+}
+
+// few input channels (Cin <= 4): out[o] = act(b[o] + sum_c w[o][c] x[c])
+template <int V>
+__global__ void __launch_bounds__(256) conv1x1_few_in(const C1Args a) {
+  const int q = a.HW / V;  // pixel groups per image
+  const size_t total = (size_t)a.N * q;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / q);
+    const int p = (int)(i - (size_t)n * q) * V;
+    float xv[FEW][V];
+#pragma unroll
+    for (int c = 0; c < FEW; ++c) {
+      if (c < a.Cin) {
+        const size_t idx = ((size_t)n * a.Cin + c) * a.HW + p;
+        load_v<V>(a.x + idx, xv[c]);
+        if (a.flags & MG_C1_TANH_BWD_IN) {
+          float tv[V];
+          load_v<V>(a.aux + idx, tv);
+#pragma unroll
+          for (int v = 0; v < V; ++v) xv[c][v] *= (1.f - tv[v] * tv[v]);
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < V; ++v) xv[c][v] = 0.f;
+      }
+    }
+    for (int o = 0; o < a.Cout; ++o) {
+      const float b = a.bias ? a.bias[o] : 0.f;
+      float acc[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[v] = b;
+#pragma unroll
+      for (int c = 0; c < FEW; ++c) {
+        if (c < a.Cin) {
+          const float wv = a.w[o * a.so + c * a.sc];
+#pragma unroll
+          for (int v = 0; v < V; ++v) acc[v] = fmaf(wv, xv[c][v], acc[v]);
+        }
+      }
+      const size_t oidx = ((size_t)n * a.Cout + o) * a.HW + p;
+      float mv[V];
+      if (a.flags & MG_C1_MASK_AUX) load_v<V>(a.aux + oidx, mv);
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        float r = acc[v];
+        if (a.flags & MG_C1_LRELU) r = mg_lrelu(r, a.slope);
+        if (a.flags & MG_C1_TANH) r = tanhf(r);
+        if (a.flags & MG_C1_MASK_AUX) r *= mg_lrelu_mask(mv[v], a.slope);
+        acc[v] = r;
+      }
+      if (V == 4) {
+        *reinterpret_cast<f32x4*>(a.y + oidx) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+      } else {
+#pragma unroll
+        for (int v = 0; v < V; ++v) a.y[oidx + v] = acc[v];
+      }
+    }
+  }
+}
+
+// few output channels (Cout <= 4): out[o] = act(b[o] + sum_c w[o][c] x[c]),  x streamed once
+template <int V>
+__global__ void __launch_bounds__(256) conv1x1_few_out(const C1Args a) {
+  const int q = a.HW / V;
+  const size_t total = (size_t)a.N * q;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / q);
+    const int p = (int)(i - (size_t)n * q) * V;
+    float acc[FEW][V];
+#pragma unroll
+    for (int o = 0; o < FEW; ++o) {
+      const float b = (a.bias && o < a.Cout) ? a.bias[o] : 0.f;
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[o][v] = b;
+    }
+    const float* xp = a.x + (size_t)n * a.Cin * a.HW + p;
+#pragma unroll 4
+    for (int c = 0; c < a.Cin; ++c) {
+      float xv[V];
+      load_v<V>(xp + (size_t)c * a.HW, xv);
+      if (a.flags & MG_C1_MASK_AUX) {  // mask on the INPUT side for this variant: x * lrelu'(aux_in)
+        float mv[V];
+        load_v<V>(a.aux + ((size_t)n * a.Cin + c) * a.HW + p, mv);
+#pragma unroll
+        for (int v = 0; v < V; ++v) xv[v] *= mg_lrelu_mask(mv[v], a.slope);
+      }
+#pragma unroll
+      for (int o = 0; o < FEW; ++o) {
+        if (o < a.Cout) {
+          const float wv = a.w[o * a.so + c * a.sc];
+#pragma unroll
+          for (int v = 0; v < V; ++v) acc[o][v] = fmaf(wv, xv[v], acc[o][v]);
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < FEW; ++o) {
+      if (o < a.Cout) {
+        const size_t oidx = ((size_t)n * a.Cout + o) * a.HW + p;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          float r = acc[o][v];
+          if (a.flags & MG_C1_LRELU) r = mg_lrelu(r, a.slope);
+          if (a.flags & MG_C1_TANH) r = tanhf(r);
+          acc[o][v] = r;
+        }
+        if (V == 4) {
+          *reinterpret_cast<f32x4*>(a.y + oidx) = f32x4{acc[o][0], acc[o][1], acc[o][2], acc[o][3]};
+        } else {
+#pragma unroll
+          for (int v = 0; v < V; ++v) a.y[oidx + v] = acc[o][v];
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- weight / bias gradient
+// M = the many-channel tensor, F = the few-channel one.  S[m][f] = sum_{n,p} M[m] F[f];  sums of gy per channel.
+constexpr int MC = 16;  // many-channels per grid.y slice
+struct W1Args {
+  const float* many;
+  const float* few;
+  const float* tanh_few;  // optional: few *= (1 - tanh_few^2)
+  float* part;            // [gridDim.x][Mtot*(F+1) + F]
+  int N, Cm, Cf, HW;
+};
+
+template <int V>
+__global__ void __launch_bounds__(256) conv1x1_wgrad_part(const W1Args a) {
+  __shared__ float red[4][MC * (FEW + 1) + FEW];
+  const int m0 = blockIdx.y * MC;
+  const int q = a.HW / V;
+  const size_t total = (size_t)a.N * q;
+  float s[MC][FEW], sm[MC], sf[FEW];
+#pragma unroll
+  for (int m = 0; m < MC; ++m) {
+    sm[m] = 0.f;
+#pragma unroll
+    for (int f = 0; f < FEW; ++f) s[m][f] = 0.f;
+  }
+#pragma unroll
+  for (int f = 0; f < FEW; ++f) sf[f] = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / q);
+    const int p = (int)(i - (size_t)n * q) * V;
+    float fv[FEW][V];
+#pragma unroll
+    for (int f = 0; f < FEW; ++f) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) fv[f][v] = 0.f;
+      if (f < a.Cf) {
+        const size_t idx = ((size_t)n * a.Cf + f) * a.HW + p;
+        load_v<V>(a.few + idx, fv[f]);
+        if (a.tanh_few) {
+          float th[V];
+          load_v<V>(a.tanh_few + idx, th);
+#pragma unroll
+          for (int v = 0; v < V; ++v) fv[f][v] *= (1.f - th[v] * th[v]);
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v) sf[f] += fv[f][v];
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MC; ++m) {
+      if (m0 + m < a.Cm) {
+        const size_t idx = ((size_t)n * a.Cm + m0 + m) * a.HW + p;
+        float mv[V];
+        load_v<V>(a.many + idx, mv);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          sm[m] += mv[v];
+#pragma unroll
+          for (int f = 0; f < FEW; ++f) s[m][f] = fmaf(mv[v], fv[f][v], s[m][f]);
+        }
+      }
+    }
+  }
+  // wave reduce, then across the 4 waves through LDS
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  auto wred = [&](float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+  };
+#pragma unroll
+  for (int m = 0; m < MC; ++m) {
+#pragma unroll
+    for (int f = 0; f < FEW; ++f) {
+      const float r = wred(s[m][f]);
+      if (lane == 0) red[wave][m * (FEW + 1) + f] = r;
+    }
+    const float r = wred(sm[m]);
+    if (lane == 0) red[wave][m * (FEW + 1) + FEW] = r;
+  }
+#pragma unroll
+  for (int f = 0; f < FEW; ++f) {
+    const float r = wred(sf[f]);
+    if (lane == 0) red[wave][MC * (FEW + 1) + f] = r;
+  }
+  __syncthreads();
+  const int per = MC * (FEW + 1) + FEW;
+  if ((int)threadIdx.x < per) {
+    const float r = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    a.part[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * per + threadIdx.x] = r;
+  }
+}
+
+// final: gw[o][c], gb[o].  gy_is_many: gy = many tensor (stem: Cout = Cm, Cin = Cf) else gy = few (head: Cout = Cf, Cin = Cm)
+__global__ void conv1x1_wgrad_final(const float* __restrict__ part, int nx, int ny, int Cm, int Cf, int gy_is_many,
+                                    float* __restrict__ gw, float* __restrict__ gb, int accumulate) {
+  const int per = MC * (FEW + 1) + FEW;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nprod = Cm * Cf;
+  const int Cout = gy_is_many ? Cm : Cf;
+  if (e < nprod) {
+    const int m = e / Cf, f = e - m * Cf;
+    const int by = m / MC, ml = m - by * MC;
+    float s = 0.f;
+    for (int bx = 0; bx < nx; ++bx) s += part[((size_t)bx * ny + by) * per + ml * (FEW + 1) + f];
+    const int idx = gy_is_many ? m * Cf + f : f * Cm + m;  // gw[o][c]
+    gw[idx] = accumulate ? gw[idx] + s : s;
+  } else if (gb != nullptr && e < nprod + Cout) {
+    const int o = e - nprod;
+    float s = 0.f;
+    if (gy_is_many) {
+      const int by = o / MC, ml = o - by * MC;
+      for (int bx = 0; bx < nx; ++bx) s += part[((size_t)bx * ny + by) * per + ml * (FEW + 1) + FEW];
+    } else {
+      for (int bx = 0; bx < nx; ++bx) s += part[((size_t)bx * ny + 0) * per + MC * (FEW + 1) + o];
+    }
+    gb[o] = accumulate ? gb[o] + s : s;
+  }
+}
+
+int c1_grid(size_t work_items) {
+  size_t b = (work_items + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+int w1_nx(int N, int HW) {
+  size_t q = (size_t)N * (HW / ((HW & 3) == 0 ? 4 : 1));
+  size_t b = (q + 255) / 256;
+  if (b > 256) b = 256;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int mg_conv1x1(const float* x, const float* w, const float* bias, const float* aux, float* y, int N, int Cin,
+                          int Cout, int HW, int flags, float slope, mg_stream_t stream) {
+  MG_CHECK_ARG(x && w && y && N > 0 && Cin > 0 && Cout > 0 && HW > 0, "mg_conv1x1: bad arguments");
+  MG_CHECK_ARG(Cin <= FEW || Cout <= FEW, "mg_conv1x1: needs Cin<=4 or Cout<=4 (got %d -> %d)", Cin, Cout);
+  MG_CHECK_ARG(!(flags & (MG_C1_MASK_AUX | MG_C1_TANH_BWD_IN)) || aux, "mg_conv1x1: aux flag without aux");
+  C1Args a;
+  a.x = x; a.w = w; a.bias = bias; a.aux = aux; a.y = y;
+  a.N = N; a.Cin = Cin; a.Cout = Cout; a.HW = HW;
+  if (flags & MG_C1_TRANSPOSED) { a.so = 1; a.sc = Cout; } else { a.so = Cin; a.sc = 1; }
+  a.flags = flags; a.slope = slope;
+  const bool vec = (HW & 3) == 0;
+  const int grid = c1_grid((size_t)N * (vec ? HW / 4 : HW));
+  hipStream_t s = (hipStream_t)stream;
+  if (Cin <= FEW) {
+    // few-in: MASK_AUX applies to the OUTPUT; TANH_BWD_IN to the input
+    if (vec) hipLaunchKernelGGL(conv1x1_few_in<4>, dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(conv1x1_few_in<1>, dim3(grid), dim3(256), 0, s, a);
+  } else {
+    // few-out: MASK_AUX applies to the INPUT (aux has Cin channels)
+    MG_CHECK_ARG(!(flags & MG_C1_TANH_BWD_IN), "mg_conv1x1: TANH_BWD_IN needs Cin<=4");
+    if (vec) hipLaunchKernelGGL(conv1x1_few_out<4>, dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(conv1x1_few_out<1>, dim3(grid), dim3(256), 0, s, a);
+  }
+  MG_CHECK_LAUNCH("mg_conv1x1");
+  return MG_OK;
+}
+
+extern "C" size_t mg_conv1x1_wgrad_ws_bytes(int N, int Cin, int Cout, int HW) {
+  const int Cm = Cin > Cout ? Cin : Cout;
+  const int ny = mg_cdiv(Cm, MC);
+  return (size_t)w1_nx(N, HW) * ny * (MC * (FEW + 1) + FEW) * sizeof(float);
+}
+
+extern "C" int mg_conv1x1_wgrad(const float* x, const float* gy, const float* tanh_y, float* gw, float* gb, void* ws,
+                                size_t ws_bytes, int N, int Cin, int Cout, int HW, int accumulate,
+                                mg_stream_t stream) {
+  MG_CHECK_ARG(x && gy && gw && ws && N > 0 && Cin > 0 && Cout > 0 && HW > 0, "mg_conv1x1_wgrad: bad arguments");
+  MG_CHECK_ARG(Cin <= FEW || Cout <= FEW, "mg_conv1x1_wgrad: needs Cin<=4 or Cout<=4");
+  const bool gy_is_many = Cout > Cin;
+  MG_CHECK_ARG(!(tanh_y && gy_is_many), "mg_conv1x1_wgrad: tanh backward only on the few-channel side");
+  if (ws_bytes < mg_conv1x1_wgrad_ws_bytes(N, Cin, Cout, HW)) {
+    mg_set_error("mg_conv1x1_wgrad: workspace too small");
+    return MG_EWORKSPACE;
+  }
+  W1Args a;
+  a.many = gy_is_many ? gy : x;
+  a.few = gy_is_many ? x : gy;
+  a.tanh_few = tanh_y;
+  a.part = reinterpret_cast<float*>(ws);
+  a.N = N; a.HW = HW;
+  a.Cm = gy_is_many ? Cout : Cin;
+  a.Cf = gy_is_many ? Cin : Cout;
+  const int nx = w1_nx(N, HW), ny = mg_cdiv(a.Cm, MC);
+  hipStream_t s = (hipStream_t)stream;
+  if ((HW & 3) == 0) hipLaunchKernelGGL(conv1x1_wgrad_part<4>, dim3(nx, ny), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(conv1x1_wgrad_part<1>, dim3(nx, ny), dim3(256), 0, s, a);
+  MG_CHECK_LAUNCH("mg_conv1x1_wgrad");
+  const int total = a.Cm * a.Cf + Cout;
+  hipLaunchKernelGGL(conv1x1_wgrad_final, dim3(mg_cdiv(total, 128)), dim3(128), 0, s, a.part, nx, ny, a.Cm, a.Cf,
+                     gy_is_many ? 1 : 0, gw, gb, accumulate);
+  MG_CHECK_LAUNCH("mg_conv1x1_wgrad(final)");
+  return MG_OK;
+}

@@ -1,0 +1,359 @@
+// 3x3 / stride 1 / pad 1 convolution as an implicit GEMM on the exact-fp32 matrix cores of gfx950
+// (v_mfma_f32_16x16x4_f32), forward and data-gradient (the latter through re-packed weights).
+//
+// Replaces nn.Conv2d(3x3) + LeakyReLU (+ PixelNorm) (+ preceding nearest Upsample) of
+//   /root/reference/music_gan/networks/generator.py:9-40 and discriminator.py:8-34.
+//
+// GEMM view:  D[pixel, out-channel] = sum_{tap, c} X[pixel + tap, c] * W[tap, c, out-channel]
+//   M (A rows)  = 16 output pixels per MFMA tile (lane&15), MI tiles per wave, 4 waves per workgroup
+//   N (B cols)  = 16 output channels per MFMA tile, NI tiles per wave (a wave sees ALL channels of its pixels, so the
+//                 PixelNorm channel reduction stays inside the wave)
+//   K           = 4 input channels of one tap per MFMA (lane>>4), 8-channel chunks staged through LDS
+// LDS image per chunk: input halo tile [8][ch_stride] (ch_stride % 32 == 16 => the two k-lanes of a half-wave hit disjoint
+// banks) and weights [9 taps][8 ch][OPL] copied verbatim from the pre-packed global layout (OPL % 32 == 16, same reason).
+// D layout (16x16x4): lane holds out-channel (lane&15) of pixels 4*(lane>>4)+{0..3} => one 16-byte store per tile.
+#include "mg_common.h"
+
+namespace {
+
+constexpr int CC = 8;  // input channels per LDS chunk
+constexpr float PN_EPS = 1e-8f;
+
+struct ConvArgs {
+  const float* x;
+  const float* wp;
+  const float* bias;
+  const float* aux;
+  float* y;
+  float* p;
+  float* rn;
+  int N, Cin, Cout, H, W, Hin, Win;
+  int flags;
+  float slope;
+  int TH, TW, TN, lgTH, lgTW, THp, TWp;
+  int tiles_x, tiles_y, tiles_n;
+  int plane, ch_stride, tab_floats;
+  int OPF;  // row stride of the packed weights (floats) = 16*ceil(Cout/16)
+  int nchunk;
+};
+
+template <int NI, int MI>
+__global__ void __launch_bounds__(256) conv3x3_mfma(const ConvArgs a) {
+  constexpr int OPL = (NI & 1) ? NI * 16 : NI * 16 + 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int* tab = reinterpret_cast<int*>(smem);
+  float* in_t = smem + a.tab_floats;
+  float* w_t = in_t + CC * a.ch_stride;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 15, rq = lane >> 4;
+  const int bid = mg_xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = bid % a.tiles_x;
+  const int t2 = bid / a.tiles_x;
+  const int ty = t2 % a.tiles_y;
+  const int tn = t2 / a.tiles_y;
+  const int o0 = blockIdx.y * NI * 16;
+  const int HWin = a.Hin * a.Win;
+  const float* xn = a.x + (size_t)tn * a.TN * a.Cin * HWin;
+  const bool ups = (a.flags & MG_CONV_UPS_IN) != 0;
+
+  // source-offset table of the halo tile (chunk-invariant): -1 => zero padding / out of range
+  {
+    const int THpTWp = a.THp * a.TWp;
+    for (int pos = tid; pos < a.plane; pos += 256) {
+      const int n_l = pos / THpTWp;
+      const int rem = pos - n_l * THpTWp;
+      const int rr = rem / a.TWp;
+      const int cc = rem - rr * a.TWp;
+      const int n = tn * a.TN + n_l, Y = ty * a.TH + rr - 1, X = tx * a.TW + cc - 1;
+      const bool ok = (n < a.N) && (Y >= 0) && (Y < a.H) && (X >= 0) && (X < a.W);
+      const int sp = ups ? (Y >> 1) * a.Win + (X >> 1) : Y * a.Win + X;
+      tab[pos] = ok ? n_l * a.Cin * HWin + sp : -1;
+    }
+  }
+
+  int pix_off[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int p = (wave * MI + mi) * 16 + col;
+    const int c = p & (a.TW - 1);
+    const int r = (p >> a.lgTW) & (a.TH - 1);
+    const int n_l = p >> (a.lgTW + a.lgTH);
+    pix_off[mi] = (n_l * a.THp + r) * a.TWp + c + rq * a.ch_stride;
+  }
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int ch = 0; ch < a.nchunk; ++ch) {
+    __syncthreads();
+    {  // input halo tile: 8 half-waves, one channel each, 32 consecutive positions per pass
+      const int cl = tid >> 5, l32 = tid & 31;
+      const int c = ch * CC + cl;
+      const bool cok = c < a.Cin;
+      const float* xc = xn + (size_t)c * HWin;
+      float* dst = in_t + cl * a.ch_stride;
+#pragma unroll 4
+      for (int pos = l32; pos < a.plane; pos += 32) {
+        const int off = tab[pos];
+        float v = 0.f;
+        if (cok && off >= 0) v = xc[off];
+        dst[pos] = v;
+      }
+    }
+    {  // weights: verbatim 16-byte copy of this chunk's packed rows
+      const float* src = a.wp + (size_t)ch * (9 * CC) * a.OPF + o0;
+      for (int e = tid; e < 9 * CC * NI * 4; e += 256) {
+        const int row = e / (NI * 4);
+        const int j = e - row * (NI * 4);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)row * a.OPF + 4 * j);
+        *reinterpret_cast<f32x4*>(w_t + row * OPL + 4 * j) = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int tap = (t / 3) * a.TWp + (t % 3);
+#pragma unroll
+      for (int ks = 0; ks < CC / 4; ++ks) {
+        float av[MI], bv[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) av[mi] = in_t[pix_off[mi] + ks * 4 * a.ch_stride + tap];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bv[ni] = w_t[(t * CC + ks * 4 + rq) * OPL + ni * 16 + col];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  const bool lrelu = (a.flags & MG_CONV_LRELU) != 0;
+  const bool mask_aux = (a.flags & MG_CONV_MASK_AUX) != 0;
+  const bool pixnorm = (a.flags & MG_CONV_PIXNORM) != 0;
+  const bool vec = (a.TW >= 4) && ((a.W & 3) == 0);
+  float bv[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int o = o0 + ni * 16 + col;
+    bv[ni] = (a.bias != nullptr && o < a.Cout) ? a.bias[o] : 0.f;
+  }
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int pb = (wave * MI + mi) * 16 + rq * 4;
+    f32x4 rnv = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v = acc[mi][ni][g] + bv[ni];
+        if (lrelu) v = mg_lrelu(v, a.slope);
+        acc[mi][ni][g] = v;
+      }
+    }
+    if (pixnorm) {
+      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) s += acc[mi][ni] * acc[mi][ni];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float t = s[g];
+        t += __shfl_xor(t, 1);
+        t += __shfl_xor(t, 2);
+        t += __shfl_xor(t, 4);
+        t += __shfl_xor(t, 8);
+        rnv[g] = 1.0f / sqrtf(t / (float)a.Cout + PN_EPS);
+      }
+    }
+    if (vec) {
+      const int c = pb & (a.TW - 1);
+      const int r = (pb >> a.lgTW) & (a.TH - 1);
+      const int n_l = pb >> (a.lgTW + a.lgTH);
+      const int n = tn * a.TN + n_l, Y = ty * a.TH + r, X = tx * a.TW + c;
+      const bool valid = (n < a.N) && (Y < a.H) && (X < a.W);
+      if (valid) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int o = o0 + ni * 16 + col;
+          if (o < a.Cout) {
+            const size_t idx = (((size_t)n * a.Cout + o) * a.H + Y) * a.W + X;
+            f32x4 v = acc[mi][ni];
+            if (mask_aux) {
+              const f32x4 ax = *reinterpret_cast<const f32x4*>(a.aux + idx);
+#pragma unroll
+              for (int g = 0; g < 4; ++g) v[g] *= mg_lrelu_mask(ax[g], a.slope);
+            }
+            if (a.y != nullptr) *reinterpret_cast<f32x4*>(a.y + idx) = v;
+            if (pixnorm) *reinterpret_cast<f32x4*>(a.p + idx) = v * rnv;
+          }
+        }
+        if (pixnorm && col == 0 && a.rn != nullptr)
+          *reinterpret_cast<f32x4*>(a.rn + ((size_t)n * a.H + Y) * a.W + X) = rnv;
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int p = pb + g;
+        const int c = p & (a.TW - 1);
+        const int r = (p >> a.lgTW) & (a.TH - 1);
+        const int n_l = p >> (a.lgTW + a.lgTH);
+        const int n = tn * a.TN + n_l, Y = ty * a.TH + r, X = tx * a.TW + c;
+        const bool valid = (n < a.N) && (Y < a.H) && (X < a.W);
+        if (valid) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            const int o = o0 + ni * 16 + col;
+            if (o < a.Cout) {
+              const size_t idx = (((size_t)n * a.Cout + o) * a.H + Y) * a.W + X;
+              float v = acc[mi][ni][g];
+              if (mask_aux) v *= mg_lrelu_mask(a.aux[idx], a.slope);
+              if (a.y != nullptr) a.y[idx] = v;
+              if (pixnorm) a.p[idx] = v * rnv[g];
+            }
+          }
+          if (pixnorm && col == 0 && a.rn != nullptr) a.rn[((size_t)n * a.H + Y) * a.W + X] = rnv[g];
+        }
+      }
+    }
+  }
+}
+
+__global__ void conv3x3_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int dgrad,
+                                    int cin_call, int cout_call, int OPF, size_t total) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int o = (int)(e % OPF);
+  size_t r = e / OPF;
+  const int cl = (int)(r % CC);
+  r /= CC;
+  const int t = (int)(r % 9);
+  const int ch = (int)(r / 9);
+  const int c = ch * CC + cl;
+  float v = 0.f;
+  if (c < cin_call && o < cout_call) {
+    // dgrad=0: conv Ci->Co, W'[o][c][t] = w[o][c][t];  dgrad=1: conv Co->Ci, W'[o][c][t] = w[c][o][8-t]
+    v = dgrad ? w[((size_t)c * Ci + o) * 9 + (8 - t)] : w[((size_t)o * Ci + c) * 9 + t];
+  }
+  wp[e] = v;
+}
+
+template <int NI, int MI>
+int launch_conv(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  static bool attr_set = false;  // benign race: idempotent
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma<NI, MI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_mfma<NI, MI>), grid, dim3(256), lds, s, a);
+  MG_CHECK_LAUNCH("mg_conv3x3");
+  return MG_OK;
+}
+
+template <int MI>
+int dispatch_ni(int NI, const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  switch (NI) {
+    case 1: return launch_conv<1, MI>(a, grid, lds, s);
+    case 2: return launch_conv<2, MI>(a, grid, lds, s);
+    case 3: return launch_conv<3, MI>(a, grid, lds, s);
+    case 4: return launch_conv<4, MI>(a, grid, lds, s);
+    case 5: return launch_conv<5, MI>(a, grid, lds, s);
+    case 6: return launch_conv<6, MI>(a, grid, lds, s);
+    default: break;
+  }
+  if constexpr (MI <= 2) {
+    switch (NI) {
+      case 7: return launch_conv<7, MI>(a, grid, lds, s);
+      case 8: return launch_conv<8, MI>(a, grid, lds, s);
+      case 9: return launch_conv<9, MI>(a, grid, lds, s);
+      case 10: return launch_conv<10, MI>(a, grid, lds, s);
+      default: break;
+    }
+  }
+  mg_set_error("mg_conv3x3: unsupported tile NI=%d MI=%d", NI, MI);
+  return MG_EINVAL;
+}
+
+}  // namespace
+
+extern "C" size_t mg_conv3x3_packed_floats(int Cin, int Cout) {
+  return (size_t)mg_cdiv(Cin, CC) * 9 * CC * (size_t)(16 * mg_cdiv(Cout, 16));
+}
+
+extern "C" int mg_conv3x3_pack(const float* w, float* wp, int Co, int Ci, int dgrad, mg_stream_t stream) {
+  MG_CHECK_ARG(w && wp && Co > 0 && Ci > 0, "mg_conv3x3_pack: bad arguments");
+  const int cin_call = dgrad ? Co : Ci, cout_call = dgrad ? Ci : Co;
+  const int OPF = 16 * mg_cdiv(cout_call, 16);
+  const size_t total = mg_conv3x3_packed_floats(cin_call, cout_call);
+  const int blocks = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(conv3x3_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wp, Co, Ci, dgrad,
+                     cin_call, cout_call, OPF, total);
+  MG_CHECK_LAUNCH("mg_conv3x3_pack");
+  return MG_OK;
+}
+
+extern "C" int mg_conv3x3(const float* x, const float* wp, const float* bias, const float* aux, float* y, float* p,
+                          float* rn, int N, int Cin, int Cout, int H, int W, int flags, float slope,
+                          mg_stream_t stream) {
+  MG_CHECK_ARG(x && wp && N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "mg_conv3x3: bad arguments");
+  MG_CHECK_ARG(Cout <= 160, "mg_conv3x3: Cout=%d > 160 unsupported", Cout);
+  const bool ups = flags & MG_CONV_UPS_IN, pn = flags & MG_CONV_PIXNORM;
+  MG_CHECK_ARG(!ups || ((H % 2 == 0) && (W % 2 == 0)), "mg_conv3x3: upsampled input needs even H,W");
+  MG_CHECK_ARG(!(flags & MG_CONV_MASK_AUX) || aux, "mg_conv3x3: MASK_AUX without aux");
+  MG_CHECK_ARG(!pn || ((flags & MG_CONV_LRELU) && p), "mg_conv3x3: PIXNORM needs LRELU and p");
+  MG_CHECK_ARG(pn || y, "mg_conv3x3: y is NULL");
+  MG_CHECK_ARG(!((flags & MG_CONV_MASK_AUX) && (flags & (MG_CONV_LRELU | MG_CONV_PIXNORM))),
+               "mg_conv3x3: MASK_AUX excludes LRELU/PIXNORM");
+  const long long in_elems = (long long)N * Cin * (ups ? (H / 2) * (W / 2) : H * W);
+  MG_CHECK_ARG(in_elems < (1ll << 31) && (long long)N * Cout * H * W < (1ll << 40), "mg_conv3x3: tensor too large");
+
+  ConvArgs a;
+  a.x = x; a.wp = wp; a.bias = bias; a.aux = aux; a.y = y; a.p = p; a.rn = rn;
+  a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+  a.Hin = ups ? H / 2 : H; a.Win = ups ? W / 2 : W;
+  a.flags = flags; a.slope = slope;
+  const int NIfull = mg_cdiv(Cout, 16);
+  a.OPF = NIfull * 16;
+  a.nchunk = mg_cdiv(Cin, CC);
+
+  // tile selection: fill the chip first (>= ~2 workgroups per CU), then grow the per-wave pixel tile
+  const long long px = (long long)N * H * W;
+  int MI = NIfull <= 6 ? 4 : 2;
+  while (MI > 1 && px / (64 * MI) < 512) MI >>= 1;
+  int NI = NIfull;
+  if (!pn && MI == 1) {
+    const long long nwg = (px + 63) / 64;
+    if (nwg * 2 <= 256) NI = 1;
+    else if (nwg <= 256 && (NIfull % 2 == 0)) NI = 2;
+    if (NI > NIfull) NI = NIfull;
+  }
+  const int P = 64 * MI;
+  a.TW = mg_pow2_ceil(W) < 32 ? mg_pow2_ceil(W) : 32;
+  if (a.TW > P) a.TW = P;
+  a.TH = mg_pow2_ceil(H) < P / a.TW ? mg_pow2_ceil(H) : P / a.TW;
+  a.TN = P / (a.TW * a.TH);
+  a.lgTW = mg_ilog2(a.TW); a.lgTH = mg_ilog2(a.TH);
+  a.THp = a.TH + 2; a.TWp = a.TW + 2;
+  a.tiles_x = mg_cdiv(W, a.TW); a.tiles_y = mg_cdiv(H, a.TH); a.tiles_n = mg_cdiv(N, a.TN);
+  a.plane = a.TN * a.THp * a.TWp;
+  a.ch_stride = ((a.plane + 15) / 32) * 32 + 16;  // smallest s >= plane with s % 32 == 16
+  if (a.ch_stride < a.plane) a.ch_stride += 32;
+  a.tab_floats = (a.plane + 3) & ~3;
+  const int OPL = (NI & 1) ? NI * 16 : NI * 16 + 16;
+  const size_t lds = (size_t)(a.tab_floats + CC * a.ch_stride + 9 * CC * OPL) * sizeof(float);
+  MG_CHECK_ARG(lds <= 160 * 1024, "mg_conv3x3: LDS tile %zu B too large", lds);
+  dim3 grid(a.tiles_x * a.tiles_y * a.tiles_n, NIfull / NI);
+  MG_CHECK_ARG(NIfull % NI == 0, "mg_conv3x3: internal tile error");
+  hipStream_t s = (hipStream_t)stream;
+  switch (MI) {
+    case 4: return dispatch_ni<4>(NI, a, grid, lds, s);
+    case 2: return dispatch_ni<2>(NI, a, grid, lds, s);
+    default: return dispatch_ni<1>(NI, a, grid, lds, s);
+  }
+}

@@ -1,0 +1,499 @@
+// HBM-bound element-wise / reduction kernels of the ProGAN step: PixelNorm fwd/bwd, nearest x2 up-sampling and 2x2 average
+// pooling (both directions), LeakyReLU backward, fade-in blends, Linear(160->1), gradient-penalty helpers, fused Adam.
+// Reference ops: /root/reference/music_gan/networks/layers.py:11-17, generator.py:26-29,124, discriminator.py:24,103-124,
+// 166-184, train.py:64-70.  One thread owns 4 consecutive floats wherever the shape allows (16-byte accesses).
+#include "mg_common.h"
+
+namespace {
+
+constexpr float PN_EPS = 1e-8f;
+
+inline int ew_grid(size_t items) {
+  size_t b = (items + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+template <int V>
+__device__ __forceinline__ void ld(const float* p, float (&o)[V]) {
+  if constexpr (V == 4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3];
+  } else {
+#pragma unroll
+    for (int v = 0; v < V; ++v) o[v] = p[v];
+  }
+}
+template <int V>
+__device__ __forceinline__ void st(float* p, const float (&o)[V]) {
+  if constexpr (V == 4) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{o[0], o[1], o[2], o[3]};
+  } else {
+#pragma unroll
+    for (int v = 0; v < V; ++v) p[v] = o[v];
+  }
+}
+
+// ---------------------------------------------------------------- PixelNorm
+template <int V>
+__global__ void __launch_bounds__(256) pixelnorm_fwd_k(const float* __restrict__ y, float* __restrict__ p,
+                                                       float* __restrict__ rn, int N, int C, int HW) {
+  const int q = HW / V;
+  const size_t total = (size_t)N * q;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / q);
+    const int px = (int)(i - (size_t)n * q) * V;
+    const float* yp = y + (size_t)n * C * HW + px;
+    float ss[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) ss[v] = 0.f;
+    for (int c = 0; c < C; ++c) {
+      float t[V];
+      ld<V>(yp + (size_t)c * HW, t);
+#pragma unroll
+      for (int v = 0; v < V; ++v) ss[v] = fmaf(t[v], t[v], ss[v]);
+    }
+    float r[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) r[v] = 1.0f / sqrtf(ss[v] / (float)C + PN_EPS);
+    if (rn) st<V>(rn + (size_t)n * HW + px, r);
+    float* pp = p + (size_t)n * C * HW + px;
+    for (int c = 0; c < C; ++c) {
+      float t[V];
+      ld<V>(yp + (size_t)c * HW, t);
+#pragma unroll
+      for (int v = 0; v < V; ++v) t[v] *= r[v];
+      st<V>(pp + (size_t)c * HW, t);
+    }
+  }
+}
+
+template <int V>
+__global__ void __launch_bounds__(256) pixelnorm_lrelu_bwd_k(const float* __restrict__ gp, const float* __restrict__ y,
+                                                             const float* __restrict__ rn, float* __restrict__ gpre,
+                                                             int N, int C, int HW, float slope) {
+  const int q = HW / V;
+  const size_t total = (size_t)N * q;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / q);
+    const int px = (int)(i - (size_t)n * q) * V;
+    const size_t base = (size_t)n * C * HW + px;
+    float r[V], dot[V];
+    ld<V>(rn + (size_t)n * HW + px, r);
+#pragma unroll
+    for (int v = 0; v < V; ++v) dot[v] = 0.f;
+    for (int c = 0; c < C; ++c) {
+      float g[V], t[V];
+      ld<V>(gp + base + (size_t)c * HW, g);
+      ld<V>(y + base + (size_t)c * HW, t);
+#pragma unroll
+      for (int v = 0; v < V; ++v) dot[v] = fmaf(g[v], t[v] * r[v], dot[v]);
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) dot[v] /= (float)C;
+    for (int c = 0; c < C; ++c) {
+      float g[V], t[V], o[V];
+      ld<V>(gp + base + (size_t)c * HW, g);
+      ld<V>(y + base + (size_t)c * HW, t);
+#pragma unroll
+      for (int v = 0; v < V; ++v) o[v] = mg_lrelu_mask(t[v], slope) * r[v] * (g[v] - t[v] * r[v] * dot[v]);
+      st<V>(gpre + base + (size_t)c * HW, o);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- up-sampling / pooling
+__global__ void __launch_bounds__(256) upsample2x_fwd_k(const float* __restrict__ x, float* __restrict__ y, size_t total,
+                                                        int Hin, int Win) {
+  // one thread per INPUT element: writes its 2x2 block
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int w = (int)(i % Win);
+    const size_t r = i / Win;
+    const int h = (int)(r % Hin);
+    const size_t nc = r / Hin;
+    const float v = x[i];
+    float* o = y + (nc * (2 * Hin) + 2 * h) * (size_t)(2 * Win) + 2 * w;
+    *reinterpret_cast<float2*>(o) = make_float2(v, v);
+    *reinterpret_cast<float2*>(o + 2 * Win) = make_float2(v, v);
+  }
+}
+
+__global__ void __launch_bounds__(256) upsample2x_bwd_k(const float* __restrict__ gy, float* __restrict__ gx,
+                                                        size_t total, int Hin, int Win) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int w = (int)(i % Win);
+    const size_t r = i / Win;
+    const int h = (int)(r % Hin);
+    const size_t nc = r / Hin;
+    const float* s = gy + (nc * (2 * Hin) + 2 * h) * (size_t)(2 * Win) + 2 * w;
+    const float2 a = *reinterpret_cast<const float2*>(s);
+    const float2 b = *reinterpret_cast<const float2*>(s + 2 * Win);
+    gx[i] = (a.x + a.y) + (b.x + b.y);
+  }
+}
+
+__global__ void __launch_bounds__(256) avgpool2_fwd_k(const float* __restrict__ x, float* __restrict__ y, size_t total,
+                                                      int Ho, int Wo) {
+  // one thread per OUTPUT element
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int w = (int)(i % Wo);
+    const size_t r = i / Wo;
+    const int h = (int)(r % Ho);
+    const size_t nc = r / Ho;
+    const float* s = x + (nc * (2 * Ho) + 2 * h) * (size_t)(2 * Wo) + 2 * w;
+    const float2 a = *reinterpret_cast<const float2*>(s);
+    const float2 b = *reinterpret_cast<const float2*>(s + 2 * Wo);
+    y[i] = ((a.x + a.y) + (b.x + b.y)) * 0.25f;
+  }
+}
+
+__global__ void __launch_bounds__(256) avgpool2_bwd_k(const float* __restrict__ gy, const float* __restrict__ act,
+                                                      float* __restrict__ gx, size_t total, int Ho, int Wo,
+                                                      float slope) {
+  // one thread per pooled (gy) element: writes the 2x2 block of gx
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int w = (int)(i % Wo);
+    const size_t r = i / Wo;
+    const int h = (int)(r % Ho);
+    const size_t nc = r / Ho;
+    const float g = gy[i] * 0.25f;
+    const size_t o = (nc * (2 * Ho) + 2 * h) * (size_t)(2 * Wo) + 2 * w;
+    float2 m0 = make_float2(1.f, 1.f), m1 = make_float2(1.f, 1.f);
+    if (act) {
+      const float2 a0 = *reinterpret_cast<const float2*>(act + o);
+      const float2 a1 = *reinterpret_cast<const float2*>(act + o + 2 * Wo);
+      m0 = make_float2(mg_lrelu_mask(a0.x, slope), mg_lrelu_mask(a0.y, slope));
+      m1 = make_float2(mg_lrelu_mask(a1.x, slope), mg_lrelu_mask(a1.y, slope));
+    }
+    *reinterpret_cast<float2*>(gx + o) = make_float2(g * m0.x, g * m0.y);
+    *reinterpret_cast<float2*>(gx + o + 2 * Wo) = make_float2(g * m1.x, g * m1.y);
+  }
+}
+
+__global__ void __launch_bounds__(256) blend_up_k(float a, const float* __restrict__ x, float b,
+                                                  const float* __restrict__ ylow, float* __restrict__ out, size_t total,
+                                                  int Ho, int Wo) {
+  // one thread per LOW-res element: out 2x2 block = a*x + b*ylow
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int w = (int)(i % Wo);
+    const size_t r = i / Wo;
+    const int h = (int)(r % Ho);
+    const size_t nc = r / Ho;
+    const float yl = b * ylow[i];
+    const size_t o = (nc * (2 * Ho) + 2 * h) * (size_t)(2 * Wo) + 2 * w;
+    const float2 x0 = *reinterpret_cast<const float2*>(x + o);
+    const float2 x1 = *reinterpret_cast<const float2*>(x + o + 2 * Wo);
+    *reinterpret_cast<float2*>(out + o) = make_float2(fmaf(a, x0.x, yl), fmaf(a, x0.y, yl));
+    *reinterpret_cast<float2*>(out + o + 2 * Wo) = make_float2(fmaf(a, x1.x, yl), fmaf(a, x1.y, yl));
+  }
+}
+
+// ---------------------------------------------------------------- flat element-wise
+template <int V>
+__global__ void __launch_bounds__(256) lrelu_bwd_k(const float* __restrict__ g, const float* __restrict__ act,
+                                                   float* __restrict__ out, size_t nq, float slope) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (size_t)gridDim.x * blockDim.x) {
+    float a[V], b[V];
+    ld<V>(g + i * V, a);
+    ld<V>(act + i * V, b);
+#pragma unroll
+    for (int v = 0; v < V; ++v) a[v] *= mg_lrelu_mask(b[v], slope);
+    st<V>(out + i * V, a);
+  }
+}
+
+template <int V>
+__global__ void __launch_bounds__(256) axpby_k(float a, const float* __restrict__ x, float b,
+                                               const float* __restrict__ y, float* __restrict__ out, size_t nq) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (size_t)gridDim.x * blockDim.x) {
+    float xv[V], yv[V];
+    ld<V>(x + i * V, xv);
+    if (y) {
+      ld<V>(y + i * V, yv);
+#pragma unroll
+      for (int v = 0; v < V; ++v) xv[v] = a * xv[v] + b * yv[v];
+    } else {
+#pragma unroll
+      for (int v = 0; v < V; ++v) xv[v] = a * xv[v];
+    }
+    st<V>(out + i * V, xv);
+  }
+}
+
+template <int V>
+__global__ void __launch_bounds__(256) gp_interp_k(const float* __restrict__ xr, const float* __restrict__ xf,
+                                                   const float* __restrict__ eps, float* __restrict__ out, int N,
+                                                   size_t chwq) {
+  const size_t total = (size_t)N * chwq;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / chwq);
+    const float e = eps[n];
+    float a[V], b[V];
+    ld<V>(xr + i * V, a);
+    ld<V>(xf + i * V, b);
+#pragma unroll
+    for (int v = 0; v < V; ++v) a[v] = e * a[v] + (1.f - e) * b[v];
+    st<V>(out + i * V, a);
+  }
+}
+
+template <int V>
+__global__ void __launch_bounds__(256) scale_per_sample_k(const float* __restrict__ g, const float* __restrict__ coef,
+                                                          float* __restrict__ out, int N, size_t chwq) {
+  const size_t total = (size_t)N * chwq;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / chwq);
+    const float c = coef[n];
+    float a[V];
+    ld<V>(g + i * V, a);
+#pragma unroll
+    for (int v = 0; v < V; ++v) a[v] *= c;
+    st<V>(out + i * V, a);
+  }
+}
+
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float s = 0.f;
+  const int nw = (blockDim.x + 63) >> 6;
+  for (int k = 0; k < nw; ++k) s += red[k];
+  return s;
+}
+
+__global__ void __launch_bounds__(1024) sumsq_per_sample_k(const float* __restrict__ g, float* __restrict__ out,
+                                                           size_t chw) {
+  __shared__ float red[16];
+  const float* p = g + (size_t)blockIdx.x * chw;
+  float s = 0.f;
+  for (size_t i = threadIdx.x; i < chw; i += blockDim.x) s = fmaf(p[i], p[i], s);
+  s = block_sum_1024(s, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+
+__global__ void gp_finish_k(const float* __restrict__ sumsq, float* __restrict__ penalty, float* __restrict__ coef,
+                            int N, float factor, float upstream) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    const float nrm = sqrtf(sumsq[n]);
+    const float d = nrm - 1.f;
+    s += d * d;
+    if (coef) coef[n] = nrm > 0.f ? upstream * factor * 2.f * d / ((float)N * nrm) : 0.f;
+  }
+  s = block_sum_1024(s, red);
+  if (threadIdx.x == 0 && penalty) penalty[0] = factor * s / (float)N;
+}
+
+__global__ void __launch_bounds__(1024) channel_sum_k(const float* __restrict__ x, float* __restrict__ out, int N, int C,
+                                                      int HW, int accumulate) {
+  __shared__ float red[16];
+  const int c = blockIdx.x;
+  float s = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const float* p = x + ((size_t)n * C + c) * HW;
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) s += p[i];
+  }
+  s = block_sum_1024(s, red);
+  if (threadIdx.x == 0) out[c] = accumulate ? out[c] + s : s;
+}
+
+// ---------------------------------------------------------------- Linear(K -> 1)
+__global__ void __launch_bounds__(64) linear1_fwd_k(const float* __restrict__ x, const float* __restrict__ w,
+                                                    const float* __restrict__ b, float* __restrict__ y, int K) {
+  const int n = blockIdx.x;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < K; k += 64) s = fmaf(w[k], x[(size_t)n * K + k], s);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+  if (threadIdx.x == 0) y[n] = s + (b ? b[0] : 0.f);
+}
+
+__global__ void __launch_bounds__(256) linear1_bwd_k(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ gy, float* __restrict__ gx,
+                                                     float* __restrict__ gw, float* __restrict__ gb, int N, int K,
+                                                     int accumulate) {
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    const float wk = w[k];
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) {
+      const float g = gy[n];
+      if (gx) gx[(size_t)n * K + k] = g * wk;
+      if (gw) s = fmaf(g, x[(size_t)n * K + k], s);
+    }
+    if (gw) gw[k] = accumulate ? gw[k] + s : s;
+  }
+  if (gb && threadIdx.x == 0) {
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += gy[n];
+    gb[0] = accumulate ? gb[0] + s : s;
+  }
+}
+
+// ---------------------------------------------------------------- Adam
+__global__ void __launch_bounds__(256) adam_k(const mg_adam_tensor_t* __restrict__ desc, float beta1, float beta2,
+                                              float eps, float grad_scale) {
+  const mg_adam_tensor_t d = desc[blockIdx.y];
+  const float step_size = d.step_size, bc2s = d.bc2_sqrt;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.numel; i += (int64_t)gridDim.x * blockDim.x) {
+    const float g = d.grad[i] * grad_scale;
+    float m = d.exp_avg[i], v = d.exp_avg_sq[i];
+    m = m + (g - m) * (1.f - beta1);           // exp_avg.lerp_(grad, 1-beta1)
+    v = v * beta2 + (1.f - beta2) * g * g;     // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1-beta2)
+    const float denom = sqrtf(v) / bc2s + eps;
+    d.param[i] = d.param[i] - step_size * (m / denom);
+    d.exp_avg[i] = m;
+    d.exp_avg_sq[i] = v;
+  }
+}
+
+}  // namespace
+
+#define EW_LAUNCH(kernel, grid, block, ...)                                                   \
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, __VA_ARGS__)
+
+extern "C" int mg_pixelnorm_fwd(const float* y, float* p, float* rn, int N, int C, int HW, mg_stream_t stream) {
+  MG_CHECK_ARG(y && p && N > 0 && C > 0 && HW > 0, "mg_pixelnorm_fwd: bad arguments");
+  if ((HW & 3) == 0) EW_LAUNCH(pixelnorm_fwd_k<4>, ew_grid((size_t)N * HW / 4), 256, y, p, rn, N, C, HW);
+  else EW_LAUNCH(pixelnorm_fwd_k<1>, ew_grid((size_t)N * HW), 256, y, p, rn, N, C, HW);
+  MG_CHECK_LAUNCH("mg_pixelnorm_fwd");
+  return MG_OK;
+}
+
+extern "C" int mg_pixelnorm_lrelu_bwd(const float* gp, const float* y, const float* rn, float* gpre, int N, int C, int HW,
+                                      float slope, mg_stream_t stream) {
+  MG_CHECK_ARG(gp && y && rn && gpre && N > 0 && C > 0 && HW > 0, "mg_pixelnorm_lrelu_bwd: bad arguments");
+  if ((HW & 3) == 0)
+    EW_LAUNCH(pixelnorm_lrelu_bwd_k<4>, ew_grid((size_t)N * HW / 4), 256, gp, y, rn, gpre, N, C, HW, slope);
+  else EW_LAUNCH(pixelnorm_lrelu_bwd_k<1>, ew_grid((size_t)N * HW), 256, gp, y, rn, gpre, N, C, HW, slope);
+  MG_CHECK_LAUNCH("mg_pixelnorm_lrelu_bwd");
+  return MG_OK;
+}
+
+extern "C" int mg_upsample2x_fwd(const float* x, float* y, int NC, int Hin, int Win, mg_stream_t stream) {
+  MG_CHECK_ARG(x && y && NC > 0 && Hin > 0 && Win > 0, "mg_upsample2x_fwd: bad arguments");
+  const size_t total = (size_t)NC * Hin * Win;
+  EW_LAUNCH(upsample2x_fwd_k, ew_grid(total), 256, x, y, total, Hin, Win);
+  MG_CHECK_LAUNCH("mg_upsample2x_fwd");
+  return MG_OK;
+}
+
+extern "C" int mg_upsample2x_bwd(const float* gy, float* gx, int NC, int Hin, int Win, mg_stream_t stream) {
+  MG_CHECK_ARG(gy && gx && NC > 0 && Hin > 0 && Win > 0, "mg_upsample2x_bwd: bad arguments");
+  const size_t total = (size_t)NC * Hin * Win;
+  EW_LAUNCH(upsample2x_bwd_k, ew_grid(total), 256, gy, gx, total, Hin, Win);
+  MG_CHECK_LAUNCH("mg_upsample2x_bwd");
+  return MG_OK;
+}
+
+extern "C" int mg_avgpool2_fwd(const float* x, float* y, int NC, int H, int W, mg_stream_t stream) {
+  MG_CHECK_ARG(x && y && NC > 0 && H > 0 && W > 0 && (H % 2 == 0) && (W % 2 == 0), "mg_avgpool2_fwd: bad arguments");
+  const size_t total = (size_t)NC * (H / 2) * (W / 2);
+  EW_LAUNCH(avgpool2_fwd_k, ew_grid(total), 256, x, y, total, H / 2, W / 2);
+  MG_CHECK_LAUNCH("mg_avgpool2_fwd");
+  return MG_OK;
+}
+
+extern "C" int mg_avgpool2_bwd(const float* gy, const float* act, float* gx, int NC, int H, int W, float slope,
+                               mg_stream_t stream) {
+  MG_CHECK_ARG(gy && gx && NC > 0 && H > 0 && W > 0 && (H % 2 == 0) && (W % 2 == 0), "mg_avgpool2_bwd: bad arguments");
+  const size_t total = (size_t)NC * (H / 2) * (W / 2);
+  EW_LAUNCH(avgpool2_bwd_k, ew_grid(total), 256, gy, act, gx, total, H / 2, W / 2, slope);
+  MG_CHECK_LAUNCH("mg_avgpool2_bwd");
+  return MG_OK;
+}
+
+extern "C" int mg_blend_up(float a, const float* x, float b, const float* y, float* out, int NC, int H, int W,
+                           mg_stream_t stream) {
+  MG_CHECK_ARG(x && y && out && NC > 0 && H > 0 && W > 0 && (H % 2 == 0) && (W % 2 == 0), "mg_blend_up: bad arguments");
+  const size_t total = (size_t)NC * (H / 2) * (W / 2);
+  EW_LAUNCH(blend_up_k, ew_grid(total), 256, a, x, b, y, out, total, H / 2, W / 2);
+  MG_CHECK_LAUNCH("mg_blend_up");
+  return MG_OK;
+}
+
+extern "C" int mg_lrelu_bwd(const float* g, const float* act, float* out, size_t n, float slope, mg_stream_t stream) {
+  MG_CHECK_ARG(g && act && out && n > 0, "mg_lrelu_bwd: bad arguments");
+  if ((n & 3) == 0) EW_LAUNCH(lrelu_bwd_k<4>, ew_grid(n / 4), 256, g, act, out, n / 4, slope);
+  else EW_LAUNCH(lrelu_bwd_k<1>, ew_grid(n), 256, g, act, out, n, slope);
+  MG_CHECK_LAUNCH("mg_lrelu_bwd");
+  return MG_OK;
+}
+
+extern "C" int mg_axpby(float a, const float* x, float b, const float* y, float* out, size_t n, mg_stream_t stream) {
+  MG_CHECK_ARG(x && out && n > 0, "mg_axpby: bad arguments");
+  if ((n & 3) == 0) EW_LAUNCH(axpby_k<4>, ew_grid(n / 4), 256, a, x, b, y, out, n / 4);
+  else EW_LAUNCH(axpby_k<1>, ew_grid(n), 256, a, x, b, y, out, n);
+  MG_CHECK_LAUNCH("mg_axpby");
+  return MG_OK;
+}
+
+extern "C" int mg_linear1_fwd(const float* x, const float* w, const float* b, float* y, int N, int K,
+                              mg_stream_t stream) {
+  MG_CHECK_ARG(x && w && y && N > 0 && K > 0, "mg_linear1_fwd: bad arguments");
+  EW_LAUNCH(linear1_fwd_k, N, 64, x, w, b, y, K);
+  MG_CHECK_LAUNCH("mg_linear1_fwd");
+  return MG_OK;
+}
+
+extern "C" int mg_linear1_bwd(const float* x, const float* w, const float* gy, float* gx, float* gw, float* gb, int N,
+                              int K, int accumulate, mg_stream_t stream) {
+  MG_CHECK_ARG(w && gy && N > 0 && K > 0 && (!gw || x), "mg_linear1_bwd: bad arguments");
+  EW_LAUNCH(linear1_bwd_k, 1, 256, x, w, gy, gx, gw, gb, N, K, accumulate);
+  MG_CHECK_LAUNCH("mg_linear1_bwd");
+  return MG_OK;
+}
+
+extern "C" int mg_gp_interp(const float* x_real, const float* x_fake, const float* eps, float* out, int N, size_t chw,
+                            mg_stream_t stream) {
+  MG_CHECK_ARG(x_real && x_fake && eps && out && N > 0 && chw > 0, "mg_gp_interp: bad arguments");
+  if ((chw & 3) == 0) EW_LAUNCH(gp_interp_k<4>, ew_grid(N * chw / 4), 256, x_real, x_fake, eps, out, N, chw / 4);
+  else EW_LAUNCH(gp_interp_k<1>, ew_grid(N * chw), 256, x_real, x_fake, eps, out, N, chw);
+  MG_CHECK_LAUNCH("mg_gp_interp");
+  return MG_OK;
+}
+
+extern "C" int mg_sumsq_per_sample(const float* g, float* out, int N, size_t chw, mg_stream_t stream) {
+  MG_CHECK_ARG(g && out && N > 0 && chw > 0, "mg_sumsq_per_sample: bad arguments");
+  EW_LAUNCH(sumsq_per_sample_k, N, 1024, g, out, chw);
+  MG_CHECK_LAUNCH("mg_sumsq_per_sample");
+  return MG_OK;
+}
+
+extern "C" int mg_scale_per_sample(const float* g, const float* coef, float* out, int N, size_t chw,
+                                   mg_stream_t stream) {
+  MG_CHECK_ARG(g && coef && out && N > 0 && chw > 0, "mg_scale_per_sample: bad arguments");
+  if ((chw & 3) == 0) EW_LAUNCH(scale_per_sample_k<4>, ew_grid(N * chw / 4), 256, g, coef, out, N, chw / 4);
+  else EW_LAUNCH(scale_per_sample_k<1>, ew_grid(N * chw), 256, g, coef, out, N, chw);
+  MG_CHECK_LAUNCH("mg_scale_per_sample");
+  return MG_OK;
+}
+
+extern "C" int mg_gp_finish(const float* sumsq, float* penalty, float* coef, int N, float factor, float upstream,
+                            mg_stream_t stream) {
+  MG_CHECK_ARG(sumsq && N > 0, "mg_gp_finish: bad arguments");
+  EW_LAUNCH(gp_finish_k, 1, 256, sumsq, penalty, coef, N, factor, upstream);
+  MG_CHECK_LAUNCH("mg_gp_finish");
+  return MG_OK;
+}
+
+extern "C" int mg_channel_sum(const float* x, float* out, int N, int C, int HW, int accumulate, mg_stream_t stream) {
+  MG_CHECK_ARG(x && out && N > 0 && C > 0 && HW > 0, "mg_channel_sum: bad arguments");
+  EW_LAUNCH(channel_sum_k, C, 1024, x, out, N, C, HW, accumulate);
+  MG_CHECK_LAUNCH("mg_channel_sum");
+  return MG_OK;
+}
+
+extern "C" int mg_adam_step(const mg_adam_tensor_t* desc, int n_tensors, float beta1, float beta2, float eps,
+                            float grad_scale, mg_stream_t stream) {
+  MG_CHECK_ARG(desc && n_tensors > 0, "mg_adam_step: bad arguments");
+  hipLaunchKernelGGL(adam_k, dim3(64, n_tensors), dim3(256), 0, (hipStream_t)stream, desc, beta1, beta2, eps,
+                     grad_scale);
+  MG_CHECK_LAUNCH("mg_adam_step");
+  return MG_OK;
+}

@@ -1,0 +1,47 @@
+// Shared host/device helpers for libmusicgan_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/musicgan_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+void mg_set_error(const char* fmt, ...);
+
+#define MG_CHECK_ARG(cond, ...)    \
+  do {                             \
+    if (!(cond)) {                 \
+      mg_set_error(__VA_ARGS__);   \
+      return MG_EINVAL;            \
+    }                              \
+  } while (0)
+
+#define MG_CHECK_LAUNCH(name)                                              \
+  do {                                                                     \
+    hipError_t e_ = hipGetLastError();                                     \
+    if (e_ != hipSuccess) {                                                \
+      mg_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));  \
+      return MG_ELAUNCH;                                                   \
+    }                                                                      \
+  } while (0)
+
+static inline int mg_ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+static inline int mg_pow2_ceil(int v) { return 1 << mg_ilog2(v); }
+static inline int mg_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// XCD-aware, bijective block-id remap: blocks b and b+8 share an XCD (observed round-robin dispatch), so give each of the
+// 8 residue classes a contiguous chunk of the logical grid => neighbouring tiles (shared halos / weights) hit one L2.
+__device__ __forceinline__ int mg_xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+__device__ __forceinline__ float mg_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+__device__ __forceinline__ float mg_lrelu_mask(float act, float slope) { return act > 0.f ? 1.f : slope; }

@@ -1,0 +1,290 @@
+// Weight (+bias) gradient of the 3x3 convolution on the fp32 matrix cores (v_mfma_f32_16x16x4_f32).
+//
+// Replaces aten::convolution_backward (weight/bias part) as reached from the reference's
+//   generator.py:16-22,31-37 / discriminator.py:15-21,26-32 under loss.backward()  (train.py:174,213).
+//
+// GEMM view per tap t=(ky,kx):  GW_t[o, c] = sum_{pixels} GY[o, pixel] * X[c, pixel + tap]
+//   K = pixels: 4 consecutive pixels per MFMA (lane>>4), A rows = 16 out-channels, B cols = 16 in-channels.
+//   One wave owns ONE 16-wide in-channel tile and WO (<=4) out-channel tiles for all 9 taps: 9*WO accumulators (f32x4),
+//   13 LDS operand reads per 36 MFMAs at WO=4.  A workgroup = one wave per in-channel tile of its (o-block, c-block).
+//   Workgroups are persistent over pixel tiles (split-K); partials go to a slab [split][tap][o][c] and a second kernel sums
+//   the splits in a fixed order (deterministic, no float atomics) while transposing to the module layout [o][c][tap].
+// LDS image per pixel tile: GY [WO*16][P+2] and X halo [nwaves*16][plane(+pad)], both with channel stride % 4 == 2 so
+// that the 16 channel-lanes x 2 k-lanes of a half-wave fall on 32 distinct banks.
+#include "mg_common.h"
+
+namespace {
+
+struct WgradArgs {
+  const float* x;
+  const float* gy;
+  float* slab;    // [nsplit][9][Cout][Cin]
+  float* slab_b;  // [nsplit][Cout]
+  int N, Cin, Cout, H, W, Hin, Win, ups;
+  int TH, TW, TN, lgTH, lgTW, THp, TWp, P;
+  int tiles_x, tiles_y, tiles_n, ntiles;
+  int plane, x_stride, gy_stride, tab_floats;
+  int oblocks;  // grid.y = oblocks * cblocks
+  int nwaves;   // in-channel tiles per workgroup
+};
+
+template <int WO>
+__global__ void __launch_bounds__(512) wgrad3x3_mfma(const WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int* tab = reinterpret_cast<int*>(smem);
+  float* gy_t = smem + a.tab_floats;
+  float* x_t = gy_t + WO * 16 * a.gy_stride;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthr = blockDim.x;
+  const int col = lane & 15, rq = lane >> 4;
+  const int ob = blockIdx.y % a.oblocks, cb = blockIdx.y / a.oblocks;
+  const int o0 = ob * WO * 16;
+  const int c0 = cb * a.nwaves * 16;
+  const int HWin = a.Hin * a.Win;
+  const int HW = a.H * a.W;
+  const int THpTWp = a.THp * a.TWp;
+  const bool vec = (a.TW >= 4) && ((a.W & 3) == 0);
+
+  f32x4 acc[WO][9];
+  float gb[WO];
+#pragma unroll
+  for (int wo = 0; wo < WO; ++wo) {
+    gb[wo] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[wo][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int tx = tile % a.tiles_x;
+    const int t2 = tile / a.tiles_x;
+    const int ty = t2 % a.tiles_y;
+    const int tn = t2 / a.tiles_y;
+    __syncthreads();  // previous tile's MFMA reads done
+    for (int pos = tid; pos < a.plane; pos += nthr) {
+      const int n_l = pos / THpTWp;
+      const int rem = pos - n_l * THpTWp;
+      const int rr = rem / a.TWp;
+      const int cc = rem - rr * a.TWp;
+      const int n = tn * a.TN + n_l, Y = ty * a.TH + rr - 1, X = tx * a.TW + cc - 1;
+      const bool ok = (n < a.N) && (Y >= 0) && (Y < a.H) && (X >= 0) && (X < a.W);
+      const int sp = a.ups ? (Y >> 1) * a.Win + (X >> 1) : Y * a.Win + X;
+      tab[pos] = ok ? n_l * a.Cin * HWin + sp : -1;
+    }
+    // GY tile [WO*16][P]
+    if (vec) {
+      const int q4 = a.P >> 2;  // float4 groups per channel
+      for (int e = tid; e < WO * 16 * q4; e += nthr) {
+        const int ol = e / q4;
+        const int p = (e - ol * q4) << 2;
+        const int c = p & (a.TW - 1);
+        const int r = (p >> a.lgTW) & (a.TH - 1);
+        const int n_l = p >> (a.lgTW + a.lgTH);
+        const int n = tn * a.TN + n_l, Y = ty * a.TH + r, X = tx * a.TW + c, o = o0 + ol;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (o < a.Cout && n < a.N && Y < a.H && X < a.W)
+          v = *reinterpret_cast<const f32x4*>(a.gy + ((size_t)n * a.Cout + o) * HW + (size_t)Y * a.W + X);
+        float* d = gy_t + ol * a.gy_stride + p;  // 8-byte aligned (gy_stride even, p % 4 == 0)
+        *reinterpret_cast<float2*>(d) = make_float2(v[0], v[1]);
+        *reinterpret_cast<float2*>(d + 2) = make_float2(v[2], v[3]);
+      }
+    } else {
+      for (int e = tid; e < WO * 16 * a.P; e += nthr) {
+        const int ol = e / a.P;
+        const int p = e - ol * a.P;
+        const int c = p & (a.TW - 1);
+        const int r = (p >> a.lgTW) & (a.TH - 1);
+        const int n_l = p >> (a.lgTW + a.lgTH);
+        const int n = tn * a.TN + n_l, Y = ty * a.TH + r, X = tx * a.TW + c, o = o0 + ol;
+        float v = 0.f;
+        if (o < a.Cout && n < a.N && Y < a.H && X < a.W) v = a.gy[((size_t)n * a.Cout + o) * HW + (size_t)Y * a.W + X];
+        gy_t[ol * a.gy_stride + p] = v;
+      }
+    }
+    __syncthreads();  // tab ready
+    {                 // X halo tile [nwaves*16][plane]: half-wave per channel, 32 consecutive positions per pass
+      const float* xn = a.x + (size_t)tn * a.TN * a.Cin * HWin;
+      const int nhalf = nthr >> 5;
+      const int l32 = tid & 31;
+      for (int cl = tid >> 5; cl < a.nwaves * 16; cl += nhalf) {
+        const int c = c0 + cl;
+        const bool cok = c < a.Cin;
+        const float* xc = xn + (size_t)c * HWin;
+        float* dst = x_t + cl * a.x_stride;
+#pragma unroll 4
+        for (int pos = l32; pos < a.plane; pos += 32) {
+          const int off = tab[pos];
+          float v = 0.f;
+          if (cok && off >= 0) v = xc[off];
+          dst[pos] = v;
+        }
+      }
+    }
+    __syncthreads();
+    const float* xw = x_t + (wave * 16 + col) * a.x_stride;
+    const float* gw_ = gy_t + col * a.gy_stride;
+    const int nk = a.P >> 2;
+    for (int kk = 0; kk < nk; ++kk) {
+      const int p = kk * 4 + rq;
+      const int c = p & (a.TW - 1);
+      const int r = (p >> a.lgTW) & (a.TH - 1);
+      const int n_l = p >> (a.lgTW + a.lgTH);
+      const int xpos = (n_l * a.THp + r) * a.TWp + c;
+      float av[WO], bv[9];
+#pragma unroll
+      for (int wo = 0; wo < WO; ++wo) av[wo] = gw_[wo * 16 * a.gy_stride + p];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) bv[t] = xw[xpos + (t / 3) * a.TWp + (t % 3)];
+#pragma unroll
+      for (int wo = 0; wo < WO; ++wo) {
+        gb[wo] += av[wo];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+          acc[wo][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[wo], bv[t], acc[wo][t], 0, 0, 0);
+      }
+    }
+  }
+
+  // partial slab: D rows = out-channels 4*rq+g, cols = in-channel col
+  const int c = c0 + wave * 16 + col;
+  float* slab = a.slab + (size_t)blockIdx.x * 9 * a.Cout * a.Cin;
+#pragma unroll
+  for (int wo = 0; wo < WO; ++wo) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int o = o0 + wo * 16 + rq * 4 + g;
+        if (o < a.Cout && c < a.Cin) slab[((size_t)t * a.Cout + o) * a.Cin + c] = acc[wo][t][g];
+      }
+    }
+  }
+  if (cb == 0 && wave == 0 && a.slab_b != nullptr) {
+#pragma unroll
+    for (int wo = 0; wo < WO; ++wo) {
+      float v = gb[wo];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      const int o = o0 + wo * 16 + col;
+      if (rq == 0 && o < a.Cout) a.slab_b[(size_t)blockIdx.x * a.Cout + o] = v;
+    }
+  }
+}
+
+__global__ void wgrad3x3_reduce(const float* __restrict__ slab, const float* __restrict__ slab_b, int nsplit,
+                                float* __restrict__ gw, float* __restrict__ gb, int Cout, int Cin, int accumulate) {
+  const int total = 9 * Cout * Cin;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < total) {
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += slab[(size_t)k * total + e];
+    const int c = e % Cin;
+    const int r = e / Cin;
+    const int o = r % Cout;
+    const int t = r / Cout;
+    const size_t idx = ((size_t)o * Cin + c) * 9 + t;
+    gw[idx] = accumulate ? gw[idx] + s : s;
+  } else if (gb != nullptr && e < total + Cout) {
+    const int o = e - total;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += slab_b[(size_t)k * Cout + o];
+    gb[o] = accumulate ? gb[o] + s : s;
+  }
+}
+
+struct WgradPlan {
+  WgradArgs a;
+  int WO, nsplit, cblocks;
+  size_t lds, ws_floats;
+};
+
+bool plan_wgrad(int N, int Cin, int Cout, int H, int W, WgradPlan& pl) {
+  WgradArgs& a = pl.a;
+  a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+  const int otiles = mg_cdiv(Cout, 16), ctiles = mg_cdiv(Cin, 16);
+  a.oblocks = mg_cdiv(otiles, 4);
+  pl.WO = mg_cdiv(otiles, a.oblocks);
+  pl.cblocks = mg_cdiv(ctiles, 8);
+  a.nwaves = mg_cdiv(ctiles, pl.cblocks);
+  // pixel tile: 128 pixels, shrunk for tiny images (halo overhead 4x..9x) until the LDS image fits comfortably
+  for (a.P = 128;; a.P >>= 1) {
+    a.TW = mg_pow2_ceil(W) < 32 ? mg_pow2_ceil(W) : 32;
+    if (a.TW > a.P) a.TW = a.P;
+    a.TH = mg_pow2_ceil(H) < a.P / a.TW ? mg_pow2_ceil(H) : a.P / a.TW;
+    a.TN = a.P / (a.TW * a.TH);
+    a.lgTW = mg_ilog2(a.TW); a.lgTH = mg_ilog2(a.TH);
+    a.THp = a.TH + 2; a.TWp = a.TW + 2;
+    a.plane = a.TN * a.THp * a.TWp;
+    a.x_stride = a.plane + ((6 - (a.plane & 3)) & 3);  // smallest s >= plane with s % 4 == 2
+    a.gy_stride = a.P + 2;
+    a.tab_floats = (a.plane + 3) & ~3;
+    pl.lds = (size_t)(a.tab_floats + pl.WO * 16 * a.gy_stride + a.nwaves * 16 * a.x_stride) * sizeof(float);
+    if (pl.lds <= 96 * 1024 || a.P <= 16) break;
+  }
+  a.tiles_x = mg_cdiv(W, a.TW); a.tiles_y = mg_cdiv(H, a.TH); a.tiles_n = mg_cdiv(N, a.TN);
+  a.ntiles = a.tiles_x * a.tiles_y * a.tiles_n;
+  const int gy_blocks = a.oblocks * pl.cblocks;
+  int nsplit = 768 / gy_blocks;
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > a.ntiles) nsplit = a.ntiles;
+  pl.nsplit = nsplit;
+  pl.ws_floats = (size_t)nsplit * ((size_t)9 * Cout * Cin + Cout);
+  return pl.lds <= 160 * 1024;
+}
+
+template <int WO>
+int launch_wgrad(const WgradPlan& pl, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_mfma<WO>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        160 * 1024);
+    attr_set = true;
+  }
+  dim3 grid(pl.nsplit, pl.a.oblocks * pl.cblocks);
+  hipLaunchKernelGGL((wgrad3x3_mfma<WO>), grid, dim3(64 * pl.a.nwaves), pl.lds, s, pl.a);
+  MG_CHECK_LAUNCH("mg_conv3x3_wgrad");
+  return MG_OK;
+}
+
+}  // namespace
+
+extern "C" size_t mg_conv3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W) {
+  WgradPlan pl;
+  plan_wgrad(N, Cin, Cout, H, W, pl);
+  return pl.ws_floats * sizeof(float);
+}
+
+extern "C" int mg_conv3x3_wgrad(const float* x, const float* gy, float* gw, float* gb, void* ws, size_t ws_bytes, int N,
+                                int Cin, int Cout, int H, int W, int flags, int accumulate, mg_stream_t stream) {
+  MG_CHECK_ARG(x && gy && gw && ws && N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "mg_conv3x3_wgrad: bad arguments");
+  const bool ups = flags & MG_CONV_UPS_IN;
+  MG_CHECK_ARG(!ups || ((H % 2 == 0) && (W % 2 == 0)), "mg_conv3x3_wgrad: upsampled input needs even H,W");
+  const long long in_elems = (long long)N * Cin * (ups ? (H / 2) * (W / 2) : H * W);
+  MG_CHECK_ARG(in_elems < (1ll << 31), "mg_conv3x3_wgrad: tensor too large");
+  WgradPlan pl;
+  MG_CHECK_ARG(plan_wgrad(N, Cin, Cout, H, W, pl), "mg_conv3x3_wgrad: LDS tile too large");
+  if (ws_bytes < pl.ws_floats * sizeof(float)) {
+    mg_set_error("mg_conv3x3_wgrad: workspace %zu < %zu bytes", ws_bytes, pl.ws_floats * sizeof(float));
+    return MG_EWORKSPACE;
+  }
+  WgradArgs& a = pl.a;
+  a.x = x; a.gy = gy;
+  a.slab = reinterpret_cast<float*>(ws);
+  a.slab_b = a.slab + (size_t)pl.nsplit * 9 * Cout * Cin;
+  a.ups = ups ? 1 : 0;
+  a.Hin = ups ? H / 2 : H; a.Win = ups ? W / 2 : W;
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  switch (pl.WO) {
+    case 1: rc = launch_wgrad<1>(pl, s); break;
+    case 2: rc = launch_wgrad<2>(pl, s); break;
+    case 3: rc = launch_wgrad<3>(pl, s); break;
+    default: rc = launch_wgrad<4>(pl, s); break;
+  }
+  if (rc != MG_OK) return rc;
+  const int total = 9 * Cout * Cin + Cout;
+  hipLaunchKernelGGL(wgrad3x3_reduce, dim3(mg_cdiv(total, 256)), dim3(256), 0, s, a.slab, a.slab_b, pl.nsplit, gw, gb,
+                     Cout, Cin, accumulate);
+  MG_CHECK_LAUNCH("mg_conv3x3_wgrad(reduce)");
+  return MG_OK;
+}

@@ -1,0 +1,266 @@
+"""Tensor-level wrappers over the C ABI (include/musicgan_hip.h).  Inputs are fp32 contiguous tensors on a ROCm device;
+every call is asynchronous on the caller's current stream.  No fallback path exists: non-GPU tensors raise."""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (MG_C1_LRELU, MG_C1_MASK_AUX, MG_C1_TANH, MG_C1_TANH_BWD_IN, MG_C1_TRANSPOSED, MG_CONV_LRELU,
+                   MG_CONV_MASK_AUX, MG_CONV_PIXNORM, MG_CONV_UPS_IN, check)
+
+SLOPE = 0.2
+
+
+def _p(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _s():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.MusicGanHipError("musicgan_amd kernels need tensors on a ROCm GPU (no CPU fallback)")
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise _lib.MusicGanHipError(f"expected contiguous float32, got {t.dtype} contiguous={t.is_contiguous()}")
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Scratch buffer per (device, stream); grown geometrically, reused across calls on that stream."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20, 0 if buf is None else 2 * buf.numel()), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+# ------------------------------------------------------------------ conv 3x3
+def pack_conv3x3(w: torch.Tensor, dgrad: bool) -> torch.Tensor:
+    _chk(w)
+    co, ci = w.shape[0], w.shape[1]
+    lib = _lib.load()
+    cin_call, cout_call = (co, ci) if dgrad else (ci, co)
+    wp = torch.empty(lib.mg_conv3x3_packed_floats(cin_call, cout_call), dtype=torch.float32, device=w.device)
+    check(lib.mg_conv3x3_pack(_p(w), _p(wp), co, ci, int(dgrad), _s()), "mg_conv3x3_pack")
+    return wp
+
+
+def conv3x3(x, wp, bias, cout: int, *, ups=False, lrelu=False, mask_aux=None, pixnorm=False, want_y=True):
+    """Returns y, or (y, p, rn) with pixnorm.  Output spatial size = input (x2 with ups)."""
+    _chk(x, wp, bias, mask_aux)
+    n, cin, hin, win = x.shape
+    h, w = (2 * hin, 2 * win) if ups else (hin, win)
+    flags = (MG_CONV_UPS_IN if ups else 0) | (MG_CONV_LRELU if lrelu else 0) | \
+            (MG_CONV_MASK_AUX if mask_aux is not None else 0) | (MG_CONV_PIXNORM if pixnorm else 0)
+    y = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device) if (want_y or not pixnorm) else None
+    p = rn = None
+    if pixnorm:
+        p = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+        rn = torch.empty((n, 1, h, w), dtype=torch.float32, device=x.device)
+    check(_lib.load().mg_conv3x3(_p(x), _p(wp), _p(bias), _p(mask_aux), _p(y), _p(p), _p(rn), n, cin, cout, h, w, flags,
+                                 SLOPE, _s()), "mg_conv3x3")
+    return (y, p, rn) if pixnorm else y
+
+
+def conv3x3_wgrad(x, gy, gw, gb, *, ups=False, accumulate=False):
+    """gw[Cout,Cin,3,3] (+)= wgrad(x, gy); gb[Cout] (+)= sum gy (gb may be None)."""
+    _chk(x, gy, gw, gb)
+    n, cout, h, w = gy.shape
+    cin = x.shape[1]
+    lib = _lib.load()
+    nbytes = lib.mg_conv3x3_wgrad_ws_bytes(n, cin, cout, h, w)
+    ws = workspace(nbytes, x.device)
+    check(lib.mg_conv3x3_wgrad(_p(x), _p(gy), _p(gw), _p(gb), _p(ws), ws.numel(), n, cin, cout, h, w,
+                               MG_CONV_UPS_IN if ups else 0, int(accumulate), _s()), "mg_conv3x3_wgrad")
+
+
+# ------------------------------------------------------------------ conv 1x1
+def conv1x1(x, w, bias, cout: int, *, lrelu=False, tanh=False, mask_aux=None, transposed=False, tanh_bwd_in=None):
+    _chk(x, w, bias, mask_aux, tanh_bwd_in)
+    n, cin, h, wd = x.shape
+    flags = (MG_C1_LRELU if lrelu else 0) | (MG_C1_TANH if tanh else 0) | (MG_C1_TRANSPOSED if transposed else 0)
+    aux = None
+    if mask_aux is not None:
+        flags |= MG_C1_MASK_AUX
+        aux = mask_aux
+    if tanh_bwd_in is not None:
+        assert aux is None
+        flags |= MG_C1_TANH_BWD_IN
+        aux = tanh_bwd_in
+    y = torch.empty((n, cout, h, wd), dtype=torch.float32, device=x.device)
+    check(_lib.load().mg_conv1x1(_p(x), _p(w), _p(bias), _p(aux), _p(y), n, cin, cout, h * wd, flags, SLOPE, _s()),
+          "mg_conv1x1")
+    return y
+
+
+def conv1x1_wgrad(x, gy, gw, gb, *, tanh_y=None, accumulate=False):
+    _chk(x, gy, gw, gb, tanh_y)
+    n, cout, h, wd = gy.shape
+    cin = x.shape[1]
+    lib = _lib.load()
+    nbytes = lib.mg_conv1x1_wgrad_ws_bytes(n, cin, cout, h * wd)
+    ws = workspace(nbytes, x.device)
+    check(lib.mg_conv1x1_wgrad(_p(x), _p(gy), _p(tanh_y), _p(gw), _p(gb), _p(ws), ws.numel(), n, cin, cout, h * wd,
+                               int(accumulate), _s()), "mg_conv1x1_wgrad")
+
+
+# ------------------------------------------------------------------ element-wise
+def pixelnorm_fwd(y):
+    _chk(y)
+    n, c, h, w = y.shape
+    p = torch.empty_like(y)
+    rn = torch.empty((n, 1, h, w), dtype=torch.float32, device=y.device)
+    check(_lib.load().mg_pixelnorm_fwd(_p(y), _p(p), _p(rn), n, c, h * w, _s()), "mg_pixelnorm_fwd")
+    return p, rn
+
+
+def pixelnorm_lrelu_bwd(gp, y, rn, slope: float = SLOPE):
+    """Backward through PixelNorm and the LeakyReLU in front of it (y = post-LeakyReLU activation)."""
+    _chk(gp, y, rn)
+    n, c, h, w = y.shape
+    out = torch.empty_like(y)
+    check(_lib.load().mg_pixelnorm_lrelu_bwd(_p(gp), _p(y), _p(rn), _p(out), n, c, h * w, float(slope), _s()),
+          "mg_pixelnorm_lrelu_bwd")
+    return out
+
+
+def pixelnorm_bwd(gp, y, rn):
+    """Backward through PixelNorm alone (mask slope 1 == identity)."""
+    return pixelnorm_lrelu_bwd(gp, y, rn, slope=1.0)
+
+
+def upsample2x_fwd(x):
+    _chk(x)
+    n, c, h, w = x.shape
+    y = torch.empty((n, c, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+    check(_lib.load().mg_upsample2x_fwd(_p(x), _p(y), n * c, h, w, _s()), "mg_upsample2x_fwd")
+    return y
+
+
+def upsample2x_bwd(gy):
+    _chk(gy)
+    n, c, h2, w2 = gy.shape
+    gx = torch.empty((n, c, h2 // 2, w2 // 2), dtype=torch.float32, device=gy.device)
+    check(_lib.load().mg_upsample2x_bwd(_p(gy), _p(gx), n * c, h2 // 2, w2 // 2, _s()), "mg_upsample2x_bwd")
+    return gx
+
+
+def avgpool2_fwd(x):
+    _chk(x)
+    n, c, h, w = x.shape
+    y = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=x.device)
+    check(_lib.load().mg_avgpool2_fwd(_p(x), _p(y), n * c, h, w, _s()), "mg_avgpool2_fwd")
+    return y
+
+
+def avgpool2_bwd(gy, act=None):
+    """gx = 0.25 * up2(gy) * lrelu'(act) (act None: no mask)."""
+    _chk(gy, act)
+    n, c, h2, w2 = gy.shape
+    gx = torch.empty((n, c, 2 * h2, 2 * w2), dtype=torch.float32, device=gy.device)
+    check(_lib.load().mg_avgpool2_bwd(_p(gy), _p(act), _p(gx), n * c, 2 * h2, 2 * w2, SLOPE, _s()), "mg_avgpool2_bwd")
+    return gx
+
+
+def lrelu_bwd(g, act, out=None):
+    _chk(g, act, out)
+    out = torch.empty_like(g) if out is None else out
+    check(_lib.load().mg_lrelu_bwd(_p(g), _p(act), _p(out), g.numel(), SLOPE, _s()), "mg_lrelu_bwd")
+    return out
+
+
+def axpby(a: float, x, b: float = 0.0, y=None, out=None):
+    _chk(x, y, out)
+    out = torch.empty_like(x) if out is None else out
+    check(_lib.load().mg_axpby(float(a), _p(x), float(b), _p(y), _p(out), x.numel(), _s()), "mg_axpby")
+    return out
+
+
+def blend_up(a: float, x, b: float, ylow):
+    _chk(x, ylow)
+    n, c, h, w = x.shape
+    out = torch.empty_like(x)
+    check(_lib.load().mg_blend_up(float(a), _p(x), float(b), _p(ylow), _p(out), n * c, h, w, _s()), "mg_blend_up")
+    return out
+
+
+def linear1_fwd(x, w, b):
+    _chk(x, w, b)
+    n, k = x.shape
+    y = torch.empty((n, 1), dtype=torch.float32, device=x.device)
+    check(_lib.load().mg_linear1_fwd(_p(x), _p(w), _p(b), _p(y), n, k, _s()), "mg_linear1_fwd")
+    return y
+
+
+def linear1_bwd(x, w, gy, *, gw=None, gb=None, need_gx=True, accumulate=False):
+    _chk(x, w, gy, gw, gb)
+    n = gy.shape[0]
+    k = w.numel()
+    gx = torch.empty((n, k), dtype=torch.float32, device=gy.device) if need_gx else None
+    check(_lib.load().mg_linear1_bwd(_p(x), _p(w), _p(gy), _p(gx), _p(gw), _p(gb), n, k, int(accumulate), _s()),
+          "mg_linear1_bwd")
+    return gx
+
+
+def gp_interp(x_real, x_fake, eps):
+    _chk(x_real, x_fake, eps)
+    n = x_real.shape[0]
+    out = torch.empty_like(x_real)
+    check(_lib.load().mg_gp_interp(_p(x_real), _p(x_fake), _p(eps), _p(out), n, x_real[0].numel(), _s()),
+          "mg_gp_interp")
+    return out
+
+
+def sumsq_per_sample(g):
+    _chk(g)
+    n = g.shape[0]
+    out = torch.empty((n,), dtype=torch.float32, device=g.device)
+    check(_lib.load().mg_sumsq_per_sample(_p(g), _p(out), n, g[0].numel(), _s()), "mg_sumsq_per_sample")
+    return out
+
+
+def scale_per_sample(g, coef):
+    _chk(g, coef)
+    n = g.shape[0]
+    out = torch.empty_like(g)
+    check(_lib.load().mg_scale_per_sample(_p(g), _p(coef), _p(out), n, g[0].numel(), _s()), "mg_scale_per_sample")
+    return out
+
+
+def gp_finish(sumsq, factor: float, upstream: float = 1.0, want_penalty=True, want_coef=True):
+    _chk(sumsq)
+    n = sumsq.numel()
+    pen = torch.empty((), dtype=torch.float32, device=sumsq.device) if want_penalty else None
+    coef = torch.empty((n,), dtype=torch.float32, device=sumsq.device) if want_coef else None
+    check(_lib.load().mg_gp_finish(_p(sumsq), _p(pen), _p(coef), n, float(factor), float(upstream), _s()),
+          "mg_gp_finish")
+    return pen, coef
+
+
+def channel_sum(x, out=None, accumulate=False):
+    _chk(x, out)
+    n, c, h, w = x.shape
+    out = torch.empty((c,), dtype=torch.float32, device=x.device) if out is None else out
+    check(_lib.load().mg_channel_sum(_p(x), _p(out), n, c, h * w, int(accumulate), _s()), "mg_channel_sum")
+    return out
+
+
+def stft_1024(wav_mono: torch.Tensor) -> torch.Tensor:
+    """mono fp32 [L] -> complex64 [512, 1 + L//256] (audio/functions.py:38-62 without the file read)."""
+    _chk(wav_mono)
+    length = wav_mono.numel()
+    t = 1 + length // 256
+    out = torch.empty((512, t, 2), dtype=torch.float32, device=wav_mono.device)
+    check(_lib.load().mg_stft_1024(_p(wav_mono), _p(out), None, length, _s()), "mg_stft_1024")
+    return torch.view_as_complex(out)

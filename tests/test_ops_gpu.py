@@ -1,0 +1,265 @@
+"""GPU parity of every C-ABI kernel against plain PyTorch fp32/fp64 CPU references of the same op."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _ops():
+    from musicgan_amd import ops
+    return ops
+
+
+def rel_err(got: torch.Tensor, ref: torch.Tensor) -> float:
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def report(name, got, ref, tol):
+    e = rel_err(got, ref)
+    if not (e <= tol):
+        g, r = got.detach().double().cpu(), ref.detach().double().cpu()
+        bad = ((g - r).abs() > tol * r.abs().max()).nonzero()
+        raise AssertionError(f"{name}: rel err {e:.3e} > {tol:.1e}; {bad.shape[0]} bad of {g.numel()}, first {bad[:6].tolist()}")
+    return e
+
+
+CONV_SHAPES = [
+    # N, Cin, Cout, H, W
+    (2, 8, 8, 2, 2), (3, 32, 128, 4, 4), (2, 128, 112, 8, 8), (2, 96, 80, 32, 32), (2, 64, 48, 64, 64),
+    (1, 48, 64, 128, 128), (2, 160, 160, 1, 1), (2, 144, 160, 2, 2), (3, 16, 32, 16, 16), (1, 24, 40, 12, 20),
+    (2, 80, 64, 64, 64), (5, 112, 128, 8, 8),
+]
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv3x3_fwd_bias_lrelu(shape):
+    ops = _ops()
+    n, ci, co, h, w = shape
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(9 * ci)
+    b = torch.randn(co, generator=g)
+    ref = F.leaky_relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1), 0.2)
+    wp = ops.pack_conv3x3(wt.to(DEV), dgrad=False)
+    y = ops.conv3x3(x.to(DEV), wp, b.to(DEV), co, lrelu=True)
+    report("conv3x3 fwd", y, ref, 2e-6)
+    # no bias, no activation
+    y2 = ops.conv3x3(x.to(DEV), wp, None, co)
+    report("conv3x3 plain", y2, F.conv2d(x.double(), wt.double(), None, padding=1), 2e-6)
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES[:8])
+def test_conv3x3_dgrad_and_mask(shape):
+    ops = _ops()
+    n, ci, co, h, w = shape
+    g = torch.Generator().manual_seed(2)
+    gy = torch.randn(n, co, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(9 * ci)
+    act = torch.randn(n, ci, h, w, generator=g)
+    ref = F.conv_transpose2d(gy.double(), wt.double(), padding=1)
+    wp = ops.pack_conv3x3(wt.to(DEV), dgrad=True)
+    gx = ops.conv3x3(gy.to(DEV), wp, None, ci)
+    report("conv3x3 dgrad", gx, ref, 2e-6)
+    gxm = ops.conv3x3(gy.to(DEV), wp, None, ci, mask_aux=act.to(DEV))
+    report("conv3x3 dgrad+mask", gxm, ref * torch.where(act > 0, 1.0, 0.2).double(), 2e-6)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 8, 2, 2), (2, 32, 128, 4, 4), (2, 96, 80, 16, 16), (1, 64, 48, 64, 64),
+                                   (2, 24, 40, 6, 10)])
+def test_conv3x3_ups_pixnorm(shape):
+    ops = _ops()
+    n, ci, co, h, w = shape  # h, w = INPUT size; output is 2h x 2w
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(9 * ci)
+    b = torch.randn(co, generator=g)
+    xd = F.interpolate(x.double(), scale_factor=2.0, mode="nearest")
+    yr = F.leaky_relu(F.conv2d(xd, wt.double(), b.double(), padding=1), 0.2)
+    nr = torch.sqrt(yr.pow(2).mean(dim=1, keepdim=True) + 1e-8)
+    wp = ops.pack_conv3x3(wt.to(DEV), dgrad=False)
+    y, p, rn = ops.conv3x3(x.to(DEV), wp, b.to(DEV), co, ups=True, lrelu=True, pixnorm=True)
+    report("ups conv y", y, yr, 2e-6)
+    report("ups conv p", p, yr / nr, 3e-6)
+    report("ups conv rn", rn, 1.0 / nr, 3e-6)
+    # stand-alone pixelnorm kernel agrees
+    p2, rn2 = ops.pixelnorm_fwd(y)
+    report("pixelnorm p", p2, yr / nr, 3e-6)
+    report("pixelnorm rn", rn2, 1.0 / nr, 3e-6)
+
+
+WGRAD_SHAPES = [(2, 8, 8, 2, 2), (3, 32, 128, 4, 4), (4, 128, 112, 8, 8), (2, 96, 80, 32, 32), (2, 64, 48, 64, 64),
+                (1, 48, 64, 128, 128), (6, 160, 160, 1, 1), (5, 144, 160, 2, 2), (3, 16, 32, 16, 16),
+                (2, 24, 40, 12, 20)]
+
+
+@pytest.mark.parametrize("shape", WGRAD_SHAPES)
+def test_conv3x3_wgrad(shape):
+    ops = _ops()
+    n, ci, co, h, w = shape
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(n, ci, h, w, generator=g).double().requires_grad_(False)
+    gy = torch.randn(n, co, h, w, generator=g).double()
+    wt = torch.zeros(co, ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    bt = torch.zeros(co, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(x, wt, bt, padding=1) * gy).sum().backward()
+    gw = torch.full((co, ci, 3, 3), 7.0, device=DEV)
+    gb = torch.full((co,), 7.0, device=DEV)
+    ops.conv3x3_wgrad(x.float().to(DEV), gy.float().to(DEV), gw, gb)
+    report("wgrad gw", gw, wt.grad, 3e-6)
+    report("wgrad gb", gb, bt.grad, 3e-6)
+    ops.conv3x3_wgrad(x.float().to(DEV), gy.float().to(DEV), gw, gb, accumulate=True)
+    report("wgrad gw acc", gw, 2 * wt.grad, 3e-6)
+    report("wgrad gb acc", gb, 2 * bt.grad, 3e-6)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 16, 2, 2), (2, 96, 80, 8, 8), (1, 64, 48, 32, 32)])
+def test_conv3x3_wgrad_upsampled_input(shape):
+    ops = _ops()
+    n, ci, co, h, w = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, ci, h, w, generator=g).double()
+    gy = torch.randn(n, co, 2 * h, 2 * w, generator=g).double()
+    wt = torch.zeros(co, ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), wt, None, padding=1) * gy).sum().backward()
+    gw = torch.empty((co, ci, 3, 3), device=DEV)
+    ops.conv3x3_wgrad(x.float().to(DEV), gy.float().to(DEV), gw, None, ups=True)
+    report("wgrad ups", gw, wt.grad, 3e-6)
+
+
+@pytest.mark.parametrize("hw", [(4, 4), (32, 32), (3, 5)])
+@pytest.mark.parametrize("c", [16, 48, 160])
+def test_conv1x1_all_modes(hw, c):
+    ops = _ops()
+    h, w = hw
+    n = 3
+    g = torch.Generator().manual_seed(6)
+    x2 = torch.randn(n, 2, h, w, generator=g)
+    xc = torch.randn(n, c, h, w, generator=g)
+    ws = torch.randn(c, 2, 1, 1, generator=g)
+    bs = torch.randn(c, generator=g)
+    wh = torch.randn(2, c, 1, 1, generator=g) / math.sqrt(c)
+    bh = torch.randn(2, generator=g)
+    # stem: 2 -> C + LReLU
+    y = ops.conv1x1(x2.to(DEV), ws.to(DEV), bs.to(DEV), c, lrelu=True)
+    report("stem", y, F.leaky_relu(F.conv2d(x2.double(), ws.double(), bs.double()), 0.2), 2e-6)
+    # stem tangent: no bias, output mask
+    act = torch.randn(n, c, h, w, generator=g)
+    y = ops.conv1x1(x2.to(DEV), ws.to(DEV), None, c, mask_aux=act.to(DEV))
+    report("stem tangent", y, F.conv2d(x2.double(), ws.double()) * torch.where(act > 0, 1.0, 0.2).double(), 2e-6)
+    # head: C -> 2 + tanh
+    mp = ops.conv1x1(xc.to(DEV), wh.to(DEV), bh.to(DEV), 2, tanh=True)
+    mp_ref = torch.tanh(F.conv2d(xc.double(), wh.double(), bh.double()))
+    report("head", mp, mp_ref, 3e-6)
+    # stem dgrad: C -> 2 with w^T
+    gyc = torch.randn(n, c, h, w, generator=g)
+    gx = ops.conv1x1(gyc.to(DEV), ws.to(DEV), None, 2, transposed=True)
+    report("stem dgrad", gx, F.conv_transpose2d(gyc.double(), ws.double()), 3e-6)
+    # head dgrad with tanh backward on the input: 2 -> C
+    gy2 = torch.randn(n, 2, h, w, generator=g)
+    gxh = ops.conv1x1(gy2.to(DEV), wh.to(DEV), None, c, transposed=True, tanh_bwd_in=mp)
+    ref = F.conv_transpose2d(gy2.double() * (1 - mp_ref ** 2), wh.double())
+    report("head dgrad", gxh, ref, 5e-6)
+    # stem wgrad
+    gw = torch.empty(c, 2, 1, 1, device=DEV)
+    gb = torch.empty(c, device=DEV)
+    ops.conv1x1_wgrad(x2.to(DEV), gyc.to(DEV), gw, gb)
+    ref_w = torch.einsum("nohw,nchw->oc", gyc.double(), x2.double())
+    report("stem wgrad", gw.reshape(c, 2), ref_w, 3e-6)
+    report("stem bgrad", gb, gyc.double().sum(dim=(0, 2, 3)), 3e-6)
+    ops.conv1x1_wgrad(x2.to(DEV), gyc.to(DEV), gw, None, accumulate=True)
+    report("stem wgrad acc", gw.reshape(c, 2), 2 * ref_w, 3e-6)
+    # head wgrad with tanh backward
+    gwh = torch.empty(2, c, 1, 1, device=DEV)
+    gbh = torch.empty(2, device=DEV)
+    ops.conv1x1_wgrad(xc.to(DEV), gy2.to(DEV), gwh, gbh, tanh_y=mp)
+    gpre = gy2.double() * (1 - mp_ref ** 2)
+    report("head wgrad", gwh.reshape(2, c), torch.einsum("nohw,nchw->oc", gpre, xc.double()), 5e-6)
+    report("head bgrad", gbh, gpre.sum(dim=(0, 2, 3)), 5e-6)
+
+
+def test_elementwise_ops():
+    ops = _ops()
+    g = torch.Generator().manual_seed(7)
+    for (n, c, h, w) in [(2, 48, 8, 8), (3, 7, 2, 2), (1, 160, 1, 1), (2, 16, 6, 10)]:
+        y = torch.randn(n, c, h, w, generator=g)
+        gp = torch.randn(n, c, h, w, generator=g)
+        yd = y.double().requires_grad_(True)
+        act = F.leaky_relu(yd, 0.2)
+        pn = act / torch.sqrt(act.pow(2).mean(dim=1, keepdim=True) + 1e-8)
+        (pn * gp.double()).sum().backward()
+        a = act.detach().float().to(DEV)
+        p, rn = ops.pixelnorm_fwd(a)
+        report("pn fwd", p, pn, 3e-6)
+        gpre = ops.pixelnorm_lrelu_bwd(gp.to(DEV), a, rn)
+        report("pn+lrelu bwd", gpre, yd.grad, 1e-5)
+        report("up fwd", ops.upsample2x_fwd(y.to(DEV)), F.interpolate(y, scale_factor=2.0, mode="nearest"), 0)
+        g2 = torch.randn(n, c, 2 * h, 2 * w, generator=g)
+        report("up bwd", ops.upsample2x_bwd(g2.to(DEV)), F.avg_pool2d(g2.double(), 2, 2) * 4, 1e-6)
+        report("pool fwd", ops.avgpool2_fwd(g2.to(DEV)), F.avg_pool2d(g2.double(), 2, 2), 1e-6)
+        act2 = torch.randn(n, c, 2 * h, 2 * w, generator=g)
+        ref = F.interpolate(y.double(), scale_factor=2.0, mode="nearest") * 0.25
+        report("pool bwd", ops.avgpool2_bwd(y.to(DEV)), ref, 1e-6)
+        report("pool bwd mask", ops.avgpool2_bwd(y.to(DEV), act2.to(DEV)), ref * torch.where(act2 > 0, 1.0, 0.2), 1e-6)
+        report("lrelu bwd", ops.lrelu_bwd(gp.to(DEV), y.to(DEV)), gp * torch.where(y > 0, 1.0, 0.2), 1e-7)
+        report("axpby", ops.axpby(0.37, y.to(DEV), 0.63, gp.to(DEV)), 0.37 * y.double() + 0.63 * gp.double(), 1e-6)
+        report("ax", ops.axpby(0.37, y.to(DEV)), 0.37 * y.double(), 1e-6)
+        report("blend_up", ops.blend_up(0.37, g2.to(DEV), 0.63, y.to(DEV)),
+               0.37 * g2.double() + 0.63 * F.interpolate(y.double(), scale_factor=2.0, mode="nearest"), 1e-6)
+        report("chan sum", ops.channel_sum(y.to(DEV)), y.double().sum(dim=(0, 2, 3)), 1e-5)
+
+
+def test_linear_and_gp_helpers():
+    ops = _ops()
+    g = torch.Generator().manual_seed(8)
+    n, k = 7, 160
+    x = torch.randn(n, k, generator=g)
+    w = torch.randn(1, k, generator=g)
+    b = torch.randn(1, generator=g)
+    gy = torch.randn(n, 1, generator=g)
+    report("linear fwd", ops.linear1_fwd(x.to(DEV), w.to(DEV), b.to(DEV)), F.linear(x.double(), w.double(), b.double()), 2e-6)
+    gw = torch.empty(1, k, device=DEV)
+    gb = torch.empty(1, device=DEV)
+    gx = ops.linear1_bwd(x.to(DEV), w.to(DEV), gy.to(DEV), gw=gw, gb=gb)
+    report("linear gx", gx, gy.double() @ w.double(), 1e-6)
+    report("linear gw", gw, gy.double().t() @ x.double(), 2e-6)
+    report("linear gb", gb, gy.double().sum().reshape(1), 2e-6)
+    xr = torch.randn(n, 2, 8, 8, generator=g)
+    xf = torch.randn(n, 2, 8, 8, generator=g)
+    eps = torch.rand(n, 1, 1, 1, generator=g)
+    report("interp", ops.gp_interp(xr.to(DEV), xf.to(DEV), eps.to(DEV)), eps * xr + (1 - eps) * xf, 1e-6)
+    ss = ops.sumsq_per_sample(xr.to(DEV))
+    report("sumsq", ss, xr.double().pow(2).sum(dim=(1, 2, 3)), 2e-6)
+    pen, coef = ops.gp_finish(ss, 10.0, 1.0)
+    nrm = xr.double().reshape(n, -1).norm(dim=1)
+    report("penalty", pen, 10 * ((nrm - 1) ** 2).mean(), 2e-6)
+    report("coef", coef, 10 * 2 * (nrm - 1) / (n * nrm), 2e-6)
+    report("scale", ops.scale_per_sample(xr.to(DEV), coef), xr.double() * (10 * 2 * (nrm - 1) / (n * nrm)).reshape(n, 1, 1, 1), 3e-6)
+
+
+def test_stft_kernel_matches_oracle_and_torch():
+    ops = _ops()
+    from oracle import audio as OA
+    g = torch.Generator().manual_seed(9)
+    for length in (141_312, 256 * 40 + 17, 1024):
+        wav = torch.rand(length, generator=g) - 0.5
+        got = ops.stft_1024(wav.to(DEV)).cpu()
+        ref = torch.from_numpy(OA.stft(wav.numpy()))
+        assert got.shape == ref.shape == (512, 1 + length // 256)
+        err = float((got - ref).abs().max() / ref.abs().max())
+        assert err <= 1e-5, f"stft L={length}: rel err {err:.3e}"
+        tref = torch.stft(wav, 1024, 256, 1024, torch.hann_window(1024), center=True, pad_mode="reflect",
+                          normalized=False, onesided=True, return_complex=True)[:-1] / math.sqrt(384.0)
+        assert float((got - tref).abs().max() / tref.abs().max()) <= 1e-5
+    # bin indexing is exact: a pure tone at bin 37 peaks at row 37 of every interior frame
+    t = torch.arange(44100, dtype=torch.float64)
+    tone = torch.sin(2 * math.pi * 37 * t / 1024).float()
+    spec = ops.stft_1024(tone.to(DEV)).abs().cpu()
+    assert bool((spec[:, 4:-4].argmax(dim=0) == 37).all())
