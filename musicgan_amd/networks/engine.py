@@ -1,0 +1,299 @@
+"""Layer plans of the ProGAN generator / discriminator on the HIP kernels: forward, hand-derived backward, and the WGAN-GP
+second-order pass.  Pure host-side sequencing (Python) over `musicgan_amd.ops`; no autograd inside.
+
+Math restated from /root/reference/music_gan/networks (generator.py:106-126, discriminator.py:107-124,157-184):
+
+Generator block i (C_i -> C_o):  y1 = LReLU(conv3(x));  p1 = PN(y1);  y2 = LReLU(conv3(up2(p1)));  p2 = PN(y2)
+  backward: g_pre = mask(y) * rn * (g_p - p * mean_c(g_p * p))   [PixelNorm + LeakyReLU, one kernel]
+            wgrad(x_in, g_pre), dgrad(g_pre) ; up2 backward = 2x2 block sums.
+Discriminator block i:  a1 = LReLU(conv3(in)); q1 = avgpool2(a1); a2 = LReLU(conv3(q1))
+  backward: the LeakyReLU mask of the layer below is fused on the OUTPUT of each data-gradient conv (MG_CONV_MASK_AUX).
+
+Gradient penalty  P = 10 * mean_n (||g_0[n]|| - 1)^2,  g_0 = d D(x~) / d x~  (first-order chain with g_out = 1):
+  the chain is linear in every weight: g_{l-1} = L_l(W_l)^T h_l with h_l = mask_l * g_l (masks are piecewise constant, their
+  derivative is zero -- autograd's leaky_relu double-backward returns zeros there too).  Back-propagating P through that chain
+  is a *forward* pass of the bias-free network on u_0 = dP/dg_0 with the saved masks:
+        u_l = mask_l * L_l(W_l) u_{l-1},        dP/dW_l = wgrad(x = u_{l-1}, gy = h_l),      dP/db = 0
+  so the penalty's parameter gradient costs one extra forward-like pass and one wgrad per layer (10 D-forward equivalents per
+  D step in total) and never touches the autograd engine.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from .. import ops
+
+
+class PackCache:
+    """Packed (LDS-image) conv3x3 weights, refreshed when the parameter's storage or version changes."""
+
+    def __init__(self):
+        self._c: Dict = {}
+
+    def get(self, w: torch.Tensor, dgrad: bool) -> torch.Tensor:
+        key = (id(w), dgrad)
+        tag = (w.data_ptr(), w._version, w.device)
+        ent = self._c.get(key)
+        if ent is None or ent[0] != tag:
+            ent = (tag, ops.pack_conv3x3(w.detach(), dgrad))
+            self._c[key] = ent
+        return ent[1]
+
+    def clear(self):
+        self._c.clear()
+
+
+class GradSink:
+    """Collects parameter gradients keyed by the parameter object; a second write to the same key accumulates."""
+
+    def __init__(self):
+        self.g: Dict[int, torch.Tensor] = {}
+
+    def slot(self, param: torch.Tensor):
+        k = id(param)
+        if k in self.g:
+            return self.g[k], True
+        t = torch.empty_like(param, memory_format=torch.contiguous_format)
+        self.g[k] = t
+        return t, False
+
+    def get(self, param: torch.Tensor) -> Optional[torch.Tensor]:
+        return self.g.get(id(param))
+
+
+# =====================================================================================================================
+# Generator
+# =====================================================================================================================
+class GenWeights:
+    """Views of the live generator parameters at the current level."""
+
+    def __init__(self, blocks, head, old_head):
+        self.blocks = blocks      # list of (w1, b1, w2, b2)
+        self.head = head          # (w, b)
+        self.old_head = old_head  # (w, b) or None
+
+    def tensors(self) -> List[torch.Tensor]:
+        out = []
+        for blk in self.blocks:
+            out += list(blk)
+        out += list(self.head)
+        if self.old_head is not None:
+            out += list(self.old_head)
+        return out
+
+
+def gen_forward(W: GenWeights, z: torch.Tensor, alpha: float, cache: PackCache, save: bool):
+    x = z.contiguous()
+    saved = []
+    for (w1, b1, w2, b2) in W.blocks:
+        ci, co = w1.shape[0], w2.shape[0]
+        y1, p1, rn1 = ops.conv3x3(x, cache.get(w1, False), b1, ci, lrelu=True, pixnorm=True)
+        y2, p2, rn2 = ops.conv3x3(p1, cache.get(w2, False), b2, co, ups=True, lrelu=True, pixnorm=True)
+        if save:
+            saved.append((x, y1, rn1, p1, y2, rn2))
+        x_in_last, x = x, p2
+    mp = ops.conv1x1(x, W.head[0], W.head[1], 2, tanh=True)
+    old = None
+    if W.old_head is not None:
+        old = ops.conv1x1(x_in_last, W.old_head[0], W.old_head[1], 2, tanh=True)
+        out = ops.blend_up(alpha, mp, 1.0 - alpha, old)
+    else:
+        out = mp
+    ctx = (saved, x, mp, old, alpha) if save else None
+    return out, ctx
+
+
+def gen_backward(W: GenWeights, ctx, g_out: torch.Tensor, cache: PackCache, sink: GradSink, need_gz: bool = False):
+    saved, x_last, mp, old, alpha = ctx
+    g_out = g_out.contiguous()
+    if W.old_head is not None:
+        g_mp = ops.axpby(alpha, g_out)
+        g_old = ops.upsample2x_bwd(g_out)
+        g_old = ops.axpby(1.0 - alpha, g_old, out=g_old)
+    else:
+        g_mp, g_old = g_out, None
+    gw, acc = sink.slot(W.head[0])
+    gb, _ = sink.slot(W.head[1])
+    ops.conv1x1_wgrad(x_last, g_mp, gw, gb, tanh_y=mp, accumulate=acc)
+    g = ops.conv1x1(g_mp, W.head[0], None, x_last.shape[1], transposed=True, tanh_bwd_in=mp)
+    last = len(W.blocks) - 1
+    gz = None
+    for i in range(last, -1, -1):
+        w1, b1, w2, b2 = W.blocks[i]
+        xin, y1, rn1, p1, y2, rn2 = saved[i]
+        ci = w1.shape[0]
+        gpre2 = ops.pixelnorm_lrelu_bwd(g, y2, rn2)
+        gw2, acc = sink.slot(w2)
+        gb2, _ = sink.slot(b2)
+        ops.conv3x3_wgrad(p1, gpre2, gw2, gb2, ups=True, accumulate=acc)
+        gup = ops.conv3x3(gpre2, cache.get(w2, True), None, ci)
+        gp1 = ops.upsample2x_bwd(gup)
+        gpre1 = ops.pixelnorm_lrelu_bwd(gp1, y1, rn1)
+        gw1, acc = sink.slot(w1)
+        gb1, _ = sink.slot(b1)
+        ops.conv3x3_wgrad(xin, gpre1, gw1, gb1, accumulate=acc)
+        if i > 0:
+            g = ops.conv3x3(gpre1, cache.get(w1, True), None, ci)
+            if g_old is not None and i == last:
+                gwo, acc = sink.slot(W.old_head[0])
+                gbo, _ = sink.slot(W.old_head[1])
+                ops.conv1x1_wgrad(xin, g_old, gwo, gbo, tanh_y=old, accumulate=acc)
+                extra = ops.conv1x1(g_old, W.old_head[0], None, xin.shape[1], transposed=True, tanh_bwd_in=old)
+                g = ops.axpby(1.0, g, 1.0, extra, out=g)
+        elif need_gz:
+            gz = ops.conv3x3(gpre1, cache.get(w1, True), None, ci)
+    return gz
+
+
+# =====================================================================================================================
+# Discriminator
+# =====================================================================================================================
+class DiscWeights:
+    def __init__(self, stem, blocks, old_stem, clf):
+        self.stem = stem          # (w, b): 2 -> C0
+        self.blocks = blocks      # list of (w1, b1, w2, b2) for conv_blocks[curr..8]
+        self.old_stem = old_stem  # (w, b) or None: 2 -> C1 of the first live block
+        self.clf = clf            # (w[1,160], b[1])
+
+    def tensors(self) -> List[torch.Tensor]:
+        out = list(self.stem)
+        for blk in self.blocks:
+            out += list(blk)
+        if self.old_stem is not None:
+            out += list(self.old_stem)
+        out += list(self.clf)
+        return out
+
+
+def disc_forward(W: DiscWeights, x: torch.Tensor, alpha: float, cache: PackCache, save: bool):
+    x = x.contiguous()
+    n = x.shape[0]
+    c0 = W.stem[0].shape[0]
+    h0 = ops.conv1x1(x, W.stem[0], W.stem[1], c0, lrelu=True)
+    saved = []
+    inp = h0
+    xp = o = None
+    for i, (w1, b1, w2, b2) in enumerate(W.blocks):
+        c1 = w1.shape[0]
+        a1 = ops.conv3x3(inp, cache.get(w1, False), b1, c1, lrelu=True)
+        q1 = ops.avgpool2_fwd(a1)
+        a2 = ops.conv3x3(q1, cache.get(w2, False), b2, c1, lrelu=True)
+        if save:
+            saved.append((inp, a1, q1, a2))
+        inp = a2
+        if i == 0 and W.old_stem is not None:
+            xp = ops.avgpool2_fwd(x)
+            o = ops.conv1x1(xp, W.old_stem[0], W.old_stem[1], c1, lrelu=True)
+            inp = ops.axpby(alpha, a2, 1.0 - alpha, o)
+    assert inp.shape[2] == 1 and inp.shape[3] == 1, \
+        f"discriminator input must be square with side 2**(9-curr_layer); final map is {tuple(inp.shape)}"
+    flat = inp.reshape(n, -1)
+    out = ops.linear1_fwd(flat, W.clf[0], W.clf[1])
+    ctx = (x, h0, saved, xp, o, flat, alpha) if save else None
+    return out, ctx
+
+
+def disc_backward(W: DiscWeights, ctx, g_out: torch.Tensor, cache: PackCache, sink: Optional[GradSink],
+                  need_gx: bool, keep_h: bool = False):
+    """Back-propagate g_out (N,1).  sink=None skips all parameter gradients (first-order pass of the penalty).
+    keep_h returns the masked per-layer gradients h_l needed by disc_gp_param_grads()."""
+    x, h0, saved, xp, o, flat, alpha = ctx
+    g_out = g_out.contiguous()
+    n = x.shape[0]
+    if sink is not None:
+        gwc, acc = sink.slot(W.clf[0])
+        gbc, _ = sink.slot(W.clf[1])
+        g = ops.linear1_bwd(flat, W.clf[0], g_out, gw=gwc, gb=gbc, accumulate=acc)
+    else:
+        g = ops.linear1_bwd(flat, W.clf[0], g_out, need_gx=True)
+    nb = len(W.blocks)
+    hs = {"blocks": [None] * nb, "stem": None, "old": None}
+    a2_last = saved[nb - 1][3]
+    g = g.reshape(a2_last.shape)
+    if nb == 1 and W.old_stem is not None:  # the blend is the classifier input
+        gpre2 = ops.lrelu_bwd(ops.axpby(alpha, g), a2_last)
+        gpre_o = ops.lrelu_bwd(ops.axpby(1.0 - alpha, g), o)
+    else:
+        gpre2 = ops.lrelu_bwd(g, a2_last)
+        gpre_o = None
+    gpre_s = None
+    for i in range(nb - 1, -1, -1):
+        w1, b1, w2, b2 = W.blocks[i]
+        inp, a1, q1, a2 = saved[i]
+        c1, cin = w1.shape[0], w1.shape[1]
+        if sink is not None:
+            gw2, acc = sink.slot(w2)
+            gb2, _ = sink.slot(b2)
+            ops.conv3x3_wgrad(q1, gpre2, gw2, gb2, accumulate=acc)
+        gq1 = ops.conv3x3(gpre2, cache.get(w2, True), None, c1)
+        gpre1 = ops.avgpool2_bwd(gq1, a1)
+        if sink is not None:
+            gw1, acc = sink.slot(w1)
+            gb1, _ = sink.slot(b1)
+            ops.conv3x3_wgrad(inp, gpre1, gw1, gb1, accumulate=acc)
+        if keep_h:
+            hs["blocks"][i] = (gpre1, gpre2)
+        if i > 0:
+            a2_prev = saved[i - 1][3]
+            if i == 1 and W.old_stem is not None:  # inp is the fade-in blend of a2_prev and the old stem path
+                gblend = ops.conv3x3(gpre1, cache.get(w1, True), None, cin)
+                gpre2 = ops.lrelu_bwd(ops.axpby(alpha, gblend), a2_prev)
+                gpre_o = ops.lrelu_bwd(ops.axpby(1.0 - alpha, gblend), o)
+            else:
+                gpre2 = ops.conv3x3(gpre1, cache.get(w1, True), None, cin, mask_aux=a2_prev)
+        else:
+            gpre_s = ops.conv3x3(gpre1, cache.get(w1, True), None, cin, mask_aux=h0)
+    if sink is not None:
+        gws, acc = sink.slot(W.stem[0])
+        gbs, _ = sink.slot(W.stem[1])
+        ops.conv1x1_wgrad(x, gpre_s, gws, gbs, accumulate=acc)
+        if W.old_stem is not None:
+            gwo, acc = sink.slot(W.old_stem[0])
+            gbo, _ = sink.slot(W.old_stem[1])
+            ops.conv1x1_wgrad(xp, gpre_o, gwo, gbo, accumulate=acc)
+    if keep_h:
+        hs["stem"], hs["old"] = gpre_s, gpre_o
+    gx = None
+    if need_gx:
+        gx = ops.conv1x1(gpre_s, W.stem[0], None, 2, transposed=True)
+        if W.old_stem is not None:
+            gxp = ops.conv1x1(gpre_o, W.old_stem[0], None, 2, transposed=True)
+            gx = ops.axpby(1.0, gx, 1.0, ops.avgpool2_bwd(gxp), out=gx)
+    return gx, (hs if keep_h else None)
+
+
+def disc_gp_param_grads(W: DiscWeights, ctx, hs, u0: torch.Tensor, cache: PackCache, sink: GradSink):
+    """Second-order pass of the gradient penalty: tangent-forward u_l = mask_l * L_l u_{l-1} and dP/dW_l = wgrad(u_{l-1}, h_l).
+    Biases receive no gradient from the penalty."""
+    x, h0, saved, xp, o, flat, alpha = ctx
+    n = x.shape[0]
+    c0 = W.stem[0].shape[0]
+    gws, acc = sink.slot(W.stem[0])
+    ops.conv1x1_wgrad(u0, hs["stem"], gws, None, accumulate=acc)
+    t = ops.conv1x1(u0, W.stem[0], None, c0, mask_aux=h0)
+    to = None
+    if W.old_stem is not None:
+        u0p = ops.avgpool2_fwd(u0)
+        gwo, acc = sink.slot(W.old_stem[0])
+        ops.conv1x1_wgrad(u0p, hs["old"], gwo, None, accumulate=acc)
+        to = ops.conv1x1(u0p, W.old_stem[0], None, W.old_stem[0].shape[0], mask_aux=o)
+    for i, (w1, b1, w2, b2) in enumerate(W.blocks):
+        inp, a1, q1, a2 = saved[i]
+        gpre1, gpre2 = hs["blocks"][i]
+        c1 = w1.shape[0]
+        gw1, acc = sink.slot(w1)
+        ops.conv3x3_wgrad(t, gpre1, gw1, None, accumulate=acc)
+        t1 = ops.conv3x3(t, cache.get(w1, False), None, c1, mask_aux=a1)
+        tq = ops.avgpool2_fwd(t1)
+        gw2, acc = sink.slot(w2)
+        ops.conv3x3_wgrad(tq, gpre2, gw2, None, accumulate=acc)
+        t = ops.conv3x3(tq, cache.get(w2, False), None, c1, mask_aux=a2)
+        if i == 0 and to is not None:
+            t = ops.axpby(alpha, t, 1.0 - alpha, to, out=t)
+    ones = torch.ones((n, 1), dtype=torch.float32, device=x.device)
+    gwc, acc = sink.slot(W.clf[0])
+    ops.linear1_bwd(t.reshape(n, -1), W.clf[0], ones, gw=gwc, gb=None, need_gx=False, accumulate=acc)
+    # parameters that the penalty does not reach (biases) still need a defined gradient when this sink is returned alone
+    return sink

@@ -1,0 +1,209 @@
+"""GPU parity of the drop-in modules (Generator / Discriminator / gradient_penalty / FusedAdam) driven exactly like
+/root/reference/music_gan/train.py:152-214, against (a) the golden vectors captured from the reference and (b) the CPU
+oracle in fp64.  Tolerances are the ones stated in SURVEY 8(c) / BASELINE.md:
+  forward <= 1e-5 max-norm relative; losses/GP 1e-6 abs (GP 1e-5: it is ~10 with a 1e-6 relative error);
+  gradients per tensor max|d| <= 1e-3 * max|g| against the fp64 oracle; post-Adam weights 2e-6.
+"""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import PROGAN_CASES, build_oracle_states, check_tensor, load, sample_idx
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+FWD_TOL = 1e-5
+GRAD_TOL = 1e-3
+
+
+def build_modules(g):
+    from musicgan_amd.networks import Discriminator, Generator
+    torch.manual_seed(int(g["seed"]))
+    gen = Generator(int(g["rand_channels"]), end_layer=int(g["g_end_layer"]))
+    disc = Discriminator(start_layer=int(g["d_start_layer"]))
+    for _ in range(int(g["n_grow"])):
+        gen.next_layer()
+        disc.next_layer()
+    ws = float(g["wscale"])
+    if ws != 1.0:
+        with torch.no_grad():
+            for net in (gen, disc):
+                for k, p in net.named_parameters():
+                    if k.endswith("weight"):
+                        p.mul_(ws)
+    return gen.to(DEV), disc.to(DEV)
+
+
+def maxrel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("case", PROGAN_CASES)
+def test_train_step_matches_reference_golden(case):
+    from musicgan_amd import networks
+    from musicgan_amd.optim import FusedAdam
+    from oracle import progan as O
+
+    g = load(f"progan_{case}.npz")
+    gen, disc = build_modules(g)
+    assert list(gen.state_dict().keys()) == list(g["g_keys"])
+    assert list(disc.state_dict().keys()) == list(g["d_keys"])
+    alpha = float(g["alpha"])
+    z, z2 = torch.from_numpy(g["z"]).to(DEV), torch.from_numpy(g["z2"]).to(DEV)
+    x_real, eps = torch.from_numpy(g["x_real"]).to(DEV), torch.from_numpy(g["eps"]).to(DEV)
+    optim_gen = FusedAdam(gen.parameters(), lr=1e-3, betas=(0.0, 0.9))
+    optim_disc = FusedAdam(disc.parameters(), lr=1e-3, betas=(0.0, 0.9))
+
+    # fp64 oracle of the same step (the gradient yard-stick)
+    gs, ds = build_oracle_states(g)
+    oargs = (torch.from_numpy(g["x_real"]), torch.from_numpy(g["z"]), torch.from_numpy(g["eps"]), alpha)
+    o64 = O.d_step(gs, ds, *oargs, dtype=torch.float64)
+    o32 = O.d_step(gs, ds, *oargs, dtype=torch.float32)
+
+    def grad_tol(k, which="d_grads"):
+        # 1e-3 * max|g| vs fp64, or twice the plain-PyTorch fp32 evaluation's own deviation from fp64
+        # (the penalty's gradient cancels heavily when ||grad_x D|| << 1)
+        return max(GRAD_TOL, 2.0 * maxrel(o32[which][k], o64[which][k]))
+
+    # ---- D step exactly as train.py:152-175 (x_fake NOT detached)
+    x_fake = gen(z, alpha)
+    out_real = disc(x_real, alpha)
+    out_fake = disc(x_fake, alpha)
+    d_loss = networks.wasserstein_discriminator_loss(out_real, out_fake)
+    grad_pen = disc.gradient_penalty_with_eps(x_real, x_fake, alpha, eps)
+    gen.zero_grad()
+    disc.zero_grad()
+    (d_loss + grad_pen).backward()
+
+    assert maxrel(x_fake, torch.from_numpy(g["x_fake"])) <= FWD_TOL
+    assert maxrel(out_real, torch.from_numpy(g["out_real"])) <= 2 * FWD_TOL
+    assert maxrel(out_fake, torch.from_numpy(g["out_fake"])) <= 2 * FWD_TOL
+    # the loss is a difference of two output means, each carrying the forward tolerance
+    out_scale = max(float(np.abs(g["out_real"]).max()), float(np.abs(g["out_fake"]).max()))
+    assert abs(float(d_loss) - float(g["disc_loss"])) <= 1e-6 + 2 * FWD_TOL * out_scale
+    assert abs(float(grad_pen) - float(g["grad_pen"])) <= 1e-5
+    assert abs(float(grad_pen) - float(o64["grad_pen"])) <= 1e-5
+
+    live = {k: p for k, p in disc.named_parameters() if p.grad is not None}
+    assert sorted(live.keys()) == sorted(g["dstep_d_live"])
+    worst = 0.0
+    for k, p in live.items():
+        e = maxrel(p.grad, o64["d_grads"][k])
+        worst = max(worst, e)
+        assert e <= grad_tol(k), f"D grad {k}: {e:.3e} vs fp64 oracle (tol {grad_tol(k):.1e})"
+        check_tensor(g, f"dstep_dgrad|{k}", p.grad, 2 * grad_tol(k), what="golden ")
+    # G receives (later discarded) gradients in the reference's D step; ours match those too
+    live_g = {k: p for k, p in gen.named_parameters() if p.grad is not None}
+    assert sorted(live_g.keys()) == sorted(g["dstep_g_live"])
+    for k, p in live_g.items():
+        assert maxrel(p.grad, o64["g_grads"][k]) <= grad_tol(k, "g_grads"), f"G grad (D step) {k}"
+
+    before = {k: (p.detach().clone(), None if p.grad is None else p.grad.detach().clone())
+              for k, p in disc.named_parameters()}
+    optim_disc.step()
+    for k, p in disc.named_parameters():
+        w0, gr = before[k]
+        if gr is None:
+            assert torch.equal(p.detach(), w0), f"{k}: parameter without gradient must not move"
+            continue
+        # (a) the fused kernel is torch.optim.Adam's update rule applied to OUR gradient, to fp32 round-off
+        exp, _, _ = O.adam_update(w0.double().cpu(), gr.double().cpu(), torch.zeros_like(w0).double().cpu(),
+                                  torch.zeros_like(w0).double().cpu(), 1)
+        assert maxrel(p, exp) <= 2e-6, f"Adam kernel {k}"
+        # (b) vs the reference's weights: the first step is lr*g/(|g|+1e-8), which amplifies fp32 round-off of entries with
+        # |g| ~ 1e-8 (the near-zero penalty gradients of a fresh critic); bound: a small fraction of one lr step
+        samp = g[f"dstep_dparam|{k}|samp"]
+        got = p.detach().cpu().reshape(-1).numpy()[sample_idx(p.numel())]
+        assert float(np.abs(got - samp).max()) <= 0.25 * 1e-3, f"post-Adam {k}"
+
+    # ---- G step, train.py:191-214
+    x_fake2 = gen(z2, alpha)
+    out_fake2 = disc(x_fake2, alpha)
+    g_loss = networks.wasserstein_generator_loss(out_fake2)
+    gen.zero_grad()
+    disc.zero_grad()
+    g_loss.backward()
+    assert maxrel(x_fake2, torch.from_numpy(g["x_fake2"])) <= FWD_TOL
+    assert abs(float(g_loss) - float(g["gen_loss"])) <= 1e-6
+    for k, p in gen.named_parameters():
+        if p.grad is not None:
+            check_tensor(g, f"gstep_ggrad|{k}", p.grad, GRAD_TOL, what="golden ")
+    optim_gen.step()
+    for k, p in gen.named_parameters():
+        samp = g[f"gstep_gparam|{k}|samp"]
+        got = p.detach().cpu().reshape(-1).numpy()[sample_idx(p.numel())]
+        assert float(np.abs(got - samp).max()) <= 0.25 * 1e-3, f"post-Adam {k}"
+    print(f"{case}: worst D-grad rel err vs fp64 {worst:.2e}")
+
+
+def test_shapes_walk_and_growth_flags():
+    """The walk of the reference's networks/test_networks.py:4-38 (shapes at every level; growing flags)."""
+    from musicgan_amd.networks import Discriminator, Generator
+    g = load("progan_shapes.npz")
+    torch.manual_seed(5)
+    gen, disc = Generator(8).to(DEV), Discriminator(7).to(DEV)
+    for i in range(gen.down_sample + 3):
+        z = torch.randn(1, 8, 2, 2, device=DEV)
+        with torch.no_grad():
+            out = gen(z, 0.5)
+            dout = disc(out, 0.5)
+        assert list(out.shape) == list(g["g_out_shapes"][i])
+        assert list(dout.shape) == list(g["d_out_shapes"][i])
+        assert [int(gen.growing), int(disc.growing)] == list(g["growing"][i])
+        gen.next_layer()
+        disc.next_layer()
+    assert list(gen.state_dict().keys()) == list(g["g_keys_final"])
+    assert list(disc.state_dict().keys()) == list(g["d_keys_final"])
+    assert next(gen.end_block_params()).is_cuda and next(disc.start_block_parameters()).is_cuda
+
+
+def test_nonsquare_generator_forward():
+    """generate.py:47-54 feeds a non-square latent through a directly constructed Generator(end_layer=k)."""
+    from musicgan_amd.networks import Generator
+    g = load("progan_shapes.npz")
+    torch.manual_seed(6)
+    gen = Generator(8, end_layer=2).to(DEV)
+    z = torch.from_numpy(g["ns_z"]).to(DEV)
+    with torch.no_grad():
+        assert maxrel(gen(z, 1.0), torch.from_numpy(g["ns_out"])) <= FWD_TOL
+        assert maxrel(gen(z, 0.37), torch.from_numpy(g["ns_out_a037"])) <= FWD_TOL
+
+
+def test_level4_step_against_oracle():
+    """BASELINE.json configs[1] shape family (2x64x64) at a small batch: product vs the fp64 CPU oracle."""
+    from musicgan_amd import networks
+    from musicgan_amd.networks import Discriminator, Generator
+    from oracle import progan as O
+    torch.manual_seed(0)
+    gs, ds = O.GenState(32), O.DiscState(7)
+    for _ in range(4):
+        gs.next_layer()
+        ds.next_layer()
+    torch.manual_seed(0)
+    gen, disc = Generator(32), Discriminator(7)
+    for _ in range(4):
+        gen.next_layer()
+        disc.next_layer()
+    gen, disc = gen.to(DEV), disc.to(DEV)
+    rng = torch.Generator().manual_seed(1234)
+    n = 4
+    x_real = torch.rand(n, 2, 64, 64, generator=rng) * 2 - 1
+    z = torch.randn(n, 32, 2, 2, generator=rng)
+    eps = torch.rand(n, 1, 1, 1, generator=rng)
+    ref = O.d_step(gs, ds, x_real, z, eps, 0.5, dtype=torch.float64, detach_fake=True)
+    ref32 = O.d_step(gs, ds, x_real, z, eps, 0.5, dtype=torch.float32, detach_fake=True)
+    x_fake = gen(z.to(DEV), 0.5).detach()
+    out_real = disc(x_real.to(DEV), 0.5)
+    out_fake = disc(x_fake, 0.5)
+    loss = networks.wasserstein_discriminator_loss(out_real, out_fake) + \
+        disc.gradient_penalty_with_eps(x_real.to(DEV), x_fake, 0.5, eps.to(DEV))
+    disc.zero_grad()
+    loss.backward()
+    assert maxrel(x_fake, ref["x_fake"]) <= FWD_TOL
+    for k, p in disc.named_parameters():
+        if p.grad is not None:
+            tol = max(GRAD_TOL, 2.0 * maxrel(ref32["d_grads"][k], ref["d_grads"][k]))
+            assert maxrel(p.grad, ref["d_grads"][k]) <= tol, f"{k}: {maxrel(p.grad, ref['d_grads'][k]):.2e} > {tol:.1e}"
+    assert all(p.grad is None for p in gen.parameters())
