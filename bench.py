@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Headline benchmark: spectrogram-images/sec of one ProGAN G+D step (one discriminator update with gradient penalty + one
+generator update, Adam on both -- /root/reference/music_gan/train.py:143-175,191-214) on synthetic 2x128x128 STFT tensors,
+batch 64 per GPU, level 5 with the fade-in branch live (alpha = 0.5).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (whole-step algorithmic FLOPs against the
+exact-fp32 MFMA peak, plus the dominant kernel timed live with HIP events) and, at N=1, `cpu_baseline` (the CPU oracle -- a
+plain-PyTorch port of the reference step as executed -- on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense, exact fp32
+LEVEL_SIDE = {3: 32, 4: 64, 5: 128}
+
+
+def build_nets(level: int, rand_channels: int, device):
+    from musicgan_amd.networks import Discriminator, Generator
+    torch.manual_seed(0)
+    gen, disc = Generator(rand_channels, end_layer=0), Discriminator(start_layer=7)
+    for _ in range(level):
+        gen.next_layer()
+        disc.next_layer()
+    return gen.to(device), disc.to(device)
+
+
+def flops_per_image(level: int, rand_channels: int) -> float:
+    """Algorithmic minimum 4*Gf + 12*Df; conv/linear MACs x 2 only.  Pure arithmetic on the layer table."""
+    tail = [128, 112, 96, 80, 64, 48, 32, 16]
+    ins = [rand_channels] + tail[:-1]
+    dch = [(16, 32), (32, 48), (48, 64), (64, 80), (80, 96), (96, 112), (112, 128), (128, 144), (144, 160)]
+    g, s = 0.0, 2
+    for i in range(level + 1):
+        g += 18 * ins[i] * ins[i] * s * s
+        s *= 2
+        g += 18 * ins[i] * tail[i] * s * s
+    g += 4 * tail[level] * s * s + (4 * tail[level - 1] * (s // 2) ** 2 if level > 0 else 0)
+    dl = 7 - level
+    d = 4 * dch[dl][0] * s * s + (4 * dch[dl][1] * (s // 2) ** 2 if level > 0 else 0)
+    t = s
+    for i in range(dl, 9):
+        ci, co = dch[i]
+        d += 18 * ci * co * t * t
+        t //= 2
+        d += 18 * co * co * t * t
+    d += 320
+    return 4 * g + 12 * d
+
+
+def dominant_kernel_probe(device, batch: int, iters: int = 10):
+    """Time the dominant kernel of the step (fused upsample-conv3x3 64->48 @128x128 + LeakyReLU + PixelNorm, the last
+    generator conv: 57.98 GFLOP at batch 64) with HIP events on the stream it is launched on."""
+    from musicgan_amd import ops
+    g = torch.Generator(device=device).manual_seed(1)
+    x = torch.randn(batch, 64, 64, 64, device=device, generator=g)
+    w = torch.randn(48, 64, 3, 3, device=device, generator=g) * 0.04
+    b = torch.randn(48, device=device, generator=g)
+    wp = ops.pack_conv3x3(w, dgrad=False)
+    for _ in range(2):
+        ops.conv3x3(x, wp, b, 48, ups=True, lrelu=True, pixnorm=True)
+    stream = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(iters):
+        ops.conv3x3(x, wp, b, 48, ups=True, lrelu=True, pixnorm=True)
+    e1.record(stream)
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flop = 2.0 * 9 * 64 * 48 * 128 * 128 * batch
+    return {"name": "conv3x3_mfma<NI=3,MI=4> ups+lrelu+pixnorm 64->48@128x128", "ms": ms, "flop": flop,
+            "tflops": flop / ms / 1e9}
+
+
+def host_cpu_share() -> int:
+    """CPUs this process may actually use: min(affinity mask, cgroup cpu.max quota) -- the GPU box reports 256 logical CPUs
+    but grants a 16-CPU quota, and oversubscribing that throttles the oracle by orders of magnitude."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(level: int, rand_channels: int, batch: int, iters: int):
+    """The CPU oracle (plain-PyTorch port of train.py:135-221 as the reference executes it, G not detached in the D step)
+    on the host cores of this box, bounded sample."""
+    from oracle import progan as O
+    torch.set_num_threads(host_cpu_share())
+    torch.manual_seed(0)
+    gs, ds = O.GenState(rand_channels), O.DiscState(7)
+    for _ in range(level):
+        gs.next_layer()
+        ds.next_layer()
+    side = LEVEL_SIDE[level]
+    rng = torch.Generator().manual_seed(1234)
+    x_real = torch.rand(batch, 2, side, side, generator=rng) * 2 - 1
+    best = None
+    for it in range(iters + 1):
+        z = torch.randn(batch, rand_channels, 2, 2, generator=rng)
+        z2 = torch.randn(batch, rand_channels, 2, 2, generator=rng)
+        eps = torch.rand(batch, 1, 1, 1, generator=rng)
+        t0 = time.perf_counter()
+        O.d_step(gs, ds, x_real, z, eps, 0.5)
+        O.g_step(gs, ds, z2, 0.5)
+        dt = time.perf_counter() - t0
+        if it > 0:
+            best = dt if best is None else min(best, dt)
+    return {"value": batch / best, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"level {level} 2x{side}x{side}, batch {batch}, min of {iters} D+G steps after 1 warm-up "
+                      f"(forward/backward only, reference-as-executed work incl. its non-detached D step)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--level", type=int, default=5, choices=[3, 4, 5])
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
+    ap.add_argument("--rand-channels", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=64)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from musicgan_amd.optim import FusedAdam
+    from musicgan_amd.train_step import ProGANStepper
+
+    gen, disc = build_nets(args.level, args.rand_channels, device)
+    optim_gen = FusedAdam(gen.parameters(), lr=1e-3, betas=(0.0, 0.9))
+    optim_disc = FusedAdam(disc.parameters(), lr=1e-3, betas=(0.0, 0.9))
+    stepper = ProGANStepper(gen, disc, optim_gen, optim_disc, args.rand_channels)
+    side = LEVEL_SIDE[args.level]
+    alpha = 0.5
+    data_rng = torch.Generator(device=device).manual_seed(1234 + rank)
+    x_real = torch.rand(args.batch, 2, side, side, device=device, generator=data_rng) * 2 - 1
+
+    def one_step():
+        z = torch.randn(args.batch, args.rand_channels, 2, 2, device=device, generator=data_rng)
+        eps = torch.rand(args.batch, 1, 1, 1, device=device, generator=data_rng)
+        z2 = torch.randn(args.batch, args.rand_channels, 2, 2, device=device, generator=data_rng)
+        stepper.d_step(x_real, alpha, z=z, eps=eps)
+        stepper.g_step(args.batch, alpha, device, z=z2)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        one_step()
+    stepper.finish()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    stepper.finish()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    images_per_s = world * args.batch * args.steps / elapsed
+
+    if rank == 0:
+        fpi = flops_per_image(args.level, args.rand_channels)
+        achieved = fpi * images_per_s / world / 1e12
+        dom = dominant_kernel_probe(device, args.batch)
+        line = {
+            "metric": f"spectrogram-images/sec G+D step, 2x{side}x{side} bs{args.batch}",
+            "value": images_per_s, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ProGAN level {args.level} WGAN-GP D+G step, 2x{side}x{side}, "
+                                   f"batch {args.batch}/GPU, rand_channels {args.rand_channels}, alpha 0.5 (fade-in live), "
+                                   f"Adam(1e-3,(0,0.9)) on both nets, random-init weights",
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "basis": f"whole step, per GPU: {fpi / 1e9:.2f} algorithmic GFLOP/image (4*Gf+12*Df) x images/s",
+                         "dominant_kernel": {**dom, "frac": dom["tflops"] / MFMA_F32_PEAK_TFLOPS}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.level, args.rand_channels, args.cpu_batch, iters=2)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

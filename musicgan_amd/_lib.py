@@ -6,6 +6,9 @@ from __future__ import annotations
 
 import ctypes
 import os
+
+import torch  # noqa: F401  -- must be imported BEFORE the library: both link libamdhip64.so.7 and the HIP runtime that
+#                             torch ships has to be the one the process binds (loading /opt/rocm's first breaks torch's device)
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
