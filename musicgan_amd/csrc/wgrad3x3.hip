@@ -171,24 +171,46 @@ __global__ void __launch_bounds__(512) wgrad3x3_mfma(const WgradArgs a) {
   }
 }
 
-__global__ void wgrad3x3_reduce(const float* __restrict__ slab, const float* __restrict__ slab_b, int nsplit,
-                                float* __restrict__ gw, float* __restrict__ gb, int Cout, int Cin, int accumulate) {
+// Sum the split-K slabs in a fixed order.  Block = 64 consecutive slab elements x 4 split-lanes (each lane sums every 4th
+// split, 4 loads in flight), LDS-combined as ((l0 + l1) + (l2 + l3)) => deterministic.
+__global__ void __launch_bounds__(256) wgrad3x3_reduce(const float* __restrict__ slab, const float* __restrict__ slab_b,
+                                                       int nsplit, float* __restrict__ gw, float* __restrict__ gb,
+                                                       int Cout, int Cin, int accumulate) {
+  __shared__ float red[4][64];
   const int total = 9 * Cout * Cin;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < total) {
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += slab[(size_t)k * total + e];
-    const int c = e % Cin;
-    const int r = e / Cin;
-    const int o = r % Cout;
-    const int t = r / Cout;
-    const size_t idx = ((size_t)o * Cin + c) * 9 + t;
-    gw[idx] = accumulate ? gw[idx] + s : s;
-  } else if (gb != nullptr && e < total + Cout) {
-    const int o = e - total;
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += slab_b[(size_t)k * Cout + o];
-    gb[o] = accumulate ? gb[o] + s : s;
+  const int all = total + (gb != nullptr ? Cout : 0);
+  const int el = threadIdx.x & 63, kl = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + el;
+  float s = 0.f;
+  if (e < all) {
+    const float* src = e < total ? slab + e : slab_b + (e - total);
+    const size_t stride = e < total ? (size_t)total : (size_t)Cout;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = kl;
+    for (; k + 12 < nsplit; k += 16) {
+      s0 += src[(size_t)k * stride];
+      s1 += src[(size_t)(k + 4) * stride];
+      s2 += src[(size_t)(k + 8) * stride];
+      s3 += src[(size_t)(k + 12) * stride];
+    }
+    for (; k < nsplit; k += 4) s0 += src[(size_t)k * stride];
+    s = (s0 + s1) + (s2 + s3);
+  }
+  red[kl][el] = s;
+  __syncthreads();
+  if (kl == 0 && e < all) {
+    s = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+    if (e < total) {
+      const int c = e % Cin;
+      const int r = e / Cin;
+      const int o = r % Cout;
+      const int t = r / Cout;
+      const size_t idx = ((size_t)o * Cin + c) * 9 + t;
+      gw[idx] = accumulate ? gw[idx] + s : s;
+    } else {
+      const int o = e - total;
+      gb[o] = accumulate ? gb[o] + s : s;
+    }
   }
 }
 
@@ -224,7 +246,7 @@ bool plan_wgrad(int N, int Cin, int Cout, int H, int W, WgradPlan& pl) {
   a.tiles_x = mg_cdiv(W, a.TW); a.tiles_y = mg_cdiv(H, a.TH); a.tiles_n = mg_cdiv(N, a.TN);
   a.ntiles = a.tiles_x * a.tiles_y * a.tiles_n;
   const int gy_blocks = a.oblocks * pl.cblocks;
-  int nsplit = 768 / gy_blocks;
+  int nsplit = 512 / gy_blocks;  // persistent workgroups: ~2 per CU in total
   if (nsplit < 1) nsplit = 1;
   if (nsplit > a.ntiles) nsplit = a.ntiles;
   pl.nsplit = nsplit;
@@ -283,7 +305,7 @@ extern "C" int mg_conv3x3_wgrad(const float* x, const float* gy, float* gw, floa
   }
   if (rc != MG_OK) return rc;
   const int total = 9 * Cout * Cin + Cout;
-  hipLaunchKernelGGL(wgrad3x3_reduce, dim3(mg_cdiv(total, 256)), dim3(256), 0, s, a.slab, a.slab_b, pl.nsplit, gw, gb,
+  hipLaunchKernelGGL(wgrad3x3_reduce, dim3(mg_cdiv(total, 64)), dim3(256), 0, s, a.slab, a.slab_b, pl.nsplit, gw, gb,
                      Cout, Cin, accumulate);
   MG_CHECK_LAUNCH("mg_conv3x3_wgrad(reduce)");
   return MG_OK;

@@ -1,0 +1,30 @@
+"""Run ONE kernel shape a few times (for rocprofv3 --pmc / --kernel-trace).  python3 tools/prof_one.py <case> [iters]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from musicgan_amd import ops
+case = sys.argv[1] if len(sys.argv) > 1 else "g54"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+N = 64
+dev = torch.device("cuda", 0)
+R = lambda *s: torch.randn(*s, device=dev)
+if case == "g54":      # fused ups conv 64->48 @128 + lrelu + pixnorm
+    x = R(N, 64, 64, 64); wp = ops.pack_conv3x3(R(48, 64, 3, 3) * 0.05, False); b = R(48)
+    fn = lambda: ops.conv3x3(x, wp, b, 48, ups=True, lrelu=True, pixnorm=True)
+elif case == "d20":    # conv 48->64 @128 + lrelu
+    x = R(N, 48, 128, 128); wp = ops.pack_conv3x3(R(64, 48, 3, 3) * 0.05, False); b = R(64)
+    fn = lambda: ops.conv3x3(x, wp, b, 64, lrelu=True)
+elif case == "w20":    # wgrad 48->64 @128
+    x = R(N, 48, 128, 128); gy = R(N, 64, 128, 128); gw = torch.empty(64, 48, 3, 3, device=dev); gb = torch.empty(64, device=dev)
+    fn = lambda: ops.conv3x3_wgrad(x, gy, gw, gb)
+elif case == "w54":
+    x = R(N, 64, 64, 64); gy = R(N, 48, 128, 128); gw = torch.empty(48, 64, 3, 3, device=dev); gb = torch.empty(48, device=dev)
+    fn = lambda: ops.conv3x3_wgrad(x, gy, gw, gb, ups=True)
+elif case == "stft":
+    wav = torch.rand(44100 * 600, device=dev) - 0.5
+    fn = lambda: ops.stft_1024(wav)
+else:
+    raise SystemExit("unknown case")
+for _ in range(iters):
+    fn()
+torch.cuda.synchronize()
