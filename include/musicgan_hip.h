@@ -133,6 +133,18 @@ int mg_adam_step(const mg_adam_tensor_t* desc, int n_tensors, float beta1, float
  * centre reflect padding, hop 256, divided by sqrt(sum w^2).  If out_im == NULL, out_re is interleaved complex64 [512][T][2]. */
 int mg_stft_1024(const float* wav, float* out_re, float* out_im, int64_t L, mg_stream_t stream);
 
+/* ------------------------------------------------------------------ magnitude/phase codec + inverse STFT
+ * mg_codec_fwd: stft_to_phase_magn [audio/functions.py:65-94].  stft_c64: interleaved complex64 [512][T] (mg_stft_1024 output);
+ * bark_scale: [512] unit-norm bark vector (functions.py:26-35); outputs [S][512][nb_vec], S = (T-1)/nb_vec, both in [-1,1].
+ * mg_codec_inv: magn_phase_to_wav [audio/functions.py:97-139] without the file write.  magn_phase: [N][2][512][W];
+ * wav_out: [256*(N*W-1)].  The unwrap / cumulative sums run sequentially per frequency row in fp32 like torch.cumsum. */
+size_t mg_codec_fwd_ws_bytes(int T);
+int mg_codec_fwd(const float* stft_c64, const float* bark_scale, float* magn_out, float* phase_out, void* ws,
+                 size_t ws_bytes, int T, int nb_vec, mg_stream_t stream);
+size_t mg_codec_inv_ws_bytes(int N, int W);
+int mg_codec_inv(const float* magn_phase, const float* bark_scale, float* wav_out, void* ws, size_t ws_bytes, int N, int W,
+                 mg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,10 @@ SIGNATURES = {
     "mg_channel_sum": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "mg_adam_step": (c_int, [_P, c_int, c_float, c_float, c_float, c_float, _P]),
     "mg_stft_1024": (c_int, [_P, _P, _P, c_int64, _P]),
+    "mg_codec_fwd_ws_bytes": (c_size_t, [c_int]),
+    "mg_codec_fwd": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, _P]),
+    "mg_codec_inv_ws_bytes": (c_size_t, [c_int, c_int]),
+    "mg_codec_inv": (c_int, [_P, _P, _P, _P, c_size_t, c_int, c_int, _P]),
 }
 
 _lib = None

@@ -1,0 +1,28 @@
+"""Minimal WAV file IO (the reference uses torchaudio.load/save, functions.py:43,139; torchaudio is not a dependency here).
+load() mirrors torchaudio.load(normalize=True): float32 tensor (channels, samples) in [-1, 1] and the sample rate."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from scipy.io import wavfile
+
+
+def load(path: str):
+    sr, data = wavfile.read(path)
+    if data.ndim == 1:
+        data = data[:, None]
+    if data.dtype == np.int16:
+        x = data.astype(np.float32) / 32768.0
+    elif data.dtype == np.int32:
+        x = data.astype(np.float32) / 2147483648.0
+    elif data.dtype == np.uint8:
+        x = (data.astype(np.float32) - 128.0) / 128.0
+    else:
+        x = data.astype(np.float32)
+    return torch.from_numpy(np.ascontiguousarray(x.T)), int(sr)
+
+
+def save(path: str, wav: torch.Tensor, sample_rate: int) -> None:
+    """(channels, samples) float tensor -> 32-bit float WAV (what torchaudio.save writes for float32 input)."""
+    x = wav.detach().to("cpu", torch.float32).numpy()
+    wavfile.write(path, int(sample_rate), np.ascontiguousarray(x.T))

@@ -264,3 +264,30 @@ def stft_1024(wav_mono: torch.Tensor) -> torch.Tensor:
     out = torch.empty((512, t, 2), dtype=torch.float32, device=wav_mono.device)
     check(_lib.load().mg_stft_1024(_p(wav_mono), _p(out), None, length, _s()), "mg_stft_1024")
     return torch.view_as_complex(out)
+
+
+def codec_fwd(stft_c: torch.Tensor, bark_scale: torch.Tensor, nb_vec: int):
+    """complex64 [512, T] -> (magn, phase) each [S, 512, nb_vec] in [-1, 1]  (audio/functions.py:65-94)."""
+    assert stft_c.is_complex() and stft_c.shape[0] == 512
+    xr = torch.view_as_real(stft_c.contiguous())
+    _chk(xr, bark_scale)
+    t = stft_c.shape[1]
+    s = (t - 1) // nb_vec
+    lib = _lib.load()
+    ws = workspace(lib.mg_codec_fwd_ws_bytes(t), xr.device)
+    magn = torch.empty((s, 512, nb_vec), dtype=torch.float32, device=xr.device)
+    phase = torch.empty_like(magn)
+    check(lib.mg_codec_fwd(_p(xr), _p(bark_scale), _p(magn), _p(phase), _p(ws), ws.numel(), t, nb_vec, _s()),
+          "mg_codec_fwd")
+    return magn, phase
+
+
+def codec_inv(magn_phase: torch.Tensor, bark_scale: torch.Tensor) -> torch.Tensor:
+    """[N, 2, 512, W] -> waveform [256*(N*W-1)]  (audio/functions.py:97-139 without the file write)."""
+    _chk(magn_phase, bark_scale)
+    n, _, _, w = magn_phase.shape
+    lib = _lib.load()
+    ws = workspace(lib.mg_codec_inv_ws_bytes(n, w), magn_phase.device)
+    wav = torch.empty((256 * (n * w - 1),), dtype=torch.float32, device=magn_phase.device)
+    check(lib.mg_codec_inv(_p(magn_phase), _p(bark_scale), _p(wav), _p(ws), ws.numel(), n, w, _s()), "mg_codec_inv")
+    return wav

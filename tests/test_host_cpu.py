@@ -1,0 +1,89 @@
+"""CPU: host-side pieces around the hot path -- growth schedule, CLI flags, WAV IO, input transforms."""
+import numpy as np
+import pytest
+import torch
+
+
+def test_grower_schedule_matches_reference_rules():
+    """utils.py:45-68 / SURVEY App. B #3: alpha = min(1, (1+step)/fadein[curr]); grow when cumsum(train)[curr] < samples
+    (strict); after the 7th grow never again."""
+    from musicgan_amd.utils import Grower
+    fade = [1, 25000, 37500, 50000, 62500, 75000, 87500, 100000]
+    train = [50000, 100000, 150000, 200000, 250000, 300000, 350000]
+    g = Grower(n_grow=7, fadein_lengths=fade, train_lengths=train)
+    assert g.alpha == 1.0
+    cum = np.cumsum(train)
+    seen, grows = 0, []
+    bs = 6
+    while len(grows) < 7:
+        grew = g.grow(bs)
+        seen += bs
+        if grew:
+            grows.append(seen)
+            assert g.alpha == pytest.approx(1.0 / fade[len(grows)])
+    for k, s in enumerate(grows):
+        assert cum[k] < s <= cum[k] + bs
+    assert not g.grow(10 ** 7)
+    g2 = Grower(7, fade, train)
+    g2.load_state_dict(g.state_dict())
+    assert g2.alpha == g.alpha and g2.curr_grow == 7
+    with pytest.raises(AssertionError):
+        Grower(7, fade[:-1], train)
+
+
+def test_grower_transform_range_and_size():
+    from musicgan_amd.utils import Grower
+    g = Grower(7, [1] * 8, [10] * 7)
+    x = torch.rand(3, 2, 512, 512, dtype=torch.float64).float() * 5 - 2
+    y = g.scale_transform(x)
+    assert tuple(y.shape) == (3, 2, 4, 4)
+    assert float(y.min()) >= -1.0 - 1e-5 and float(y.max()) <= 1.0 + 1e-5
+
+
+def test_transforms_match_reference_formulas():
+    from musicgan_amd.audio import ChangeRange, ChannelMinMaxNorm
+    x = torch.randn(4, 2, 8, 8)
+    y = ChannelMinMaxNorm()(x)
+    flat = x.view(4, 2, -1)
+    ref = (x - flat.min(-1)[0].view(4, 2, 1, 1)) / (flat.max(-1)[0].view(4, 2, 1, 1) - flat.min(-1)[0].view(4, 2, 1, 1) + 1e-8)
+    assert torch.equal(y, ref)
+    assert torch.equal(ChangeRange(-1., 1.)(y), y * 2. + -1.)
+    with pytest.raises(AssertionError):
+        ChannelMinMaxNorm()(torch.zeros(2, 3, 4, 4))
+
+
+def test_cli_flags_are_the_reference_flags():
+    from musicgan_amd.__main__ import build_parser
+    p = build_parser()
+    a = p.parse_args(["create_dataset", "/x/*.wav", "-o", "out"])
+    assert (a.mode, a.audio_path, a.output_dir) == ("create_dataset", "/x/*.wav", "out")
+    a = p.parse_args(["train", "run0", "-o", "out", "-i", "data"])
+    assert (a.mode, a.run, a.out_path, a.input_dataset) == ("train", "run0", "out", "data")
+    a = p.parse_args(["generate", "gen.pt", "32", "-o", "o"])
+    assert (a.gen_dict_state, a.rand_channels, a.nb_vec, a.nb_music, a.output_dir) == ("gen.pt", 32, 10, 5, "o")
+    a = p.parse_args(["view_audio", "--input-audio", "a.wav", "--image-idx", "3"])
+    assert (a.input_audio, a.image_idx) == ("a.wav", 3)
+    with pytest.raises(SystemExit):
+        p.parse_args(["train", "run0"])
+
+
+def test_wav_io_roundtrip(tmp_path):
+    from musicgan_amd.audio import wavio
+    x = (torch.rand(2, 4410) - 0.5)
+    path = str(tmp_path / "a.wav")
+    wavio.save(path, x, 44100)
+    y, sr = wavio.load(path)
+    assert sr == 44100 and torch.equal(x, y)
+    from scipy.io import wavfile
+    wavfile.write(str(tmp_path / "b.wav"), 22050, (x[0].numpy() * 32767).astype(np.int16))
+    y, sr = wavio.load(str(tmp_path / "b.wav"))
+    assert sr == 22050 and tuple(y.shape) == (1, 4410) and float((y[0] - x[0]).abs().max()) < 1e-4
+
+
+def test_package_reexports_drivers_lazily():
+    import musicgan_amd
+    assert callable(musicgan_amd.train) and callable(musicgan_amd.generate)
+    assert callable(musicgan_amd.create_dataset) and callable(musicgan_amd.view_audio)
+    assert callable(musicgan_amd.train)  # still the function after the sub-module import
+    from musicgan_amd.audio import N_FFT, N_VEC, SAMPLE_RATE, STFT_STRIDE
+    assert (N_FFT, N_VEC, STFT_STRIDE, SAMPLE_RATE) == (1024, 512, 256, 44100)
