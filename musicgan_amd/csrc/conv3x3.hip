@@ -12,6 +12,8 @@
 // LDS image per chunk: input halo tile [8][ch_stride] (ch_stride % 32 == 16 => the two k-lanes of a half-wave hit disjoint
 // banks) and weights [9 taps][8 ch][OPL] copied verbatim from the pre-packed global layout (OPL % 32 == 16, same reason).
 // D layout (16x16x4): lane holds out-channel (lane&15) of pixels 4*(lane>>4)+{0..3} => one 16-byte store per tile.
+#include <cstdlib>
+
 #include "mg_common.h"
 
 namespace {
@@ -37,7 +39,12 @@ struct ConvArgs {
   int nchunk;
 };
 
-template <int NI, int MI>
+// PF: software-pipelined variant -- the next chunk's global loads are issued into registers right after the barrier that
+// starts the current chunk's MFMA phase and written to LDS after it (T14 "issue early / write late"), so staging latency hides
+// under the matrix work of the same workgroup instead of relying on other workgroups being in a different phase.
+constexpr int PF_NIN = 12;  // halo positions per thread held in flight (covers plane <= 384: every tile of a >= 16-wide image)
+
+template <int NI, int MI, bool PF>
 __global__ void __launch_bounds__(256) conv3x3_mfma(const ConvArgs a) {
   constexpr int OPL = (NI & 1) ? NI * 16 : NI * 16 + 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -88,32 +95,12 @@ __global__ void __launch_bounds__(256) conv3x3_mfma(const ConvArgs a) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int ch = 0; ch < a.nchunk; ++ch) {
-    __syncthreads();
-    {  // input halo tile: 8 half-waves, one channel each, 32 consecutive positions per pass
-      const int cl = tid >> 5, l32 = tid & 31;
-      const int c = ch * CC + cl;
-      const bool cok = c < a.Cin;
-      const float* xc = xn + (size_t)c * HWin;
-      float* dst = in_t + cl * a.ch_stride;
-#pragma unroll 4
-      for (int pos = l32; pos < a.plane; pos += 32) {
-        const int off = tab[pos];
-        float v = 0.f;
-        if (cok && off >= 0) v = xc[off];
-        dst[pos] = v;
-      }
-    }
-    {  // weights: verbatim 16-byte copy of this chunk's packed rows
-      const float* src = a.wp + (size_t)ch * (9 * CC) * a.OPF + o0;
-      for (int e = tid; e < 9 * CC * NI * 4; e += 256) {
-        const int row = e / (NI * 4);
-        const int j = e - row * (NI * 4);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)row * a.OPF + 4 * j);
-        *reinterpret_cast<f32x4*>(w_t + row * OPL + 4 * j) = v;
-      }
-    }
-    __syncthreads();
+  constexpr int NW4 = (9 * CC * NI * 4 + 255) / 256;
+  const int cl_ = tid >> 5, l32_ = tid & 31;
+  float rin[PF ? PF_NIN : 1];
+  f32x4 rw[PF ? NW4 : 1];
+
+  auto compute_chunk = [&]() {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int tap = (t / 3) * a.TWp + (t % 3);
@@ -130,6 +117,88 @@ __global__ void __launch_bounds__(256) conv3x3_mfma(const ConvArgs a) {
           for (int ni = 0; ni < NI; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
       }
+    }
+  };
+
+  if constexpr (PF) {
+    auto load_chunk = [&](int ch) {
+      const int c = ch * CC + cl_;
+      const bool cok = c < a.Cin;
+      const float* xc = xn + (size_t)c * HWin;
+#pragma unroll
+      for (int j = 0; j < PF_NIN; ++j) {
+        const int pos = l32_ + 32 * j;
+        float v = 0.f;
+        if (pos < a.plane) {
+          const int off = tab[pos];
+          if (cok && off >= 0) v = xc[off];
+        }
+        rin[j] = v;
+      }
+      const float* src = a.wp + (size_t)ch * (9 * CC) * a.OPF + o0;
+#pragma unroll
+      for (int j = 0; j < NW4; ++j) {
+        const int e = tid + 256 * j;
+        if (e < 9 * CC * NI * 4) {
+          const int row = e / (NI * 4);
+          const int jj = e - row * (NI * 4);
+          rw[j] = *reinterpret_cast<const f32x4*>(src + (size_t)row * a.OPF + 4 * jj);
+        }
+      }
+    };
+    auto store_chunk = [&]() {
+      float* dst = in_t + cl_ * a.ch_stride;
+#pragma unroll
+      for (int j = 0; j < PF_NIN; ++j) {
+        const int pos = l32_ + 32 * j;
+        if (pos < a.plane) dst[pos] = rin[j];
+      }
+#pragma unroll
+      for (int j = 0; j < NW4; ++j) {
+        const int e = tid + 256 * j;
+        if (e < 9 * CC * NI * 4) {
+          const int row = e / (NI * 4);
+          const int jj = e - row * (NI * 4);
+          *reinterpret_cast<f32x4*>(w_t + row * OPL + 4 * jj) = rw[j];
+        }
+      }
+    };
+    __syncthreads();  // tab visible
+    load_chunk(0);
+    for (int ch = 0; ch < a.nchunk; ++ch) {
+      __syncthreads();  // previous chunk's LDS reads done
+      store_chunk();
+      __syncthreads();
+      if (ch + 1 < a.nchunk) load_chunk(ch + 1);  // in flight during the MFMA phase below
+      compute_chunk();
+    }
+  } else {
+    for (int ch = 0; ch < a.nchunk; ++ch) {
+      __syncthreads();
+      {  // input halo tile: 8 half-waves, one channel each, 32 consecutive positions per pass
+        const int c = ch * CC + cl_;
+        const bool cok = c < a.Cin;
+        const float* xc = xn + (size_t)c * HWin;
+        float* dst = in_t + cl_ * a.ch_stride;
+#pragma unroll 4
+        for (int pos = l32_; pos < a.plane; pos += 32) {
+          const int off = tab[pos];
+          float v = 0.f;
+          if (cok && off >= 0) v = xc[off];
+          dst[pos] = v;
+        }
+      }
+      {  // weights: verbatim 16-byte copy of this chunk's packed rows
+        const float* src = a.wp + (size_t)ch * (9 * CC) * a.OPF + o0;
+        for (int e = tid; e < 9 * CC * NI * 4; e += 256) {
+          const int row = e / (NI * 4);
+          const int j = e - row * (NI * 4);
+          const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)row * a.OPF + 4 * j);
+          *reinterpret_cast<f32x4*>(w_t + row * OPL + 4 * j) = v;
+        }
+      }
+      __syncthreads();
+      compute_chunk();
     }
   }
 
@@ -243,17 +312,33 @@ __global__ void conv3x3_pack_kernel(const float* __restrict__ w, float* __restri
   wp[e] = v;
 }
 
-template <int NI, int MI>
-int launch_conv(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+template <int NI, int MI, bool PF>
+int launch_conv_pf(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;  // benign race: idempotent
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma<NI, MI>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma<NI, MI, PF>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_mfma<NI, MI>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv3x3_mfma<NI, MI, PF>), grid, dim3(256), lds, s, a);
   MG_CHECK_LAUNCH("mg_conv3x3");
   return MG_OK;
+}
+
+bool pf_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MG_CONV_PF");
+    v = (e == nullptr) ? 1 : (atoi(e) != 0);
+  }
+  return v != 0;
+}
+
+template <int NI, int MI>
+int launch_conv(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  // the pipelined variant needs the halo tile to fit its in-flight registers and more than one chunk to overlap
+  if (pf_enabled() && a.plane <= 32 * PF_NIN && a.nchunk > 1) return launch_conv_pf<NI, MI, true>(a, grid, lds, s);
+  return launch_conv_pf<NI, MI, false>(a, grid, lds, s);
 }
 
 template <int MI>
