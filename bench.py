@@ -146,9 +146,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also with a single rank)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend="nccl", device_id=device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -194,6 +195,9 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     images_per_s = world * args.batch * args.steps / elapsed
 
+    if os.environ.get("MG_BENCH_CHECKSUM") and rank == 0:
+        cs = sum(float(p.detach().double().abs().sum()) for p in list(gen.parameters()) + list(disc.parameters()))
+        print(f"weights_abs_sum {cs:.10e}", file=sys.stderr, flush=True)
     if rank == 0:
         fpi = flops_per_image(args.level, args.rand_channels)
         achieved = fpi * images_per_s / world / 1e12
@@ -215,7 +219,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.level, args.rand_channels, args.cpu_batch, iters=2)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

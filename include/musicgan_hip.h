@@ -80,9 +80,10 @@ int mg_conv1x1_wgrad(const float* x, const float* gy, const float* tanh_y, float
 /* ------------------------------------------------------------------ element-wise / small ops */
 /* PixelNorm forward [layers.py:11-17]: p = y*rn, rn[n,hw] = 1/sqrt(mean_c y^2 + 1e-8) */
 int mg_pixelnorm_fwd(const float* y, float* p, float* rn, int N, int C, int HW, mg_stream_t stream);
-/* backward through PixelNorm then LeakyReLU: gpre = mask(y) * rn * (gp - p * mean_c(gp * p)), p = y*rn */
+/* backward through PixelNorm then LeakyReLU: gpre = mask(y) * rn * (gp - p * mean_c(gp * p)), p = y*rn.
+ * from_p != 0: the `y` argument is the normalised output p itself (the pre-norm activation need not be kept). */
 int mg_pixelnorm_lrelu_bwd(const float* gp, const float* y, const float* rn, float* gpre, int N, int C, int HW,
-                           float slope, mg_stream_t stream);
+                           float slope, int from_p, mg_stream_t stream);
 /* nn.Upsample(x2 nearest) forward / backward (sum of each 2x2 block) [generator.py:26-29,99-102] */
 int mg_upsample2x_fwd(const float* x, float* y, int NC, int Hin, int Win, mg_stream_t stream);
 int mg_upsample2x_bwd(const float* gy, float* gx, int NC, int Hin, int Win, mg_stream_t stream);

@@ -240,31 +240,42 @@ __global__ void __launch_bounds__(256) conv1x1_wgrad_part(const W1Args a) {
   }
 }
 
-// final: gw[o][c], gb[o].  gy_is_many: gy = many tensor (stem: Cout = Cm, Cin = Cf) else gy = few (head: Cout = Cf, Cin = Cm)
-__global__ void conv1x1_wgrad_final(const float* __restrict__ part, int nx, int ny, int Cm, int Cf, int gy_is_many,
-                                    float* __restrict__ gw, float* __restrict__ gb, int accumulate) {
+// final: gw[o][c], gb[o].  gy_is_many: gy = many tensor (stem: Cout = Cm, Cin = Cf) else gy = few (head: Cout = Cf, Cin = Cm).
+// One wave per output element; lanes stride over the per-block partials and combine with a fixed shuffle tree (deterministic).
+__global__ void __launch_bounds__(256) conv1x1_wgrad_final(const float* __restrict__ part, int nx, int ny, int Cm, int Cf,
+                                                           int gy_is_many, float* __restrict__ gw, float* __restrict__ gb,
+                                                           int accumulate) {
   const int per = MC * (FEW + 1) + FEW;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int nprod = Cm * Cf;
   const int Cout = gy_is_many ? Cm : Cf;
+  if (e >= nprod + (gb != nullptr ? Cout : 0)) return;
+  int by, slot, idx;
+  float* dst;
   if (e < nprod) {
     const int m = e / Cf, f = e - m * Cf;
-    const int by = m / MC, ml = m - by * MC;
-    float s = 0.f;
-    for (int bx = 0; bx < nx; ++bx) s += part[((size_t)bx * ny + by) * per + ml * (FEW + 1) + f];
-    const int idx = gy_is_many ? m * Cf + f : f * Cm + m;  // gw[o][c]
-    gw[idx] = accumulate ? gw[idx] + s : s;
-  } else if (gb != nullptr && e < nprod + Cout) {
+    by = m / MC;
+    slot = (m - by * MC) * (FEW + 1) + f;
+    idx = gy_is_many ? m * Cf + f : f * Cm + m;
+    dst = gw;
+  } else {
     const int o = e - nprod;
-    float s = 0.f;
+    idx = o;
+    dst = gb;
     if (gy_is_many) {
-      const int by = o / MC, ml = o - by * MC;
-      for (int bx = 0; bx < nx; ++bx) s += part[((size_t)bx * ny + by) * per + ml * (FEW + 1) + FEW];
+      by = o / MC;
+      slot = (o - by * MC) * (FEW + 1) + FEW;
     } else {
-      for (int bx = 0; bx < nx; ++bx) s += part[((size_t)bx * ny + 0) * per + MC * (FEW + 1) + o];
+      by = 0;
+      slot = MC * (FEW + 1) + o;
     }
-    gb[o] = accumulate ? gb[o] + s : s;
   }
+  float s = 0.f;
+  for (int bx = lane; bx < nx; bx += 64) s += part[((size_t)bx * ny + by) * per + slot];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+  if (lane == 0) dst[idx] = accumulate ? dst[idx] + s : s;
 }
 
 int c1_grid(size_t work_items) {
@@ -342,7 +353,7 @@ extern "C" int mg_conv1x1_wgrad(const float* x, const float* gy, const float* ta
   else hipLaunchKernelGGL(conv1x1_wgrad_part<1>, dim3(nx, ny), dim3(256), 0, s, a);
   MG_CHECK_LAUNCH("mg_conv1x1_wgrad");
   const int total = a.Cm * a.Cf + Cout;
-  hipLaunchKernelGGL(conv1x1_wgrad_final, dim3(mg_cdiv(total, 128)), dim3(128), 0, s, a.part, nx, ny, a.Cm, a.Cf,
+  hipLaunchKernelGGL(conv1x1_wgrad_final, dim3(mg_cdiv(total, 4)), dim3(256), 0, s, a.part, nx, ny, a.Cm, a.Cf,
                      gy_is_many ? 1 : 0, gw, gb, accumulate);
   MG_CHECK_LAUNCH("mg_conv1x1_wgrad(final)");
   return MG_OK;

@@ -69,26 +69,31 @@ __global__ void __launch_bounds__(256) pixelnorm_fwd_k(const float* __restrict__
   }
 }
 
+// Backward through PixelNorm and the LeakyReLU in front of it.  from_p == 0: `y` is the post-LeakyReLU activation, p = y*rn.
+// from_p != 0: `y` IS the normalised output p (the pre-norm activation is never stored: sign(p) == sign(y) since rn > 0).
 template <int V>
 __global__ void __launch_bounds__(256) pixelnorm_lrelu_bwd_k(const float* __restrict__ gp, const float* __restrict__ y,
                                                              const float* __restrict__ rn, float* __restrict__ gpre,
-                                                             int N, int C, int HW, float slope) {
+                                                             int N, int C, int HW, float slope, int from_p) {
   const int q = HW / V;
   const size_t total = (size_t)N * q;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int n = (int)(i / q);
     const int px = (int)(i - (size_t)n * q) * V;
     const size_t base = (size_t)n * C * HW + px;
-    float r[V], dot[V];
+    float r[V], dot[V], pr[V];
     ld<V>(rn + (size_t)n * HW + px, r);
 #pragma unroll
-    for (int v = 0; v < V; ++v) dot[v] = 0.f;
+    for (int v = 0; v < V; ++v) {
+      dot[v] = 0.f;
+      pr[v] = from_p ? 1.f : r[v];
+    }
     for (int c = 0; c < C; ++c) {
       float g[V], t[V];
       ld<V>(gp + base + (size_t)c * HW, g);
       ld<V>(y + base + (size_t)c * HW, t);
 #pragma unroll
-      for (int v = 0; v < V; ++v) dot[v] = fmaf(g[v], t[v] * r[v], dot[v]);
+      for (int v = 0; v < V; ++v) dot[v] = fmaf(g[v], t[v] * pr[v], dot[v]);
     }
 #pragma unroll
     for (int v = 0; v < V; ++v) dot[v] /= (float)C;
@@ -97,7 +102,7 @@ __global__ void __launch_bounds__(256) pixelnorm_lrelu_bwd_k(const float* __rest
       ld<V>(gp + base + (size_t)c * HW, g);
       ld<V>(y + base + (size_t)c * HW, t);
 #pragma unroll
-      for (int v = 0; v < V; ++v) o[v] = mg_lrelu_mask(t[v], slope) * r[v] * (g[v] - t[v] * r[v] * dot[v]);
+      for (int v = 0; v < V; ++v) o[v] = mg_lrelu_mask(t[v], slope) * r[v] * (g[v] - t[v] * pr[v] * dot[v]);
       st<V>(gpre + base + (size_t)c * HW, o);
     }
   }
@@ -366,11 +371,11 @@ extern "C" int mg_pixelnorm_fwd(const float* y, float* p, float* rn, int N, int 
 }
 
 extern "C" int mg_pixelnorm_lrelu_bwd(const float* gp, const float* y, const float* rn, float* gpre, int N, int C, int HW,
-                                      float slope, mg_stream_t stream) {
+                                      float slope, int from_p, mg_stream_t stream) {
   MG_CHECK_ARG(gp && y && rn && gpre && N > 0 && C > 0 && HW > 0, "mg_pixelnorm_lrelu_bwd: bad arguments");
   if ((HW & 3) == 0)
-    EW_LAUNCH(pixelnorm_lrelu_bwd_k<4>, ew_grid((size_t)N * HW / 4), 256, gp, y, rn, gpre, N, C, HW, slope);
-  else EW_LAUNCH(pixelnorm_lrelu_bwd_k<1>, ew_grid((size_t)N * HW), 256, gp, y, rn, gpre, N, C, HW, slope);
+    EW_LAUNCH(pixelnorm_lrelu_bwd_k<4>, ew_grid((size_t)N * HW / 4), 256, gp, y, rn, gpre, N, C, HW, slope, from_p);
+  else EW_LAUNCH(pixelnorm_lrelu_bwd_k<1>, ew_grid((size_t)N * HW), 256, gp, y, rn, gpre, N, C, HW, slope, from_p);
   MG_CHECK_LAUNCH("mg_pixelnorm_lrelu_bwd");
   return MG_OK;
 }

@@ -11,6 +11,8 @@
 //   the splits in a fixed order (deterministic, no float atomics) while transposing to the module layout [o][c][tap].
 // LDS image per pixel tile: GY [WO*16][P+2] and X halo [nwaves*16][plane(+pad)], both with channel stride % 4 == 2 so
 // that the 16 channel-lanes x 2 k-lanes of a half-wave fall on 32 distinct banks.
+#include <cstdlib>
+
 #include "mg_common.h"
 
 namespace {
@@ -25,26 +27,39 @@ struct WgradArgs {
   int tiles_x, tiles_y, tiles_n, ntiles;
   int plane, x_stride, gy_stride, tab_floats;
   int oblocks;  // grid.y = oblocks * cblocks
-  int nwaves;   // in-channel tiles per workgroup
+  int ogroups;  // waves along the out-channel tiles of the block (each owns WO tiles)
+  int nct;      // in-channel tiles per workgroup; waves = ogroups * nct
 };
 
-template <int WO>
+// NIX > 0: software-pipelined variant.  Every global load of the NEXT pixel tile is issued into registers right after the
+// barrier that starts the current tile's MFMA phase (NIX = 8 / ogroups channel passes per half-wave x 7 halo positions +
+// up to 8 float4 of gy) and written to LDS after it, so the ~70 KB of staging per tile hides under ~18k cycles of matrix work.
+// NIX == 0: simple load->store->compute variant (tiny images, odd shapes).
+constexpr int PF_NJ = 7;   // halo positions per lane (plane <= 224)
+constexpr int PF_NG4 = 6;  // gy float4 per thread
+
+template <int WO, int NIX>
 __global__ void __launch_bounds__(512) wgrad3x3_mfma(const WgradArgs a) {
+  constexpr bool PF = NIX > 0;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int* tab = reinterpret_cast<int*>(smem);
   float* gy_t = smem + a.tab_floats;
-  float* x_t = gy_t + WO * 16 * a.gy_stride;
+  const int TB = WO * a.ogroups;  // out-channel tiles staged per workgroup
+  float* x_t = gy_t + TB * 16 * a.gy_stride;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int og = wave % a.ogroups, ct = wave / a.ogroups;
   const int nthr = blockDim.x;
   const int col = lane & 15, rq = lane >> 4;
   const int ob = blockIdx.y % a.oblocks, cb = blockIdx.y / a.oblocks;
-  const int o0 = ob * WO * 16;
-  const int c0 = cb * a.nwaves * 16;
+  const int o0 = ob * TB * 16;
+  const int c0 = cb * a.nct * 16;
   const int HWin = a.Hin * a.Win;
   const int HW = a.H * a.W;
   const int THpTWp = a.THp * a.TWp;
   const bool vec = (a.TW >= 4) && ((a.W & 3) == 0);
+  const int q4 = a.P >> 2;  // float4 groups per gy channel row
+  const int nhalf = nthr >> 5, hw_ = tid >> 5, l32 = tid & 31;
 
   f32x4 acc[WO][9];
   float gb[WO];
@@ -55,12 +70,11 @@ __global__ void __launch_bounds__(512) wgrad3x3_mfma(const WgradArgs a) {
     for (int t = 0; t < 9; ++t) acc[wo][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+  auto build_tab = [&](int tile) {
     const int tx = tile % a.tiles_x;
     const int t2 = tile / a.tiles_x;
     const int ty = t2 % a.tiles_y;
     const int tn = t2 / a.tiles_y;
-    __syncthreads();  // previous tile's MFMA reads done
     for (int pos = tid; pos < a.plane; pos += nthr) {
       const int n_l = pos / THpTWp;
       const int rem = pos - n_l * THpTWp;
@@ -71,59 +85,13 @@ __global__ void __launch_bounds__(512) wgrad3x3_mfma(const WgradArgs a) {
       const int sp = a.ups ? (Y >> 1) * a.Win + (X >> 1) : Y * a.Win + X;
       tab[pos] = ok ? n_l * a.Cin * HWin + sp : -1;
     }
-    // GY tile [WO*16][P]
-    if (vec) {
-      const int q4 = a.P >> 2;  // float4 groups per channel
-      for (int e = tid; e < WO * 16 * q4; e += nthr) {
-        const int ol = e / q4;
-        const int p = (e - ol * q4) << 2;
-        const int c = p & (a.TW - 1);
-        const int r = (p >> a.lgTW) & (a.TH - 1);
-        const int n_l = p >> (a.lgTW + a.lgTH);
-        const int n = tn * a.TN + n_l, Y = ty * a.TH + r, X = tx * a.TW + c, o = o0 + ol;
-        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (o < a.Cout && n < a.N && Y < a.H && X < a.W)
-          v = *reinterpret_cast<const f32x4*>(a.gy + ((size_t)n * a.Cout + o) * HW + (size_t)Y * a.W + X);
-        float* d = gy_t + ol * a.gy_stride + p;  // 8-byte aligned (gy_stride even, p % 4 == 0)
-        *reinterpret_cast<float2*>(d) = make_float2(v[0], v[1]);
-        *reinterpret_cast<float2*>(d + 2) = make_float2(v[2], v[3]);
-      }
-    } else {
-      for (int e = tid; e < WO * 16 * a.P; e += nthr) {
-        const int ol = e / a.P;
-        const int p = e - ol * a.P;
-        const int c = p & (a.TW - 1);
-        const int r = (p >> a.lgTW) & (a.TH - 1);
-        const int n_l = p >> (a.lgTW + a.lgTH);
-        const int n = tn * a.TN + n_l, Y = ty * a.TH + r, X = tx * a.TW + c, o = o0 + ol;
-        float v = 0.f;
-        if (o < a.Cout && n < a.N && Y < a.H && X < a.W) v = a.gy[((size_t)n * a.Cout + o) * HW + (size_t)Y * a.W + X];
-        gy_t[ol * a.gy_stride + p] = v;
-      }
-    }
-    __syncthreads();  // tab ready
-    {                 // X halo tile [nwaves*16][plane]: half-wave per channel, 32 consecutive positions per pass
-      const float* xn = a.x + (size_t)tn * a.TN * a.Cin * HWin;
-      const int nhalf = nthr >> 5;
-      const int l32 = tid & 31;
-      for (int cl = tid >> 5; cl < a.nwaves * 16; cl += nhalf) {
-        const int c = c0 + cl;
-        const bool cok = c < a.Cin;
-        const float* xc = xn + (size_t)c * HWin;
-        float* dst = x_t + cl * a.x_stride;
-#pragma unroll 4
-        for (int pos = l32; pos < a.plane; pos += 32) {
-          const int off = tab[pos];
-          float v = 0.f;
-          if (cok && off >= 0) v = xc[off];
-          dst[pos] = v;
-        }
-      }
-    }
-    __syncthreads();
-    const float* xw = x_t + (wave * 16 + col) * a.x_stride;
-    const float* gw_ = gy_t + col * a.gy_stride;
+  };
+
+  auto compute_tile = [&]() {
+    const float* xw = x_t + (ct * 16 + col) * a.x_stride;
+    const float* gw_ = gy_t + (og * WO * 16 + col) * a.gy_stride;
     const int nk = a.P >> 2;
+#pragma unroll 2
     for (int kk = 0; kk < nk; ++kk) {
       const int p = kk * 4 + rq;
       const int c = p & (a.TW - 1);
@@ -143,10 +111,157 @@ __global__ void __launch_bounds__(512) wgrad3x3_mfma(const WgradArgs a) {
           acc[wo][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[wo], bv[t], acc[wo][t], 0, 0, 0);
       }
     }
+  };
+
+  if constexpr (PF) {
+    float rx[NIX][PF_NJ];
+    f32x4 rg[PF_NG4];
+    // `z` is an opaque zero refreshed every iteration: staging indices derived from it cannot be hoisted out of the tile
+    // loop (hipcc otherwise keeps ~40 loop-invariant LDS/global offsets live across the MFMA phase and halves occupancy).
+    int z = 0;
+    auto load_tile = [&](int tile) {
+      const int tid = threadIdx.x + z, hw_ = (threadIdx.x >> 5) + z, l32 = (threadIdx.x & 31) + z;
+      const int tx = tile % a.tiles_x;
+      const int t2 = tile / a.tiles_x;
+      const int ty = t2 % a.tiles_y;
+      const int tn = t2 / a.tiles_y;
+#pragma unroll
+      for (int j = 0; j < PF_NG4; ++j) {
+        const int e = tid + j * nthr;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (e < TB * 16 * q4) {
+          const int ol = e / q4;
+          const int p = (e - ol * q4) << 2;
+          const int c = p & (a.TW - 1);
+          const int r = (p >> a.lgTW) & (a.TH - 1);
+          const int n_l = p >> (a.lgTW + a.lgTH);
+          const int n = tn * a.TN + n_l, Y = ty * a.TH + r, X = tx * a.TW + c, o = o0 + ol;
+          if (o < a.Cout && n < a.N && Y < a.H && X < a.W)
+            v = *reinterpret_cast<const f32x4*>(a.gy + ((size_t)n * a.Cout + o) * HW + (size_t)Y * a.W + X);
+        }
+        rg[j] = v;
+      }
+      const float* xn = a.x + (size_t)tn * a.TN * a.Cin * HWin;
+      int offs[PF_NJ];
+#pragma unroll
+      for (int j = 0; j < PF_NJ; ++j) {
+        const int pos = l32 + 32 * j;
+        offs[j] = pos < a.plane ? tab[pos] : -1;
+      }
+#pragma unroll
+      for (int i = 0; i < NIX; ++i) {
+        const int cl = hw_ + i * nhalf;
+        const int c = c0 + cl;
+        const bool cok = (cl < a.nct * 16) && (c < a.Cin);
+        const float* xc = xn + (size_t)c * HWin;
+#pragma unroll
+        for (int j = 0; j < PF_NJ; ++j) {
+          float v = 0.f;
+          if (cok && offs[j] >= 0) v = xc[offs[j]];
+          rx[i][j] = v;
+        }
+      }
+    };
+    auto store_tile = [&]() {
+      const int tid = threadIdx.x + z, hw_ = (threadIdx.x >> 5) + z, l32 = (threadIdx.x & 31) + z;
+#pragma unroll
+      for (int j = 0; j < PF_NG4; ++j) {
+        const int e = tid + j * nthr;
+        if (e < TB * 16 * q4) {
+          const int ol = e / q4;
+          const int p = (e - ol * q4) << 2;
+          float* d = gy_t + ol * a.gy_stride + p;  // 8-byte aligned (gy_stride even, p % 4 == 0)
+          *reinterpret_cast<float2*>(d) = make_float2(rg[j][0], rg[j][1]);
+          *reinterpret_cast<float2*>(d + 2) = make_float2(rg[j][2], rg[j][3]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NIX; ++i) {
+        const int cl = hw_ + i * nhalf;
+        if (cl < a.nct * 16) {
+          float* dst = x_t + cl * a.x_stride;
+#pragma unroll
+          for (int j = 0; j < PF_NJ; ++j) {
+            const int pos = l32 + 32 * j;
+            if (pos < a.plane) dst[pos] = rx[i][j];
+          }
+        }
+      }
+    };
+    int tile = blockIdx.x;
+    build_tab(tile);
+    __syncthreads();
+    load_tile(tile);
+    for (; tile < a.ntiles; tile += gridDim.x) {
+      const int next = tile + gridDim.x;
+      asm volatile("" : "+v"(z));
+      __syncthreads();  // previous tile's MFMA reads done; every thread has issued the loads that used tab
+      store_tile();
+      if (next < a.ntiles) build_tab(next);
+      __syncthreads();
+      if (next < a.ntiles) load_tile(next);  // in flight during the MFMA phase below
+      compute_tile();
+    }
+  } else {
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+      const int tx = tile % a.tiles_x;
+      const int t2 = tile / a.tiles_x;
+      const int ty = t2 % a.tiles_y;
+      const int tn = t2 / a.tiles_y;
+      __syncthreads();  // previous tile's MFMA reads done
+      build_tab(tile);
+      if (vec) {
+        for (int e = tid; e < TB * 16 * q4; e += nthr) {
+          const int ol = e / q4;
+          const int p = (e - ol * q4) << 2;
+          const int c = p & (a.TW - 1);
+          const int r = (p >> a.lgTW) & (a.TH - 1);
+          const int n_l = p >> (a.lgTW + a.lgTH);
+          const int n = tn * a.TN + n_l, Y = ty * a.TH + r, X = tx * a.TW + c, o = o0 + ol;
+          f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (o < a.Cout && n < a.N && Y < a.H && X < a.W)
+            v = *reinterpret_cast<const f32x4*>(a.gy + ((size_t)n * a.Cout + o) * HW + (size_t)Y * a.W + X);
+          float* d = gy_t + ol * a.gy_stride + p;  // 8-byte aligned (gy_stride even, p % 4 == 0)
+          *reinterpret_cast<float2*>(d) = make_float2(v[0], v[1]);
+          *reinterpret_cast<float2*>(d + 2) = make_float2(v[2], v[3]);
+        }
+      } else {
+        for (int e = tid; e < TB * 16 * a.P; e += nthr) {
+          const int ol = e / a.P;
+          const int p = e - ol * a.P;
+          const int c = p & (a.TW - 1);
+          const int r = (p >> a.lgTW) & (a.TH - 1);
+          const int n_l = p >> (a.lgTW + a.lgTH);
+          const int n = tn * a.TN + n_l, Y = ty * a.TH + r, X = tx * a.TW + c, o = o0 + ol;
+          float v = 0.f;
+          if (o < a.Cout && n < a.N && Y < a.H && X < a.W) v = a.gy[((size_t)n * a.Cout + o) * HW + (size_t)Y * a.W + X];
+          gy_t[ol * a.gy_stride + p] = v;
+        }
+      }
+      __syncthreads();  // tab ready
+      {                 // X halo tile [nct*16][plane]: half-wave per channel, 32 consecutive positions per pass
+        const float* xn = a.x + (size_t)tn * a.TN * a.Cin * HWin;
+        for (int cl = hw_; cl < a.nct * 16; cl += nhalf) {
+          const int c = c0 + cl;
+          const bool cok = c < a.Cin;
+          const float* xc = xn + (size_t)c * HWin;
+          float* dst = x_t + cl * a.x_stride;
+#pragma unroll 4
+          for (int pos = l32; pos < a.plane; pos += 32) {
+            const int off = tab[pos];
+            float v = 0.f;
+            if (cok && off >= 0) v = xc[off];
+            dst[pos] = v;
+          }
+        }
+      }
+      __syncthreads();
+      compute_tile();
+    }
   }
 
   // partial slab: D rows = out-channels 4*rq+g, cols = in-channel col
-  const int c = c0 + wave * 16 + col;
+  const int c = c0 + ct * 16 + col;
   float* slab = a.slab + (size_t)blockIdx.x * 9 * a.Cout * a.Cin;
 #pragma unroll
   for (int wo = 0; wo < WO; ++wo) {
@@ -154,18 +269,18 @@ __global__ void __launch_bounds__(512) wgrad3x3_mfma(const WgradArgs a) {
     for (int t = 0; t < 9; ++t) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int o = o0 + wo * 16 + rq * 4 + g;
+        const int o = o0 + (og * WO + wo) * 16 + rq * 4 + g;
         if (o < a.Cout && c < a.Cin) slab[((size_t)t * a.Cout + o) * a.Cin + c] = acc[wo][t][g];
       }
     }
   }
-  if (cb == 0 && wave == 0 && a.slab_b != nullptr) {
+  if (cb == 0 && ct == 0 && a.slab_b != nullptr) {
 #pragma unroll
     for (int wo = 0; wo < WO; ++wo) {
       float v = gb[wo];
       v += __shfl_xor(v, 16);
       v += __shfl_xor(v, 32);
-      const int o = o0 + wo * 16 + col;
+      const int o = o0 + (og * WO + wo) * 16 + col;
       if (rq == 0 && o < a.Cout) a.slab_b[(size_t)blockIdx.x * a.Cout + o] = v;
     }
   }
@@ -225,9 +340,22 @@ bool plan_wgrad(int N, int Cin, int Cout, int H, int W, WgradPlan& pl) {
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
   const int otiles = mg_cdiv(Cout, 16), ctiles = mg_cdiv(Cin, 16);
   a.oblocks = mg_cdiv(otiles, 4);
-  pl.WO = mg_cdiv(otiles, a.oblocks);
-  pl.cblocks = mg_cdiv(ctiles, 8);
-  a.nwaves = mg_cdiv(ctiles, pl.cblocks);
+  const int TB = mg_cdiv(otiles, a.oblocks);  // out-channel tiles per workgroup (<= 4)
+  // waves = ogroups x nct <= 8: fewest in-channel blocks first (each re-reads the gy tile), then the most waves
+  int best_d = 1, best_cb = 1 << 30, best_w = 0;
+  for (int d = 1; d <= TB; ++d) {
+    if (TB % d) continue;
+    const int nct_max = 8 / d;
+    if (nct_max < 1) continue;
+    const int cbk = mg_cdiv(ctiles, nct_max);
+    const int nct = mg_cdiv(ctiles, cbk);
+    const int w = d * nct;
+    if (cbk < best_cb || (cbk == best_cb && w > best_w)) { best_d = d; best_cb = cbk; best_w = w; }
+  }
+  a.ogroups = best_d;
+  pl.WO = TB / best_d;
+  pl.cblocks = best_cb;
+  a.nct = mg_cdiv(ctiles, pl.cblocks);
   // pixel tile: 128 pixels, shrunk for tiny images (halo overhead 4x..9x) until the LDS image fits comfortably
   for (a.P = 128;; a.P >>= 1) {
     a.TW = mg_pow2_ceil(W) < 32 ? mg_pow2_ceil(W) : 32;
@@ -240,7 +368,7 @@ bool plan_wgrad(int N, int Cin, int Cout, int H, int W, WgradPlan& pl) {
     a.x_stride = a.plane + ((6 - (a.plane & 3)) & 3);  // smallest s >= plane with s % 4 == 2
     a.gy_stride = a.P + 2;
     a.tab_floats = (a.plane + 3) & ~3;
-    pl.lds = (size_t)(a.tab_floats + pl.WO * 16 * a.gy_stride + a.nwaves * 16 * a.x_stride) * sizeof(float);
+    pl.lds = (size_t)(a.tab_floats + TB * 16 * a.gy_stride + a.nct * 16 * a.x_stride) * sizeof(float);
     if (pl.lds <= 96 * 1024 || a.P <= 16) break;
   }
   a.tiles_x = mg_cdiv(W, a.TW); a.tiles_y = mg_cdiv(H, a.TH); a.tiles_n = mg_cdiv(N, a.TN);
@@ -254,18 +382,54 @@ bool plan_wgrad(int N, int Cin, int Cout, int H, int W, WgradPlan& pl) {
   return pl.lds <= 160 * 1024;
 }
 
-template <int WO>
+template <int WO, int NIX>
 int launch_wgrad(const WgradPlan& pl, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_mfma<WO>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_mfma<WO, NIX>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   dim3 grid(pl.nsplit, pl.a.oblocks * pl.cblocks);
-  hipLaunchKernelGGL((wgrad3x3_mfma<WO>), grid, dim3(64 * pl.a.nwaves), pl.lds, s, pl.a);
+  hipLaunchKernelGGL((wgrad3x3_mfma<WO, NIX>), grid, dim3(64 * pl.a.ogroups * pl.a.nct), pl.lds, s, pl.a);
   MG_CHECK_LAUNCH("mg_conv3x3_wgrad");
   return MG_OK;
+}
+
+bool wgrad_pf_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MG_WGRAD_PF");
+    v = (e == nullptr) ? 1 : (atoi(e) != 0);
+  }
+  return v != 0;
+}
+
+int dispatch_wgrad(const WgradPlan& pl, hipStream_t s) {
+  const WgradArgs& a = pl.a;
+  const int nthr = 64 * a.ogroups * a.nct;
+  const bool vec = (a.TW >= 4) && ((a.W & 3) == 0);
+  const bool pf = wgrad_pf_enabled() && vec && a.plane <= 32 * PF_NJ &&
+                  pl.WO * a.ogroups * 16 * (a.P / 4) <= PF_NG4 * nthr && a.ntiles > pl.nsplit;
+  const int key = pl.WO * 10 + (pf ? a.ogroups : 0);
+  switch (key) {
+    case 10: return launch_wgrad<1, 0>(pl, s);
+    case 20: return launch_wgrad<2, 0>(pl, s);
+    case 30: return launch_wgrad<3, 0>(pl, s);
+    case 40: return launch_wgrad<4, 0>(pl, s);
+    case 11: return launch_wgrad<1, 8>(pl, s);
+    case 12: return launch_wgrad<1, 4>(pl, s);
+    case 22: return launch_wgrad<2, 4>(pl, s);
+    case 14: return launch_wgrad<1, 2>(pl, s);
+    default: break;
+  }
+  // ogroups == 3 (three out-channel tiles split one per wave): no pipelined instantiation, use the simple variant
+  switch (pl.WO) {
+    case 1: return launch_wgrad<1, 0>(pl, s);
+    case 2: return launch_wgrad<2, 0>(pl, s);
+    case 3: return launch_wgrad<3, 0>(pl, s);
+    default: return launch_wgrad<4, 0>(pl, s);
+  }
 }
 
 }  // namespace
@@ -283,6 +447,7 @@ extern "C" int mg_conv3x3_wgrad(const float* x, const float* gy, float* gw, floa
   MG_CHECK_ARG(!ups || ((H % 2 == 0) && (W % 2 == 0)), "mg_conv3x3_wgrad: upsampled input needs even H,W");
   const long long in_elems = (long long)N * Cin * (ups ? (H / 2) * (W / 2) : H * W);
   MG_CHECK_ARG(in_elems < (1ll << 31), "mg_conv3x3_wgrad: tensor too large");
+  hipStream_t s = (hipStream_t)stream;
   WgradPlan pl;
   MG_CHECK_ARG(plan_wgrad(N, Cin, Cout, H, W, pl), "mg_conv3x3_wgrad: LDS tile too large");
   if (ws_bytes < pl.ws_floats * sizeof(float)) {
@@ -295,14 +460,7 @@ extern "C" int mg_conv3x3_wgrad(const float* x, const float* gy, float* gw, floa
   a.slab_b = a.slab + (size_t)pl.nsplit * 9 * Cout * Cin;
   a.ups = ups ? 1 : 0;
   a.Hin = ups ? H / 2 : H; a.Win = ups ? W / 2 : W;
-  hipStream_t s = (hipStream_t)stream;
-  int rc;
-  switch (pl.WO) {
-    case 1: rc = launch_wgrad<1>(pl, s); break;
-    case 2: rc = launch_wgrad<2>(pl, s); break;
-    case 3: rc = launch_wgrad<3>(pl, s); break;
-    default: rc = launch_wgrad<4>(pl, s); break;
-  }
+  const int rc = dispatch_wgrad(pl, s);
   if (rc != MG_OK) return rc;
   const int total = 9 * Cout * Cin + Cout;
   hipLaunchKernelGGL(wgrad3x3_reduce, dim3(mg_cdiv(total, 64)), dim3(256), 0, s, a.slab, a.slab_b, pl.nsplit, gw, gb,

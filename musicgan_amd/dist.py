@@ -11,6 +11,7 @@ Works unchanged on CPU tensors with the gloo backend (used by the world_size-2 t
 """
 from __future__ import annotations
 
+import os
 from typing import Iterable, List, Optional
 
 import torch
@@ -18,7 +19,11 @@ import torch.distributed as dist
 
 
 def is_distributed() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """True when gradients must be exchanged.  MG_FORCE_DP=1 takes the data-parallel code path (side stream, flat bucket,
+    all-reduce, Adam behind it) even with a single rank -- used to rehearse that path on a one-GPU box."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("MG_FORCE_DP", "0") == "1"
 
 
 class GradBucket:
@@ -58,7 +63,7 @@ class GradBucket:
             with torch.cuda.stream(side):
                 side.wait_event(ready)
                 flat = torch.cat([p.grad.reshape(-1) for p in plist])
-                if self.world > 1:
+                if is_distributed():
                     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
                 self._done = torch.cuda.Event()
                 self._done.record(side)

@@ -89,10 +89,11 @@ def gen_forward(W: GenWeights, z: torch.Tensor, alpha: float, cache: PackCache, 
     saved = []
     for (w1, b1, w2, b2) in W.blocks:
         ci, co = w1.shape[0], w2.shape[0]
-        y1, p1, rn1 = ops.conv3x3(x, cache.get(w1, False), b1, ci, lrelu=True, pixnorm=True)
-        y2, p2, rn2 = ops.conv3x3(p1, cache.get(w2, False), b2, co, ups=True, lrelu=True, pixnorm=True)
+        # only the normalised outputs p and the per-pixel 1/norm are kept: the backward derives mask and x_hat from p
+        _, p1, rn1 = ops.conv3x3(x, cache.get(w1, False), b1, ci, lrelu=True, pixnorm=True, want_y=False)
+        _, p2, rn2 = ops.conv3x3(p1, cache.get(w2, False), b2, co, ups=True, lrelu=True, pixnorm=True, want_y=False)
         if save:
-            saved.append((x, y1, rn1, p1, y2, rn2))
+            saved.append((x, rn1, p1, rn2, p2))
         x_in_last, x = x, p2
     mp = ops.conv1x1(x, W.head[0], W.head[1], 2, tanh=True)
     old = None
@@ -122,15 +123,15 @@ def gen_backward(W: GenWeights, ctx, g_out: torch.Tensor, cache: PackCache, sink
     gz = None
     for i in range(last, -1, -1):
         w1, b1, w2, b2 = W.blocks[i]
-        xin, y1, rn1, p1, y2, rn2 = saved[i]
+        xin, rn1, p1, rn2, p2 = saved[i]
         ci = w1.shape[0]
-        gpre2 = ops.pixelnorm_lrelu_bwd(g, y2, rn2)
+        gpre2 = ops.pixelnorm_lrelu_bwd(g, p2, rn2, from_p=True)
         gw2, acc = sink.slot(w2)
         gb2, _ = sink.slot(b2)
         ops.conv3x3_wgrad(p1, gpre2, gw2, gb2, ups=True, accumulate=acc)
         gup = ops.conv3x3(gpre2, cache.get(w2, True), None, ci)
         gp1 = ops.upsample2x_bwd(gup)
-        gpre1 = ops.pixelnorm_lrelu_bwd(gp1, y1, rn1)
+        gpre1 = ops.pixelnorm_lrelu_bwd(gp1, p1, rn1, from_p=True)
         gw1, acc = sink.slot(w1)
         gb1, _ = sink.slot(b1)
         ops.conv3x3_wgrad(xin, gpre1, gw1, gb1, accumulate=acc)

@@ -125,13 +125,14 @@ def pixelnorm_fwd(y):
     return p, rn
 
 
-def pixelnorm_lrelu_bwd(gp, y, rn, slope: float = SLOPE):
-    """Backward through PixelNorm and the LeakyReLU in front of it (y = post-LeakyReLU activation)."""
+def pixelnorm_lrelu_bwd(gp, y, rn, slope: float = SLOPE, from_p: bool = False):
+    """Backward through PixelNorm and the LeakyReLU in front of it.  y = post-LeakyReLU activation, or (from_p) the
+    normalised output p = y*rn itself."""
     _chk(gp, y, rn)
     n, c, h, w = y.shape
     out = torch.empty_like(y)
-    check(_lib.load().mg_pixelnorm_lrelu_bwd(_p(gp), _p(y), _p(rn), _p(out), n, c, h * w, float(slope), _s()),
-          "mg_pixelnorm_lrelu_bwd")
+    check(_lib.load().mg_pixelnorm_lrelu_bwd(_p(gp), _p(y), _p(rn), _p(out), n, c, h * w, float(slope), int(from_p),
+                                             _s()), "mg_pixelnorm_lrelu_bwd")
     return out
 
 

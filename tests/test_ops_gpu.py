@@ -200,6 +200,7 @@ def test_elementwise_ops():
         report("pn fwd", p, pn, 3e-6)
         gpre = ops.pixelnorm_lrelu_bwd(gp.to(DEV), a, rn)
         report("pn+lrelu bwd", gpre, yd.grad, 1e-5)
+        report("pn+lrelu bwd from p", ops.pixelnorm_lrelu_bwd(gp.to(DEV), p, rn, from_p=True), yd.grad, 1e-5)
         report("up fwd", ops.upsample2x_fwd(y.to(DEV)), F.interpolate(y, scale_factor=2.0, mode="nearest"), 0)
         g2 = torch.randn(n, c, 2 * h, 2 * w, generator=g)
         report("up bwd", ops.upsample2x_bwd(g2.to(DEV)), F.avg_pool2d(g2.double(), 2, 2) * 4, 1e-6)
