@@ -55,11 +55,13 @@ int mg_conv3x3(const float* x, const float* wp, const float* bias, const float* 
 
 /* weight/bias gradient of the same conv (aten::convolution_backward, weight+bias grads):
  *   gw[Cout][Cin][3][3] (+)= sum_{n,y,x} gy[n,o,y,x] * xin[n,c,y+ky-1,x+kx-1],  gb[Cout] (+)= sum gy   (gb may be NULL)
- * flags: MG_CONV_UPS_IN as above; accumulate!=0 adds to gw/gb instead of overwriting.  ws: scratch of
- * mg_conv3x3_wgrad_ws_bytes() bytes (split-K partial slabs, reduced in a fixed order => deterministic). */
+ * flags: MG_CONV_UPS_IN as above; accumulate!=0 adds to gw/gb instead of overwriting.  bias_n: only samples n < bias_n feed
+ * gb (<= 0: all N) -- lets one launch over a concatenated batch sum weight gradients of all samples but bias gradients of a
+ * leading sub-batch (the gradient-penalty part has no bias gradient).  ws: scratch of mg_conv3x3_wgrad_ws_bytes() bytes
+ * (split-K partial slabs, reduced in a fixed order => deterministic). */
 size_t mg_conv3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W);
 int mg_conv3x3_wgrad(const float* x, const float* gy, float* gw, float* gb, void* ws, size_t ws_bytes, int N, int Cin,
-                     int Cout, int H, int W, int flags, int accumulate, mg_stream_t stream);
+                     int Cout, int H, int W, int flags, int accumulate, int bias_n, mg_stream_t stream);
 
 /* ------------------------------------------------------------------ 1x1 convolutions (stem 2->C, head C->2)
  * Replaces MagPhaseLayer [discriminator.py:37-50] and ToMagnPhaseLayer [generator.py:43-52].  One of Cin/Cout must be <= 4.

@@ -29,6 +29,7 @@ struct WgradArgs {
   int oblocks;  // grid.y = oblocks * cblocks
   int ogroups;  // waves along the out-channel tiles of the block (each owns WO tiles)
   int nct;      // in-channel tiles per workgroup; waves = ogroups * nct
+  int bias_n;   // only samples n < bias_n contribute to the bias gradient
 };
 
 // NIX > 0: software-pipelined variant.  Every global load of the NEXT pixel tile is issued into registers right after the
@@ -87,6 +88,7 @@ __global__ void __launch_bounds__(512) wgrad3x3_mfma(const WgradArgs a) {
     }
   };
 
+  int cur_tn = 0;  // sample-tile index of the tile being consumed (bias masking)
   auto compute_tile = [&]() {
     const float* xw = x_t + (ct * 16 + col) * a.x_stride;
     const float* gw_ = gy_t + (og * WO * 16 + col) * a.gy_stride;
@@ -103,9 +105,10 @@ __global__ void __launch_bounds__(512) wgrad3x3_mfma(const WgradArgs a) {
       for (int wo = 0; wo < WO; ++wo) av[wo] = gw_[wo * 16 * a.gy_stride + p];
 #pragma unroll
       for (int t = 0; t < 9; ++t) bv[t] = xw[xpos + (t / 3) * a.TWp + (t % 3)];
+      const bool bias_on = (cur_tn * a.TN + n_l) < a.bias_n;
 #pragma unroll
       for (int wo = 0; wo < WO; ++wo) {
-        gb[wo] += av[wo];
+        gb[wo] += bias_on ? av[wo] : 0.f;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
           acc[wo][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[wo], bv[t], acc[wo][t], 0, 0, 0);
@@ -200,6 +203,7 @@ __global__ void __launch_bounds__(512) wgrad3x3_mfma(const WgradArgs a) {
       if (next < a.ntiles) build_tab(next);
       __syncthreads();
       if (next < a.ntiles) load_tile(next);  // in flight during the MFMA phase below
+      cur_tn = (tile / a.tiles_x) / a.tiles_y;
       compute_tile();
     }
   } else {
@@ -256,6 +260,7 @@ __global__ void __launch_bounds__(512) wgrad3x3_mfma(const WgradArgs a) {
         }
       }
       __syncthreads();
+      cur_tn = tn;
       compute_tile();
     }
   }
@@ -441,7 +446,8 @@ extern "C" size_t mg_conv3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int
 }
 
 extern "C" int mg_conv3x3_wgrad(const float* x, const float* gy, float* gw, float* gb, void* ws, size_t ws_bytes, int N,
-                                int Cin, int Cout, int H, int W, int flags, int accumulate, mg_stream_t stream) {
+                                int Cin, int Cout, int H, int W, int flags, int accumulate, int bias_n,
+                                mg_stream_t stream) {
   MG_CHECK_ARG(x && gy && gw && ws && N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "mg_conv3x3_wgrad: bad arguments");
   const bool ups = flags & MG_CONV_UPS_IN;
   MG_CHECK_ARG(!ups || ((H % 2 == 0) && (W % 2 == 0)), "mg_conv3x3_wgrad: upsampled input needs even H,W");
@@ -460,6 +466,7 @@ extern "C" int mg_conv3x3_wgrad(const float* x, const float* gy, float* gw, floa
   a.slab_b = a.slab + (size_t)pl.nsplit * 9 * Cout * Cin;
   a.ups = ups ? 1 : 0;
   a.Hin = ups ? H / 2 : H; a.Win = ups ? W / 2 : W;
+  a.bias_n = (bias_n <= 0 || bias_n > N) ? N : bias_n;
   const int rc = dispatch_wgrad(pl, s);
   if (rc != MG_OK) return rc;
   const int total = 9 * Cout * Cin + Cout;

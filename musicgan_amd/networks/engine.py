@@ -84,7 +84,7 @@ class GenWeights:
         return out
 
 
-def gen_forward(W: GenWeights, z: torch.Tensor, alpha: float, cache: PackCache, save: bool):
+def gen_forward(W: GenWeights, z: torch.Tensor, alpha: float, cache: PackCache, save: bool, out=None):
     x = z.contiguous()
     saved = []
     for (w1, b1, w2, b2) in W.blocks:
@@ -95,13 +95,13 @@ def gen_forward(W: GenWeights, z: torch.Tensor, alpha: float, cache: PackCache, 
         if save:
             saved.append((x, rn1, p1, rn2, p2))
         x_in_last, x = x, p2
-    mp = ops.conv1x1(x, W.head[0], W.head[1], 2, tanh=True)
     old = None
     if W.old_head is not None:
+        mp = ops.conv1x1(x, W.head[0], W.head[1], 2, tanh=True)
         old = ops.conv1x1(x_in_last, W.old_head[0], W.old_head[1], 2, tanh=True)
-        out = ops.blend_up(alpha, mp, 1.0 - alpha, old)
+        out = ops.blend_up(alpha, mp, 1.0 - alpha, old, out=out)
     else:
-        out = mp
+        out = mp = ops.conv1x1(x, W.head[0], W.head[1], 2, tanh=True, out=out)
     ctx = (saved, x, mp, old, alpha) if save else None
     return out, ctx
 
@@ -298,3 +298,80 @@ def disc_gp_param_grads(W: DiscWeights, ctx, hs, u0: torch.Tensor, cache: PackCa
     ops.linear1_bwd(t.reshape(n, -1), W.clf[0], ones, gw=gwc, gb=None, need_gx=False, accumulate=acc)
     # parameters that the penalty does not reach (biases) still need a defined gradient when this sink is returned alone
     return sink
+
+
+# =====================================================================================================================
+# Fused discriminator step (one batched pass instead of three)
+# =====================================================================================================================
+def disc_step_fused(W: DiscWeights, x_real: torch.Tensor, x_fake: torch.Tensor, eps: torch.Tensor, alpha: float,
+                    cache: PackCache, sink: GradSink, gp_factor: float = 10.0, xcat: Optional[torch.Tensor] = None):
+    """Gradient of  -(mean D(x_real) - mean D(x_fake)) + gp_factor * mean((||grad D(x~)|| - 1)^2)  w.r.t. every live critic
+    parameter, written into `sink`; returns (disc_loss, grad_pen, out) with out = D([x_real; x_fake; x~]).
+
+    Same arithmetic as three `disc_forward` + two `disc_backward` + `disc_gp_param_grads`, organised as ONE forward and ONE
+    data-gradient chain over the concatenated batch [real | fake | interpolated] (per-sample upstream -1/N, +1/N, 1), the
+    penalty's tangent pass written IN PLACE over the interpolated slice of every saved activation (the conv epilogue reads
+    the LeakyReLU mask and overwrites it with the tangent in the same lane), and then ONE weight-gradient launch per layer
+    over all 3N samples: x = [a_real | a_fake | u],  gy = [delta_real | delta_fake | h]  sums the Wasserstein and the penalty
+    gradients at once (bias gradients only from the first 2N samples: the penalty has none).
+    If `xcat` (3N,2,H,W) is given, x_real / x_fake must already sit in its first two thirds."""
+    n = x_real.shape[0]
+    if xcat is None:
+        xcat = torch.empty((3 * n,) + tuple(x_real.shape[1:]), dtype=torch.float32, device=x_real.device)
+        xcat[:n].copy_(x_real)
+        xcat[n:2 * n].copy_(x_fake)
+    ops.gp_interp(xcat[:n], xcat[n:2 * n], eps.contiguous(), out=xcat[2 * n:])
+    out, ctx = disc_forward(W, xcat, alpha, cache, save=True)
+    g_out = torch.empty((3 * n, 1), dtype=torch.float32, device=xcat.device)
+    g_out[:n] = -1.0 / n
+    g_out[n:2 * n] = 1.0 / n
+    g_out[2 * n:] = 1.0
+    gx, hs = disc_backward(W, ctx, g_out, cache, None, need_gx=True, keep_h=True)
+    # penalty value and u_0 = dP/dg_0, written over the interpolated inputs (they are not needed any more)
+    ss = ops.sumsq_per_sample(gx[2 * n:])
+    grad_pen, coef = ops.gp_finish(ss, gp_factor, 1.0)
+    x, h0, saved, xp, o, flat, _ = ctx
+    sl = slice(2 * n, 3 * n)
+    ops.scale_per_sample(gx[sl], coef, out=x[sl])
+    # ---- tangent pass, in place over the interpolated slices
+    c0 = W.stem[0].shape[0]
+    ops.conv1x1(x[sl], W.stem[0], None, c0, mask_aux=h0[sl], out=h0[sl])
+    if W.old_stem is not None:
+        ops.avgpool2_fwd(x[sl], out=xp[sl])
+        ops.conv1x1(xp[sl], W.old_stem[0], None, W.old_stem[0].shape[0], mask_aux=o[sl], out=o[sl])
+    nb = len(W.blocks)
+    for i, (w1, b1, w2, b2) in enumerate(W.blocks):
+        inp, a1, q1, a2 = saved[i]
+        c1 = w1.shape[0]
+        ops.conv3x3(inp[sl], cache.get(w1, False), None, c1, mask_aux=a1[sl], out=a1[sl])
+        ops.avgpool2_fwd(a1[sl], out=q1[sl])
+        ops.conv3x3(q1[sl], cache.get(w2, False), None, c1, mask_aux=a2[sl], out=a2[sl])
+        if i == 0 and W.old_stem is not None:
+            target = saved[1][0][sl] if nb > 1 else flat[sl].reshape(a2[sl].shape)
+            ops.axpby(alpha, a2[sl], 1.0 - alpha, o[sl], out=target)
+    # ---- one weight-gradient sweep over the 3N samples
+    for i, (w1, b1, w2, b2) in enumerate(W.blocks):
+        inp, a1, q1, a2 = saved[i]
+        gpre1, gpre2 = hs["blocks"][i]
+        gw1, acc = sink.slot(w1)
+        gb1, _ = sink.slot(b1)
+        ops.conv3x3_wgrad(inp, gpre1, gw1, gb1, accumulate=acc, bias_n=2 * n)
+        gw2, acc = sink.slot(w2)
+        gb2, _ = sink.slot(b2)
+        ops.conv3x3_wgrad(q1, gpre2, gw2, gb2, accumulate=acc, bias_n=2 * n)
+    lo = slice(0, 2 * n)
+    gws, acc = sink.slot(W.stem[0])
+    gbs, _ = sink.slot(W.stem[1])
+    ops.conv1x1_wgrad(x[lo], hs["stem"][lo], gws, gbs, accumulate=acc)
+    ops.conv1x1_wgrad(x[sl], hs["stem"][sl], gws, None, accumulate=True)
+    if W.old_stem is not None:
+        gwo, acc = sink.slot(W.old_stem[0])
+        gbo, _ = sink.slot(W.old_stem[1])
+        ops.conv1x1_wgrad(xp[lo], hs["old"][lo], gwo, gbo, accumulate=acc)
+        ops.conv1x1_wgrad(xp[sl], hs["old"][sl], gwo, None, accumulate=True)
+    gwc, acc = sink.slot(W.clf[0])
+    gbc, _ = sink.slot(W.clf[1])
+    ops.linear1_bwd(flat, W.clf[0], g_out, gw=gwc, gb=None, need_gx=False, accumulate=acc)
+    ops.linear1_bwd(flat[lo], W.clf[0], g_out[lo], gw=None, gb=gbc, need_gx=False, accumulate=acc)
+    disc_loss = -(out[:n].mean() - out[n:2 * n].mean())
+    return disc_loss, grad_pen, out

@@ -56,14 +56,16 @@ def pack_conv3x3(w: torch.Tensor, dgrad: bool) -> torch.Tensor:
     return wp
 
 
-def conv3x3(x, wp, bias, cout: int, *, ups=False, lrelu=False, mask_aux=None, pixnorm=False, want_y=True):
-    """Returns y, or (y, p, rn) with pixnorm.  Output spatial size = input (x2 with ups)."""
-    _chk(x, wp, bias, mask_aux)
+def conv3x3(x, wp, bias, cout: int, *, ups=False, lrelu=False, mask_aux=None, pixnorm=False, want_y=True, out=None):
+    """Returns y, or (y, p, rn) with pixnorm.  Output spatial size = input (x2 with ups).  `out` (optional) receives y; it may
+    alias mask_aux (the mask is read and the result written by the same lane)."""
+    _chk(x, wp, bias, mask_aux, out)
     n, cin, hin, win = x.shape
     h, w = (2 * hin, 2 * win) if ups else (hin, win)
     flags = (MG_CONV_UPS_IN if ups else 0) | (MG_CONV_LRELU if lrelu else 0) | \
             (MG_CONV_MASK_AUX if mask_aux is not None else 0) | (MG_CONV_PIXNORM if pixnorm else 0)
-    y = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device) if (want_y or not pixnorm) else None
+    y = out if out is not None else (
+        torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device) if (want_y or not pixnorm) else None)
     p = rn = None
     if pixnorm:
         p = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
@@ -73,8 +75,8 @@ def conv3x3(x, wp, bias, cout: int, *, ups=False, lrelu=False, mask_aux=None, pi
     return (y, p, rn) if pixnorm else y
 
 
-def conv3x3_wgrad(x, gy, gw, gb, *, ups=False, accumulate=False):
-    """gw[Cout,Cin,3,3] (+)= wgrad(x, gy); gb[Cout] (+)= sum gy (gb may be None)."""
+def conv3x3_wgrad(x, gy, gw, gb, *, ups=False, accumulate=False, bias_n: int = 0):
+    """gw[Cout,Cin,3,3] (+)= wgrad(x, gy); gb[Cout] (+)= sum gy over samples n < bias_n (0: all; gb may be None)."""
     _chk(x, gy, gw, gb)
     n, cout, h, w = gy.shape
     cin = x.shape[1]
@@ -82,12 +84,13 @@ def conv3x3_wgrad(x, gy, gw, gb, *, ups=False, accumulate=False):
     nbytes = lib.mg_conv3x3_wgrad_ws_bytes(n, cin, cout, h, w)
     ws = workspace(nbytes, x.device)
     check(lib.mg_conv3x3_wgrad(_p(x), _p(gy), _p(gw), _p(gb), _p(ws), ws.numel(), n, cin, cout, h, w,
-                               MG_CONV_UPS_IN if ups else 0, int(accumulate), _s()), "mg_conv3x3_wgrad")
+                               MG_CONV_UPS_IN if ups else 0, int(accumulate), int(bias_n), _s()), "mg_conv3x3_wgrad")
 
 
 # ------------------------------------------------------------------ conv 1x1
-def conv1x1(x, w, bias, cout: int, *, lrelu=False, tanh=False, mask_aux=None, transposed=False, tanh_bwd_in=None):
-    _chk(x, w, bias, mask_aux, tanh_bwd_in)
+def conv1x1(x, w, bias, cout: int, *, lrelu=False, tanh=False, mask_aux=None, transposed=False, tanh_bwd_in=None,
+            out=None):
+    _chk(x, w, bias, mask_aux, tanh_bwd_in, out)
     n, cin, h, wd = x.shape
     flags = (MG_C1_LRELU if lrelu else 0) | (MG_C1_TANH if tanh else 0) | (MG_C1_TRANSPOSED if transposed else 0)
     aux = None
@@ -98,7 +101,7 @@ def conv1x1(x, w, bias, cout: int, *, lrelu=False, tanh=False, mask_aux=None, tr
         assert aux is None
         flags |= MG_C1_TANH_BWD_IN
         aux = tanh_bwd_in
-    y = torch.empty((n, cout, h, wd), dtype=torch.float32, device=x.device)
+    y = out if out is not None else torch.empty((n, cout, h, wd), dtype=torch.float32, device=x.device)
     check(_lib.load().mg_conv1x1(_p(x), _p(w), _p(bias), _p(aux), _p(y), n, cin, cout, h * wd, flags, SLOPE, _s()),
           "mg_conv1x1")
     return y
@@ -157,10 +160,10 @@ def upsample2x_bwd(gy):
     return gx
 
 
-def avgpool2_fwd(x):
-    _chk(x)
+def avgpool2_fwd(x, out=None):
+    _chk(x, out)
     n, c, h, w = x.shape
-    y = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=x.device)
+    y = out if out is not None else torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=x.device)
     check(_lib.load().mg_avgpool2_fwd(_p(x), _p(y), n * c, h, w, _s()), "mg_avgpool2_fwd")
     return y
 
@@ -188,10 +191,10 @@ def axpby(a: float, x, b: float = 0.0, y=None, out=None):
     return out
 
 
-def blend_up(a: float, x, b: float, ylow):
-    _chk(x, ylow)
+def blend_up(a: float, x, b: float, ylow, out=None):
+    _chk(x, ylow, out)
     n, c, h, w = x.shape
-    out = torch.empty_like(x)
+    out = torch.empty_like(x) if out is None else out
     check(_lib.load().mg_blend_up(float(a), _p(x), float(b), _p(ylow), _p(out), n * c, h, w, _s()), "mg_blend_up")
     return out
 
@@ -214,10 +217,10 @@ def linear1_bwd(x, w, gy, *, gw=None, gb=None, need_gx=True, accumulate=False):
     return gx
 
 
-def gp_interp(x_real, x_fake, eps):
-    _chk(x_real, x_fake, eps)
+def gp_interp(x_real, x_fake, eps, out=None):
+    _chk(x_real, x_fake, eps, out)
     n = x_real.shape[0]
-    out = torch.empty_like(x_real)
+    out = torch.empty_like(x_real) if out is None else out
     check(_lib.load().mg_gp_interp(_p(x_real), _p(x_fake), _p(eps), _p(out), n, x_real[0].numel(), _s()),
           "mg_gp_interp")
     return out
@@ -231,10 +234,10 @@ def sumsq_per_sample(g):
     return out
 
 
-def scale_per_sample(g, coef):
-    _chk(g, coef)
+def scale_per_sample(g, coef, out=None):
+    _chk(g, coef, out)
     n = g.shape[0]
-    out = torch.empty_like(g)
+    out = torch.empty_like(g) if out is None else out
     check(_lib.load().mg_scale_per_sample(_p(g), _p(coef), _p(out), n, g[0].numel(), _s()), "mg_scale_per_sample")
     return out
 

@@ -22,10 +22,12 @@ from .dist import GradBucket, is_distributed
 
 
 class ProGANStepper:
-    def __init__(self, gen, disc, optim_gen, optim_disc, rand_channels: int, height: int = 2, width: int = 2):
+    def __init__(self, gen, disc, optim_gen, optim_disc, rand_channels: int, height: int = 2, width: int = 2,
+                 fused_d_step: bool = True):
         self.gen, self.disc = gen, disc
         self.optim_gen, self.optim_disc = optim_gen, optim_disc
         self.rand_channels, self.h, self.w = rand_channels, height, width
+        self.fused_d_step = fused_d_step
         self.dp = is_distributed()
         self.bucket_d = GradBucket()
         self.bucket_g = GradBucket()
@@ -49,6 +51,8 @@ class ProGANStepper:
         n = x_real.shape[0]
         if z is None:
             z = self._latent(n, x_real.device)
+        if self.fused_d_step:
+            return self._d_step_fused(x_real, alpha, z, eps)
         if self.dp:
             self.bucket_d.wait()  # D weights final (Adam of the previous D step)
         out_real = self.disc(x_real, alpha)  # independent of G: overlaps the G exchange of the previous G step
@@ -68,6 +72,34 @@ class ProGANStepper:
         self._update(self.bucket_d, self.disc, self.optim_disc)
         return {"disc_loss": disc_loss.detach(), "grad_pen": grad_pen.detach(),
                 "out_real_mean": out_real.detach().mean(), "out_fake_mean": out_fake.detach().mean()}
+
+    def _d_step_fused(self, x_real, alpha, z, eps) -> Dict[str, torch.Tensor]:
+        """Same update as the module path above through `engine.disc_step_fused`: one batched critic pass over
+        [real | fake | interpolated] instead of three, one weight-gradient launch per layer."""
+        from .networks import engine
+        n = x_real.shape[0]
+        dev = x_real.device
+        if eps is None:
+            eps = torch.rand(n, 1, 1, 1, device=dev)
+        if self.dp:
+            self.bucket_d.wait()
+            self.bucket_g.wait()
+        xcat = torch.empty((3 * n,) + tuple(x_real.shape[1:]), dtype=torch.float32, device=dev)
+        xcat[:n].copy_(x_real)
+        with torch.no_grad():
+            engine.gen_forward(self.gen._weights(), z.contiguous(), alpha, self.gen._pack_cache, save=False,
+                               out=xcat[n:2 * n])
+            W = self.disc._weights()
+            sink = engine.GradSink()
+            disc_loss, grad_pen, out = engine.disc_step_fused(W, xcat[:n], xcat[n:2 * n], eps, alpha,
+                                                              self.disc._pack_cache, sink, xcat=xcat)
+        self.gen.zero_grad()
+        self.disc.zero_grad()
+        for p in W.tensors():
+            p.grad = sink.get(p)
+        self._update(self.bucket_d, self.disc, self.optim_disc)
+        return {"disc_loss": disc_loss, "grad_pen": grad_pen, "out_real_mean": out[:n].mean(),
+                "out_fake_mean": out[n:2 * n].mean()}
 
     def g_step(self, batch_size: int, alpha: float, device, z: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         if z is None:
