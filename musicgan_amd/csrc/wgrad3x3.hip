@@ -40,7 +40,7 @@ constexpr int PF_NJ = 7;   // halo positions per lane (plane <= 224)
 constexpr int PF_NG4 = 6;  // gy float4 per thread
 
 template <int WO, int NIX>
-__global__ void __launch_bounds__(512) wgrad3x3_mfma(const WgradArgs a) {
+__global__ void __launch_bounds__(WO == 1 ? 768 : 512) wgrad3x3_mfma(const WgradArgs a) {
   constexpr bool PF = NIX > 0;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int* tab = reinterpret_cast<int*>(smem);
@@ -346,16 +346,22 @@ bool plan_wgrad(int N, int Cin, int Cout, int H, int W, WgradPlan& pl) {
   const int otiles = mg_cdiv(Cout, 16), ctiles = mg_cdiv(Cin, 16);
   a.oblocks = mg_cdiv(otiles, 4);
   const int TB = mg_cdiv(otiles, a.oblocks);  // out-channel tiles per workgroup (<= 4)
-  // waves = ogroups x nct <= 8: fewest in-channel blocks first (each re-reads the gy tile), then the most waves
-  int best_d = 1, best_cb = 1 << 30, best_w = 0;
+  // Wave grid = ogroups (out-channel tiles, WO each) x nct (in-channel tiles).  Preference order: a shape the pipelined
+  // kernel is instantiated for (WO == 1 with up to 12 waves, or WO == 2 x 2 groups), then the fewest in-channel blocks (each
+  // re-reads the gy tile), then the most waves.
+  int best_d = 1, best_cb = 1 << 30, best_w = 0, best_pf = -1;
   for (int d = 1; d <= TB; ++d) {
     if (TB % d) continue;
-    const int nct_max = 8 / d;
+    const int wo = TB / d;
+    const int pf = (wo == 1 || (wo == 2 && d == 2)) ? 1 : 0;
+    const int wmax = wo == 1 ? 12 : 8;
+    const int nct_max = wmax / d;
     if (nct_max < 1) continue;
     const int cbk = mg_cdiv(ctiles, nct_max);
     const int nct = mg_cdiv(ctiles, cbk);
     const int w = d * nct;
-    if (cbk < best_cb || (cbk == best_cb && w > best_w)) { best_d = d; best_cb = cbk; best_w = w; }
+    const bool better = pf > best_pf || (pf == best_pf && (cbk < best_cb || (cbk == best_cb && w > best_w)));
+    if (better) { best_d = d; best_cb = cbk; best_w = w; best_pf = pf; }
   }
   a.ogroups = best_d;
   pl.WO = TB / best_d;
@@ -425,6 +431,7 @@ int dispatch_wgrad(const WgradPlan& pl, hipStream_t s) {
     case 11: return launch_wgrad<1, 8>(pl, s);
     case 12: return launch_wgrad<1, 4>(pl, s);
     case 22: return launch_wgrad<2, 4>(pl, s);
+    case 13: return launch_wgrad<1, 3>(pl, s);
     case 14: return launch_wgrad<1, 2>(pl, s);
     default: break;
   }
