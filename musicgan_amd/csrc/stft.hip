@@ -13,8 +13,8 @@
 namespace {
 
 constexpr int NFFT = 1024, HOP = 256, NB = 512;  // NB = complex points = output bins
-constexpr int FPW = 4;                            // frames per wave
-constexpr int FPB = 16;                           // frames per workgroup
+constexpr int FPW = 2;                            // frames per wave
+constexpr int FPB = 8;                            // frames per workgroup
 constexpr int OSTR = FPB + 1;                     // padded row of the output tile (float2 units)
 
 struct cf {
@@ -150,11 +150,11 @@ __global__ void __launch_bounds__(256) stft1024_kernel(const float* __restrict__
     }
   }
   __syncthreads();
-  // transposed write-out: 16 consecutive frames of one bin per 16 lanes
-  const int f = tid & 15;
+  // transposed write-out: FPB consecutive frames of one bin per FPB lanes
+  const int f = tid & (FPB - 1);
   const int t = t0 + f;
   if (t < T) {
-    for (int k = tid >> 4; k < NB; k += 16) {
+    for (int k = tid / FPB; k < NB; k += 256 / FPB) {
       const float2 o = otile[k * OSTR + f];
       const size_t idx = (size_t)k * T + t;
       if (out_im != nullptr) {
