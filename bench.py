@@ -71,18 +71,25 @@ def dominant_kernel_probe(device, batch: int, iters: int = 10):
     b = torch.randn(48, device=device, generator=g)
     wp = ops.pack_conv3x3(w, dgrad=False)
     for _ in range(2):
-        ops.conv3x3(x, wp, b, 48, ups=True, lrelu=True, pixnorm=True)
+        ops.conv3x3(x, wp, b, 48, ups=True, lrelu=True, pixnorm=True, want_y=False)
     stream = torch.cuda.current_stream()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
     for _ in range(iters):
-        ops.conv3x3(x, wp, b, 48, ups=True, lrelu=True, pixnorm=True)
+        ops.conv3x3(x, wp, b, 48, ups=True, lrelu=True, pixnorm=True, want_y=False)  # as Generator.forward calls it
     e1.record(stream)
     e1.synchronize()
     ms = e0.elapsed_time(e1) / iters
     flop = 2.0 * 9 * 64 * 48 * 128 * 128 * batch
-    return {"name": "conv3x3_mfma<NI=3,MI=4> ups+lrelu+pixnorm 64->48@128x128", "ms": ms, "flop": flop,
-            "tflops": flop / ms / 1e9}
+    out = {"name": "conv3x3_mfma<NI=3,MI=4,PF> ups+lrelu+pixnorm 64->48@128x128", "ms": ms, "flop": flop,
+           "tflops": flop / ms / 1e9,
+           "algorithmic_bytes": 4.0 * batch * (64 * 64 * 64 + 48 * 128 * 128 + 128 * 128)}
+    # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), measured by tools/measure_traffic.sh
+    tpath = os.path.join(ROOT, "profiles", "traffic_dominant_kernel.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            out["hbm_traffic"] = json.load(f)
+    return out
 
 
 def host_cpu_share() -> int:
@@ -212,7 +219,8 @@ def main():
                                    f"Adam(1e-3,(0,0.9)) on both nets, random-init weights",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / MFMA_F32_PEAK_TFLOPS,
+                         "traffic": (dom.get("hbm_traffic") or {}).get("bytes_per_launch"),
                          "basis": f"whole step, per GPU: {fpi / 1e9:.2f} algorithmic GFLOP/image (4*Gf+12*Df) x images/s",
                          "dominant_kernel": {**dom, "frac": dom["tflops"] / MFMA_F32_PEAK_TFLOPS}},
         }

@@ -293,6 +293,39 @@ __global__ void __launch_bounds__(256) conv3x3_mfma(const ConvArgs a) {
   }
 }
 
+// Direct (non-MFMA) variant for 1x1 images (the last critic conv; 2x2 measured slower than the MFMA path).  A 256-pixel MFMA
+// tile would hold 64..256 samples with a 4x..9x halo and 5 of 9 taps entirely in the zero padding; here one thread owns one
+// output value, lanes run along the output channel (coalesced packed weights), and only in-range taps are visited.
+__global__ void __launch_bounds__(256) conv3x3_tiny(const ConvArgs a) {
+  const int HW = a.H * a.W;
+  const size_t total = (size_t)a.N * HW * a.OPF;
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int o = (int)(e % a.OPF);
+  const size_t r = e / a.OPF;
+  const int pix = (int)(r % HW);
+  const int n = (int)(r / HW);
+  if (o >= a.Cout) return;
+  const int y = pix / a.W, x = pix - y * a.W;
+  const bool ups = (a.flags & MG_CONV_UPS_IN) != 0;
+  const int HWin = a.Hin * a.Win;
+  const float* xn = a.x + (size_t)n * a.Cin * HWin;
+  float acc = a.bias != nullptr ? a.bias[o] : 0.f;
+  for (int t = 0; t < 9; ++t) {
+    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+    if (yy < 0 || yy >= a.H || xx < 0 || xx >= a.W) continue;
+    const int sp = ups ? (yy >> 1) * a.Win + (xx >> 1) : yy * a.Win + xx;
+    const float* wt = a.wp + (size_t)t * CC * a.OPF + o;
+#pragma unroll 4
+    for (int c = 0; c < a.Cin; ++c)
+      acc = fmaf(xn[(size_t)c * HWin + sp], wt[((size_t)(c >> 3) * 9 * CC + (c & 7)) * a.OPF], acc);
+  }
+  const size_t idx = ((size_t)n * a.Cout + o) * HW + pix;
+  if (a.flags & MG_CONV_LRELU) acc = mg_lrelu(acc, a.slope);
+  if (a.flags & MG_CONV_MASK_AUX) acc *= mg_lrelu_mask(a.aux[idx], a.slope);
+  a.y[idx] = acc;
+}
+
 __global__ void conv3x3_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int dgrad,
                                     int cin_call, int cout_call, int OPF, size_t total) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -407,6 +440,12 @@ extern "C" int mg_conv3x3(const float* x, const float* wp, const float* bias, co
   a.OPF = NIfull * 16;
   a.nchunk = mg_cdiv(Cin, CC);
 
+  if (H * W == 1 && !pn) {
+    const size_t total = (size_t)N * H * W * a.OPF;
+    hipLaunchKernelGGL(conv3x3_tiny, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    MG_CHECK_LAUNCH("mg_conv3x3(tiny)");
+    return MG_OK;
+  }
   // tile selection: fill the chip first (>= ~2 workgroups per CU), then grow the per-wave pixel tile
   const long long px = (long long)N * H * W;
   int MI = NIfull <= 6 ? 4 : 2;

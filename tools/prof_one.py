@@ -10,7 +10,7 @@ dev = torch.device("cuda", 0)
 R = lambda *s: torch.randn(*s, device=dev)
 if case == "g54":      # fused ups conv 64->48 @128 + lrelu + pixnorm
     x = R(N, 64, 64, 64); wp = ops.pack_conv3x3(R(48, 64, 3, 3) * 0.05, False); b = R(48)
-    fn = lambda: ops.conv3x3(x, wp, b, 48, ups=True, lrelu=True, pixnorm=True)
+    fn = lambda: ops.conv3x3(x, wp, b, 48, ups=True, lrelu=True, pixnorm=True, want_y=False)
 elif case == "d20":    # conv 48->64 @128 + lrelu
     x = R(N, 48, 128, 128); wp = ops.pack_conv3x3(R(64, 48, 3, 3) * 0.05, False); b = R(64)
     fn = lambda: ops.conv3x3(x, wp, b, 64, lrelu=True)
