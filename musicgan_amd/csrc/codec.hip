@@ -78,7 +78,33 @@ __global__ void __launch_bounds__(64) codec_unwrap_delta(const float* __restrict
   float c = 0.f;       // running cumsum of the adjustments (fp32, sequential)
   float prev_u = prev;  // unwrapped[0] = phi[0] + 0
   float mn = INFINITY, mx = -INFINITY;
-  for (int t = 1; t < T; ++t) {
+  // the recurrence is sequential, the loads are not: fetch 16 frames ahead so their latency overlaps the scan
+  constexpr int BLK = 16;
+  int t = 1;
+  for (; t + BLK <= T; t += BLK) {
+    float cur[BLK], out[BLK];
+#pragma unroll
+    for (int j = 0; j < BLK; ++j) cur[j] = p[t + j];
+#pragma unroll
+    for (int j = 0; j < BLK; ++j) {
+      const float dphi = cur[j] - prev;
+      float dm = py_mod(dphi + PI_F, TWO_PI_F) - PI_F;
+      if (dm == -PI_F && dphi > 0.f) dm = PI_F;
+      float adj = dm - dphi;
+      if (fabsf(dphi) < PI_F) adj = 0.f;
+      c += adj;
+      const float u = cur[j] + c;
+      const float dl = u - prev_u;
+      out[j] = dl;
+      mn = fminf(mn, dl);
+      mx = fmaxf(mx, dl);
+      prev = cur[j];
+      prev_u = u;
+    }
+#pragma unroll
+    for (int j = 0; j < BLK; ++j) d[t - 1 + j] = out[j];
+  }
+  for (; t < T; ++t) {
     const float cur = p[t];
     const float dphi = cur - prev;
     float dm = py_mod(dphi + PI_F, TWO_PI_F) - PI_F;
