@@ -62,6 +62,10 @@ class GradBucket:
             ready.record(main)
             with torch.cuda.stream(side):
                 side.wait_event(ready)
+                for p in plist:
+                    # the gradients were allocated on the main stream and are dropped (re-pointed) below while the side
+                    # stream may not have read them yet: tell the caching allocator they are in use there
+                    p.grad.record_stream(side)
                 flat = torch.cat([p.grad.reshape(-1) for p in plist])
                 if is_distributed():
                     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
