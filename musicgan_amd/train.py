@@ -33,7 +33,11 @@ except ImportError:  # pragma: no cover
 
 
 def train(run_name: str, input_dataset_path: str, output_dir: str, *, nb_epoch: int = 1000, batch_size: int = 6,
-          num_workers: int = 6, metric_every: int = 20, max_iters: int = 0) -> None:
+          num_workers: int = 6, metric_every: int = 20, max_iters: int = 0, save_every: int = 1000,
+          resume_from: str = None) -> None:
+    """Reference signature plus keyword-only extensions (all defaulting to the reference's literals).  `resume_from`: a
+    directory written by a previous run; the newest `train_state_k.pt` / `gen_k.pt` / `disc_k.pt` / `optim_*_k.pt` set is
+    loaded (growth level, Grower counters, weights, Adam state) -- the reference can only save (train.py never loads)."""
     assert isdir(input_dataset_path), f"\"{input_dataset_path}\" doesn't exist or is not a directory"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -65,6 +69,28 @@ def train(run_name: str, input_dataset_path: str, output_dir: str, *, nb_epoch: 
     broadcast_parameters([gen, disc])
     optim_gen = FusedAdam(gen.parameters(), lr=gen_lr, betas=betas)
     optim_disc = FusedAdam(disc.parameters(), lr=disc_lr, betas=betas)
+    start_iter = 0
+    resume_state = None
+    if resume_from is not None:
+        import glob
+        import re
+        states = glob.glob(os.path.join(resume_from, "train_state_*.pt"))
+        assert states, f"no train_state_*.pt in \"{resume_from}\""
+        k = max(int(re.search(r"train_state_(\d+)\.pt$", p).group(1)) for p in states)
+        resume_state = th.load(os.path.join(resume_from, f"train_state_{k}.pt"))
+        for _ in range(resume_state["level"]):  # replay the growth so parameter groups line up with the saved optimizers
+            gen.next_layer()
+            disc.next_layer()
+            optim_gen.add_param_group({"params": gen.end_block_params(), "lr": gen_lr, "betas": betas})
+            optim_disc.add_param_group({"params": disc.start_block_parameters(), "lr": disc_lr, "betas": betas})
+        gen.load_state_dict(th.load(os.path.join(resume_from, f"gen_{k}.pt"), map_location=device))
+        disc.load_state_dict(th.load(os.path.join(resume_from, f"disc_{k}.pt"), map_location=device))
+        optim_gen.load_state_dict(th.load(os.path.join(resume_from, f"optim_gen_{k}.pt"), map_location=device))
+        optim_disc.load_state_dict(th.load(os.path.join(resume_from, f"optim_disc_{k}.pt"), map_location=device))
+        for opt in (optim_gen, optim_disc):  # torch keeps `step` on the host, the moments on the device
+            for st in opt.state.values():
+                st["step"] = st["step"].to("cpu")
+        start_iter = int(resume_state["iter_idx"])
     stepper = ProGANStepper(gen, disc, optim_gen, optim_disc, rand_channels, height, width)
 
     audio_dataset = audio.AudioDataset(input_dataset_path)
@@ -82,12 +108,14 @@ def train(run_name: str, input_dataset_path: str, output_dir: str, *, nb_epoch: 
 
     grower = Grower(n_grow=7, fadein_lengths=[1, 25000, 37500, 50000, 62500, 75000, 87500, 100000],
                     train_lengths=[50000, 100000, 150000, 200000, 250000, 300000, 350000])
-    saver = Saver(output_dir, save_every=1000, rand_channels=rand_channels, rand_height=height, rand_width=width)
+    saver = Saver(output_dir, save_every=save_every, rand_channels=rand_channels, rand_height=height, rand_width=width)
+    if resume_state is not None:
+        grower.load_state_dict(resume_state["grower"])
 
     window = 20
     hist = {k: [0.] * window for k in ("disc_loss", "grad_pen", "gen_loss", "e_tp", "e_tn", "e_gen")}
     pending = []  # device scalars waiting for the next metric read-back
-    iter_idx = 0
+    iter_idx = start_iter
     last_gen = None
     for e in range(nb_epoch):
         if sampler is not None:
@@ -124,11 +152,12 @@ def train(run_name: str, input_dataset_path: str, output_dir: str, *, nb_epoch: 
                     "disc_loss": float(d["disc_loss"]), "gen_loss": float(last_gen["gen_loss"]),
                     "batch_tp_error": float(d["out_real_mean"]), "batch_tn_error": float(d["out_fake_mean"])})
 
-            if rank == 0:
-                if (saver.save_counter + 1) % 1000 == 0:
-                    stepper.finish()
-                saver.request_save(gen, disc, optim_gen, optim_disc, alpha)
             iter_idx += 1
+            if rank == 0:
+                if (saver.save_counter + 1) % save_every == 0:
+                    stepper.finish()
+                saver.request_save(gen, disc, optim_gen, optim_disc, alpha, train_state=lambda: {
+                    "grower": grower.state_dict(), "level": gen.curr_layer, "iter_idx": iter_idx})
 
             if grower.grow(batch_size * world) and gen.growing:
                 stepper.finish()

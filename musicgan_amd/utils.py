@@ -129,10 +129,16 @@ class Saver:
                     fig.savefig(join(self.__output_dir, f"{name}_{self.__curr_save}_ID{gen_idx}.png"))
                     plt.close()
 
-    def request_save(self, gen: Generator, disc: Discriminator, optim_gen, optim_disc, alpha: float) -> bool:
+    def request_save(self, gen: Generator, disc: Discriminator, optim_gen, optim_disc, alpha: float,
+                     train_state=None) -> bool:
+        """`train_state` (optional callable -> dict) is an extension over the reference: the growth level, the Grower counters
+        and the iteration index are written next to the four reference files as `train_state_{k}.pt`, which is what
+        `train(..., resume_from=...)` needs (the reference cannot resume: utils.py:118-145 saves weights only)."""
         self.__counter += 1
         if self.__counter % self.__save_every == 0:
             self.__save_models(gen, disc, optim_gen, optim_disc)
+            if train_state is not None:
+                th.save(train_state(), join(self.__output_dir, f"train_state_{self.__curr_save}.pt"))
             self.__save_outputs(gen, alpha)
             self.__curr_save += 1
             return True

@@ -99,7 +99,20 @@ def test_drivers_end_to_end_tiny_corpus(tmp_path):
     assert len(audio.AudioDataset(str(data_dir))) == 4
 
     from musicgan_amd.train import train
-    train("t", str(data_dir), str(out_dir), nb_epoch=3, batch_size=2, num_workers=0, max_iters=6)
+    train("t", str(data_dir), str(out_dir), nb_epoch=3, batch_size=2, num_workers=0, max_iters=6, save_every=4)
+    saved = sorted(f for f in os.listdir(out_dir) if f.endswith(".pt"))  # (+ 12 preview PNGs when matplotlib is installed)
+    assert saved == ["disc_0.pt", "gen_0.pt", "optim_disc_0.pt", "optim_gen_0.pt", "train_state_0.pt"]
+    st = torch.load(str(out_dir / "train_state_0.pt"))
+    assert st["iter_idx"] == 4 and st["level"] == 0 and st["grower"]["sample_idx"] == 6  # grow() runs after the save
+    # checkpoint keys are the reference's (gen_{k}.pt loads into a reference Generator): utils.py:118-145
+    gsd = torch.load(str(out_dir / "gen_0.pt"))
+    assert "_Generator__gen_blocks.0.0.weight" in gsd and "_Generator__end_block.0.bias" in gsd
+    osd = torch.load(str(out_dir / "optim_disc_0.pt"))
+    assert set(osd.keys()) == {"state", "param_groups"} and "exp_avg_sq" in next(iter(osd["state"].values()))
+    # resume: continues from iteration 4 with the saved weights / Adam state and runs two more iterations
+    out2 = tmp_path / "out2"
+    train("t2", str(data_dir), str(out2), nb_epoch=3, batch_size=2, num_workers=0, max_iters=6, save_every=100,
+          resume_from=str(out_dir))
     # generate needs a level-7 checkpoint
     torch.manual_seed(0)
     g7 = Generator(8, end_layer=7)
