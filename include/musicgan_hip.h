@@ -43,6 +43,7 @@ const char* mg_last_error(void);
 #define MG_CONV_LRELU 2    /* y = leaky_relu(acc + bias, slope) */
 #define MG_CONV_MASK_AUX 4 /* y = acc * (aux > 0 ? 1 : slope): LeakyReLU backward fused on the output (aux: N,Cout,H,W) */
 #define MG_CONV_PIXNORM 8  /* also emit p = y * rn and rn = 1/sqrt(mean_c(y^2)+1e-8) (needs MG_CONV_LRELU) */
+#define MG_CONV_POOL_OUT 16 /* also emit p = AvgPool2d(2,2)(y) (N,Cout,H/2,W/2) [discriminator.py:24]; excludes PIXNORM */
 
 /* number of floats of the packed (LDS-image) weight layout for a Cin->Cout conv */
 size_t mg_conv3x3_packed_floats(int Cin, int Cout);

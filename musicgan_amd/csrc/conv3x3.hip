@@ -13,6 +13,7 @@
 // banks) and weights [9 taps][8 ch][OPL] copied verbatim from the pre-packed global layout (OPL % 32 == 16, same reason).
 // D layout (16x16x4): lane holds out-channel (lane&15) of pixels 4*(lane>>4)+{0..3} => one 16-byte store per tile.
 #include <cstdlib>
+#include <type_traits>
 
 #include "mg_common.h"
 
@@ -257,6 +258,7 @@ __global__ void __launch_bounds__(256) conv3x3_mfma(const ConvArgs a) {
               const f32x4 ax = *reinterpret_cast<const f32x4*>(a.aux + idx);
 #pragma unroll
               for (int g = 0; g < 4; ++g) v[g] *= mg_lrelu_mask(ax[g], a.slope);
+              acc[mi][ni] = v;  // the pooled output below averages the masked values
             }
             if (a.y != nullptr) *reinterpret_cast<f32x4*>(a.y + idx) = v;
             if (pixnorm) *reinterpret_cast<f32x4*>(a.p + idx) = v * rnv;
@@ -290,6 +292,40 @@ __global__ void __launch_bounds__(256) conv3x3_mfma(const ConvArgs a) {
         }
       }
     }
+  }
+
+  // Fused AvgPool2d(2,2) of the output just written (discriminator.py:24): a wave holds complete row pairs -- m-tile mi and
+  // mi + TPR cover the same 16 columns of two consecutive rows, and a lane's 4 pixels are 2 horizontal pairs -- so the
+  // pooled tensor costs no extra read of the full-resolution activation.  Host guarantees: vector path, TW >= 16, an even
+  // number of tile rows per wave, even H and W.
+  if (a.flags & MG_CONV_POOL_OUT) {
+    auto pool = [&](auto tpr_) {
+      constexpr int TPR = decltype(tpr_)::value;  // m-tiles per tile row
+      const int Hp = a.H >> 1, Wp = a.W >> 1;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        if (((mi / TPR) & 1) == 0 && mi + TPR < MI) {
+          const int pb = (wave * MI + mi) * 16 + rq * 4;
+          const int c = pb & (a.TW - 1);
+          const int r = (pb >> a.lgTW) & (a.TH - 1);
+          const int n_l = pb >> (a.lgTW + a.lgTH);
+          const int n = tn * a.TN + n_l, Y = ty * a.TH + r, X = tx * a.TW + c;
+          if ((n < a.N) && (Y < a.H) && (X < a.W)) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              const int o = o0 + ni * 16 + col;
+              if (o < a.Cout) {
+                const f32x4 u = acc[mi][ni], d = acc[(mi + TPR) % MI][ni];
+                const float2 pv = make_float2(((u[0] + u[1]) + (d[0] + d[1])) * 0.25f, ((u[2] + u[3]) + (d[2] + d[3])) * 0.25f);
+                *reinterpret_cast<float2*>(a.p + (((size_t)n * a.Cout + o) * Hp + (Y >> 1)) * Wp + (X >> 1)) = pv;
+              }
+            }
+          }
+        }
+      }
+    };
+    if (a.TW == 32) pool(std::integral_constant<int, 2>{});
+    else pool(std::integral_constant<int, 1>{});
   }
 }
 
@@ -426,6 +462,8 @@ extern "C" int mg_conv3x3(const float* x, const float* wp, const float* bias, co
   MG_CHECK_ARG(!(flags & MG_CONV_MASK_AUX) || aux, "mg_conv3x3: MASK_AUX without aux");
   MG_CHECK_ARG(!pn || ((flags & MG_CONV_LRELU) && p), "mg_conv3x3: PIXNORM needs LRELU and p");
   MG_CHECK_ARG(pn || y, "mg_conv3x3: y is NULL");
+  const bool want_pool = (flags & MG_CONV_POOL_OUT) != 0;
+  MG_CHECK_ARG(!want_pool || (!pn && p && (H % 2 == 0) && (W % 2 == 0)), "mg_conv3x3: POOL_OUT needs p, even H,W, no PIXNORM");
   MG_CHECK_ARG(!((flags & MG_CONV_MASK_AUX) && (flags & (MG_CONV_LRELU | MG_CONV_PIXNORM))),
                "mg_conv3x3: MASK_AUX excludes LRELU/PIXNORM");
   const long long in_elems = (long long)N * Cin * (ups ? (H / 2) * (W / 2) : H * W);
@@ -475,9 +513,19 @@ extern "C" int mg_conv3x3(const float* x, const float* wp, const float* bias, co
   dim3 grid(a.tiles_x * a.tiles_y * a.tiles_n, NIfull / NI);
   MG_CHECK_ARG(NIfull % NI == 0, "mg_conv3x3: internal tile error");
   hipStream_t s = (hipStream_t)stream;
-  switch (MI) {
-    case 4: return dispatch_ni<4>(NI, a, grid, lds, s);
-    case 2: return dispatch_ni<2>(NI, a, grid, lds, s);
-    default: return dispatch_ni<1>(NI, a, grid, lds, s);
+  // the pooled output is produced in the epilogue when a wave owns whole row pairs; otherwise by the stand-alone kernel
+  bool pool_fused = false;
+  if (want_pool) {
+    const int rows_per_wave = (MI * 16) / a.TW;
+    pool_fused = ((W & 3) == 0) && a.TW >= 16 && rows_per_wave >= 2 && (rows_per_wave % 2 == 0) && (a.TH % 2 == 0);
+    if (!pool_fused) a.flags &= ~MG_CONV_POOL_OUT;
   }
+  int rc;
+  switch (MI) {
+    case 4: rc = dispatch_ni<4>(NI, a, grid, lds, s); break;
+    case 2: rc = dispatch_ni<2>(NI, a, grid, lds, s); break;
+    default: rc = dispatch_ni<1>(NI, a, grid, lds, s); break;
+  }
+  if (rc == MG_OK && want_pool && !pool_fused) rc = mg_avgpool2_fwd(y, p, N * Cout, H, W, stream);
+  return rc;
 }

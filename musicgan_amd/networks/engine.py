@@ -178,8 +178,7 @@ def disc_forward(W: DiscWeights, x: torch.Tensor, alpha: float, cache: PackCache
     xp = o = None
     for i, (w1, b1, w2, b2) in enumerate(W.blocks):
         c1 = w1.shape[0]
-        a1 = ops.conv3x3(inp, cache.get(w1, False), b1, c1, lrelu=True)
-        q1 = ops.avgpool2_fwd(a1)
+        a1, q1 = ops.conv3x3(inp, cache.get(w1, False), b1, c1, lrelu=True, pool=True)  # AvgPool2d fused in the epilogue
         a2 = ops.conv3x3(q1, cache.get(w2, False), b2, c1, lrelu=True)
         if save:
             saved.append((inp, a1, q1, a2))
@@ -286,8 +285,7 @@ def disc_gp_param_grads(W: DiscWeights, ctx, hs, u0: torch.Tensor, cache: PackCa
         c1 = w1.shape[0]
         gw1, acc = sink.slot(w1)
         ops.conv3x3_wgrad(t, gpre1, gw1, None, accumulate=acc)
-        t1 = ops.conv3x3(t, cache.get(w1, False), None, c1, mask_aux=a1)
-        tq = ops.avgpool2_fwd(t1)
+        t1, tq = ops.conv3x3(t, cache.get(w1, False), None, c1, mask_aux=a1, pool=True)
         gw2, acc = sink.slot(w2)
         ops.conv3x3_wgrad(tq, gpre2, gw2, None, accumulate=acc)
         t = ops.conv3x3(tq, cache.get(w2, False), None, c1, mask_aux=a2)
@@ -343,8 +341,7 @@ def disc_step_fused(W: DiscWeights, x_real: torch.Tensor, x_fake: torch.Tensor, 
     for i, (w1, b1, w2, b2) in enumerate(W.blocks):
         inp, a1, q1, a2 = saved[i]
         c1 = w1.shape[0]
-        ops.conv3x3(inp[sl], cache.get(w1, False), None, c1, mask_aux=a1[sl], out=a1[sl])
-        ops.avgpool2_fwd(a1[sl], out=q1[sl])
+        ops.conv3x3(inp[sl], cache.get(w1, False), None, c1, mask_aux=a1[sl], out=a1[sl], pool_out=q1[sl])
         ops.conv3x3(q1[sl], cache.get(w2, False), None, c1, mask_aux=a2[sl], out=a2[sl])
         if i == 0 and W.old_stem is not None:
             target = saved[1][0][sl] if nb > 1 else flat[sl].reshape(a2[sl].shape)

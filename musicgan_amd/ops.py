@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 from ._lib import (MG_C1_LRELU, MG_C1_MASK_AUX, MG_C1_TANH, MG_C1_TANH_BWD_IN, MG_C1_TRANSPOSED, MG_CONV_LRELU,
-                   MG_CONV_MASK_AUX, MG_CONV_PIXNORM, MG_CONV_UPS_IN, check)
+                   MG_CONV_MASK_AUX, MG_CONV_PIXNORM, MG_CONV_POOL_OUT, MG_CONV_UPS_IN, check)
 
 SLOPE = 0.2
 
@@ -56,22 +56,31 @@ def pack_conv3x3(w: torch.Tensor, dgrad: bool) -> torch.Tensor:
     return wp
 
 
-def conv3x3(x, wp, bias, cout: int, *, ups=False, lrelu=False, mask_aux=None, pixnorm=False, want_y=True, out=None):
-    """Returns y, or (y, p, rn) with pixnorm.  Output spatial size = input (x2 with ups).  `out` (optional) receives y; it may
-    alias mask_aux (the mask is read and the result written by the same lane)."""
-    _chk(x, wp, bias, mask_aux, out)
+def conv3x3(x, wp, bias, cout: int, *, ups=False, lrelu=False, mask_aux=None, pixnorm=False, want_y=True, out=None,
+            pool=False, pool_out=None):
+    """Returns y, or (y, p, rn) with pixnorm, or (y, pooled) with pool (AvgPool2d(2,2) of y fused in the epilogue).  Output
+    spatial size = input (x2 with ups).  `out` (optional) receives y; it may alias mask_aux (the mask is read and the result
+    written by the same lane); `pool_out` (optional) receives the pooled tensor."""
+    _chk(x, wp, bias, mask_aux, out, pool_out)
+    pool = pool or pool_out is not None
     n, cin, hin, win = x.shape
     h, w = (2 * hin, 2 * win) if ups else (hin, win)
     flags = (MG_CONV_UPS_IN if ups else 0) | (MG_CONV_LRELU if lrelu else 0) | \
-            (MG_CONV_MASK_AUX if mask_aux is not None else 0) | (MG_CONV_PIXNORM if pixnorm else 0)
+            (MG_CONV_MASK_AUX if mask_aux is not None else 0) | (MG_CONV_PIXNORM if pixnorm else 0) | \
+            (MG_CONV_POOL_OUT if pool else 0)
     y = out if out is not None else (
         torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device) if (want_y or not pixnorm) else None)
     p = rn = None
     if pixnorm:
         p = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
         rn = torch.empty((n, 1, h, w), dtype=torch.float32, device=x.device)
+    if pool:
+        p = pool_out if pool_out is not None else torch.empty((n, cout, h // 2, w // 2), dtype=torch.float32,
+                                                              device=x.device)
     check(_lib.load().mg_conv3x3(_p(x), _p(wp), _p(bias), _p(mask_aux), _p(y), _p(p), _p(rn), n, cin, cout, h, w, flags,
                                  SLOPE, _s()), "mg_conv3x3")
+    if pool:
+        return y, p
     return (y, p, rn) if pixnorm else y
 
 

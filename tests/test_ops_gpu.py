@@ -264,3 +264,28 @@ def test_stft_kernel_matches_oracle_and_torch():
     tone = torch.sin(2 * math.pi * 37 * t / 1024).float()
     spec = ops.stft_1024(tone.to(DEV)).abs().cpu()
     assert bool((spec[:, 4:-4].argmax(dim=0) == 37).all())
+
+
+@pytest.mark.parametrize("shape", [(2, 48, 64, 128, 128), (3, 64, 80, 64, 64), (4, 80, 96, 32, 32), (2, 96, 112, 16, 16),
+                                   (3, 112, 128, 8, 8), (2, 144, 160, 2, 2), (1, 24, 40, 12, 20)])
+def test_conv3x3_fused_avgpool_output(shape):
+    """MG_CONV_POOL_OUT: the pooled tensor from the conv epilogue (or the fallback launch) equals AvgPool2d(2,2) of y, for the
+    forward (bias + LeakyReLU) and the tangent (mask) forms, including in-place y over the mask."""
+    ops = _ops()
+    n, ci, co, h, w = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(9 * ci)
+    b = torch.randn(co, generator=g)
+    act = torch.randn(n, co, h, w, generator=g)
+    wp = ops.pack_conv3x3(wt.to(DEV), dgrad=False)
+    yr = F.leaky_relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1), 0.2)
+    y, q = ops.conv3x3(x.to(DEV), wp, b.to(DEV), co, lrelu=True, pool=True)
+    report("pool y", y, yr, 2e-6)
+    report("pool q", q, F.avg_pool2d(yr, 2, 2), 3e-6)
+    tr = F.conv2d(x.double(), wt.double(), None, padding=1) * torch.where(act > 0, 1.0, 0.2).double()
+    buf = act.to(DEV).clone()
+    q2 = torch.empty(n, co, h // 2, w // 2, device=DEV)
+    ops.conv3x3(x.to(DEV), wp, None, co, mask_aux=buf, out=buf, pool_out=q2)
+    report("tangent y", buf, tr, 2e-6)
+    report("tangent q", q2, F.avg_pool2d(tr, 2, 2), 3e-6)
