@@ -54,6 +54,15 @@ int mg_conv3x3_pack(const float* w, float* wp, int Co, int Ci, int dgrad, mg_str
 int mg_conv3x3(const float* x, const float* wp, const float* bias, const float* aux, float* y, float* p, float* rn,
                int N, int Cin, int Cout, int H, int W, int flags, float slope, mg_stream_t stream);
 
+/* Upsample(x2 nearest) -> Conv2d(3x3) [generator.py:26-37] in sub-pixel form: four 2x2 convolutions on the LOW-resolution
+ * input (16 instead of 36 multiply-adds per low-res pixel and channel pair; same result up to fp32 summation order).
+ * x: (N,Cin,Hin,Win); y/p: (N,Cout,2Hin,2Win); rn: (N,1,2Hin,2Win).  flags: MG_CONV_LRELU, MG_CONV_PIXNORM.  wp from
+ * mg_upconv3x3_pack (effective weights, mg_upconv3x3_packed_floats floats).  Cout <= 96 recommended (register budget). */
+size_t mg_upconv3x3_packed_floats(int Cin, int Cout);
+int mg_upconv3x3_pack(const float* w, float* wp, int Co, int Ci, mg_stream_t stream);
+int mg_upconv3x3(const float* x, const float* wp, const float* bias, float* y, float* p, float* rn, int N, int Cin, int Cout,
+                 int Hin, int Win, int flags, float slope, mg_stream_t stream);
+
 /* weight/bias gradient of the same conv (aten::convolution_backward, weight+bias grads):
  *   gw[Cout][Cin][3][3] (+)= sum_{n,y,x} gy[n,o,y,x] * xin[n,c,y+ky-1,x+kx-1],  gb[Cout] (+)= sum gy   (gb may be NULL)
  * flags: MG_CONV_UPS_IN as above; accumulate!=0 adds to gw/gb instead of overwriting.  bias_n: only samples n < bias_n feed

@@ -41,6 +41,16 @@ class PackCache:
             self._c[key] = ent
         return ent[1]
 
+    def get_up(self, w: torch.Tensor) -> torch.Tensor:
+        """Effective sub-pixel weights of Upsample(x2) -> Conv3x3 (ops.upconv3x3)."""
+        key = (id(w), "up")
+        tag = (w.data_ptr(), w._version, w.device)
+        ent = self._c.get(key)
+        if ent is None or ent[0] != tag:
+            ent = (tag, ops.pack_upconv3x3(w.detach()))
+            self._c[key] = ent
+        return ent[1]
+
     def clear(self):
         self._c.clear()
 
@@ -91,7 +101,10 @@ def gen_forward(W: GenWeights, z: torch.Tensor, alpha: float, cache: PackCache, 
         ci, co = w1.shape[0], w2.shape[0]
         # only the normalised outputs p and the per-pixel 1/norm are kept: the backward derives mask and x_hat from p
         _, p1, rn1 = ops.conv3x3(x, cache.get(w1, False), b1, ci, lrelu=True, pixnorm=True, want_y=False)
-        _, p2, rn2 = ops.conv3x3(p1, cache.get(w2, False), b2, co, ups=True, lrelu=True, pixnorm=True, want_y=False)
+        if ops.upconv3x3_supported(co, p1.shape[3]):  # sub-pixel form: 2.25x fewer MFMAs than conv over the upsampled map
+            _, p2, rn2 = ops.upconv3x3(p1, cache.get_up(w2), b2, co, lrelu=True, pixnorm=True, want_y=False)
+        else:
+            _, p2, rn2 = ops.conv3x3(p1, cache.get(w2, False), b2, co, ups=True, lrelu=True, pixnorm=True, want_y=False)
         if save:
             saved.append((x, rn1, p1, rn2, p2))
         x_in_last, x = x, p2

@@ -84,6 +84,38 @@ def conv3x3(x, wp, bias, cout: int, *, ups=False, lrelu=False, mask_aux=None, pi
     return (y, p, rn) if pixnorm else y
 
 
+def pack_upconv3x3(w: torch.Tensor) -> torch.Tensor:
+    """Effective sub-pixel weights of Upsample(x2) -> Conv3x3 in the kernel's LDS image layout."""
+    _chk(w)
+    co, ci = w.shape[0], w.shape[1]
+    lib = _lib.load()
+    wp = torch.empty(lib.mg_upconv3x3_packed_floats(ci, co), dtype=torch.float32, device=w.device)
+    check(lib.mg_upconv3x3_pack(_p(w), _p(wp), co, ci, _s()), "mg_upconv3x3_pack")
+    return wp
+
+
+def upconv3x3_supported(cout: int, win: int) -> bool:
+    """The sub-pixel kernel keeps 4 phases x all output channels of 16 pixels in one wave: beyond 80 channels its registers
+    cost more occupancy than the 2.25x MFMA saving returns (measured: 112->96 @8x8 is slower than the direct form)."""
+    return cout <= 80 and win >= 2
+
+
+def upconv3x3(x, wp, bias, cout: int, *, lrelu=False, pixnorm=False, want_y=True):
+    """Upsample(x2 nearest) -> Conv3x3 (+ LeakyReLU + PixelNorm) in sub-pixel form.  Returns y or (y, p, rn)."""
+    _chk(x, wp, bias)
+    n, cin, hin, win = x.shape
+    h, w = 2 * hin, 2 * win
+    flags = (MG_CONV_LRELU if lrelu else 0) | (MG_CONV_PIXNORM if pixnorm else 0)
+    y = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device) if (want_y or not pixnorm) else None
+    p = rn = None
+    if pixnorm:
+        p = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+        rn = torch.empty((n, 1, h, w), dtype=torch.float32, device=x.device)
+    check(_lib.load().mg_upconv3x3(_p(x), _p(wp), _p(bias), _p(y), _p(p), _p(rn), n, cin, cout, hin, win, flags, SLOPE, _s()),
+          "mg_upconv3x3")
+    return (y, p, rn) if pixnorm else y
+
+
 def conv3x3_wgrad(x, gy, gw, gb, *, ups=False, accumulate=False, bias_n: int = 0):
     """gw[Cout,Cin,3,3] (+)= wgrad(x, gy); gb[Cout] (+)= sum gy over samples n < bias_n (0: all; gb may be None)."""
     _chk(x, gy, gw, gb)

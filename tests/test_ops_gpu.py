@@ -289,3 +289,25 @@ def test_conv3x3_fused_avgpool_output(shape):
     ops.conv3x3(x.to(DEV), wp, None, co, mask_aux=buf, out=buf, pool_out=q2)
     report("tangent y", buf, tr, 2e-6)
     report("tangent q", q2, F.avg_pool2d(tr, 2, 2), 3e-6)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 16, 2, 2), (3, 32, 96, 4, 4), (2, 112, 96, 8, 8), (2, 96, 80, 16, 16),
+                                   (2, 80, 64, 32, 32), (1, 64, 48, 64, 64), (2, 24, 40, 6, 10), (1, 16, 8, 3, 5)])
+def test_upconv3x3_subpixel_matches_upsample_conv(shape):
+    """mg_upconv3x3 (four 2x2 convs on the low-res input) == Upsample(x2 nearest) -> Conv2d(3x3) -> LeakyReLU -> PixelNorm."""
+    ops = _ops()
+    n, ci, co, h, w = shape  # low-res input size
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(9 * ci)
+    b = torch.randn(co, generator=g)
+    xd = F.interpolate(x.double(), scale_factor=2.0, mode="nearest")
+    yr = F.leaky_relu(F.conv2d(xd, wt.double(), b.double(), padding=1), 0.2)
+    nr = torch.sqrt(yr.pow(2).mean(dim=1, keepdim=True) + 1e-8)
+    wp = ops.pack_upconv3x3(wt.to(DEV))
+    y, p, rn = ops.upconv3x3(x.to(DEV), wp, b.to(DEV), co, lrelu=True, pixnorm=True)
+    report("upconv y", y, yr, 3e-6)
+    report("upconv p", p, yr / nr, 4e-6)
+    report("upconv rn", rn, 1.0 / nr, 4e-6)
+    y2 = ops.upconv3x3(x.to(DEV), wp, None, co)
+    report("upconv plain", y2, F.conv2d(xd, wt.double(), None, padding=1), 3e-6)

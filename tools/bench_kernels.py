@@ -78,3 +78,21 @@ bw_case("axpby 64@64", lambda: ops.axpby(0.5, gq, 0.5, gq), 3 * gq.numel() * 4)
 print(f"{'kernel':42s} {'ms':>8s} {'TFLOP/s | GB/s':>16s}")
 for name, ms, v in rows:
     print(f"{name:42s} {ms:8.3f} {('%.1f TF' % v) if v >= 0 else ('%.0f GB/s' % -v):>16s}")
+
+# sub-pixel form of the generator's upsample-convs vs the direct form (same layers)
+rows.clear()
+def up_case(name, ci, co, hin):
+    x = R(N, ci, hin, hin); wt = R(co, ci, 3, 3) * 0.05; b = R(co)
+    wpu = ops.pack_upconv3x3(wt); wpd = ops.pack_conv3x3(wt, dgrad=False)
+    fl = 2.0 * 9 * ci * co * (2 * hin) ** 2 * N
+    ms = timeit(lambda: ops.upconv3x3(x, wpu, b, co, lrelu=True, pixnorm=True, want_y=False))
+    rows.append((name + " sub-pixel", ms, fl / ms / 1e9))
+    ms = timeit(lambda: ops.conv3x3(x, wpd, b, co, ups=True, lrelu=True, pixnorm=True, want_y=False))
+    rows.append((name + " direct", ms, fl / ms / 1e9))
+up_case("G5.4 64->48 @64->128", 64, 48, 64)
+up_case("G4.4 80->64 @32->64", 80, 64, 32)
+up_case("G3.4 96->80 @16->32", 96, 80, 16)
+up_case("G2.4 112->96 @8->16", 112, 96, 8)
+print("(TF/s below are ALGORITHMIC: 18*Cin*Cout per output pixel)")
+for name, ms, v in rows:
+    print(f"{name:42s} {ms:8.3f} {('%.1f TF' % v):>16s}")
