@@ -63,6 +63,14 @@ int mg_upconv3x3_pack(const float* w, float* wp, int Co, int Ci, mg_stream_t str
 int mg_upconv3x3(const float* x, const float* wp, const float* bias, float* y, float* p, float* rn, int N, int Cin, int Cout,
                  int Hin, int Win, int flags, float slope, mg_stream_t stream);
 
+/* Data gradient of Upsample(x2) -> Conv3x3 w.r.t. the LOW-resolution input: one stride-2 convolution with the 4x4 effective
+ * kernel over gy (N,Cout,2Hin,2Win) -> gx (N,Cin,Hin,Win); replaces conv-dgrad at 2Hx2W + the 2x2 block sums of Upsample's
+ * backward.  wp from mg_upconv3x3_dgrad_pack(w [Co][Ci][3][3]). */
+size_t mg_upconv3x3_dgrad_packed_floats(int Cin, int Cout);
+int mg_upconv3x3_dgrad_pack(const float* w, float* wp, int Co, int Ci, mg_stream_t stream);
+int mg_upconv3x3_dgrad(const float* gy, const float* wp, float* gx, int N, int Cin, int Cout, int Hin, int Win,
+                       mg_stream_t stream);
+
 /* weight/bias gradient of the same conv (aten::convolution_backward, weight+bias grads):
  *   gw[Cout][Cin][3][3] (+)= sum_{n,y,x} gy[n,o,y,x] * xin[n,c,y+ky-1,x+kx-1],  gb[Cout] (+)= sum gy   (gb may be NULL)
  * flags: MG_CONV_UPS_IN as above; accumulate!=0 adds to gw/gb instead of overwriting.  bias_n: only samples n < bias_n feed

@@ -274,6 +274,233 @@ __global__ void __launch_bounds__(256) upconv3x3_mfma(const UpArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Data gradient of the same layer in sub-pixel form.  The transpose of "four 2x2 convs + pixel interleave" is ONE stride-2
+// convolution with a 4x4 effective kernel over the high-resolution output gradient:
+//   gx[c, y, x] = sum_o sum_{u,v in 0..3} K4[u][v][o][c] * gy[o, 2y + u - 1, 2x + v - 1],
+//   K4[u][.] = Weff[py(u)][.][a(u)][.]   with row offsets u-1: -1 -> (py 1, a 1), 0 -> (0, 1), +1 -> (1, 0), +2 -> (0, 0)
+// (it replaces conv3x3-dgrad at 2H x 2W followed by the 2x2 block sum of Upsample's backward: 16 instead of 36 multiply-adds
+// per low-res pixel and channel pair, and the 4x larger intermediate gradient is never written).
+// Implicit GEMM like conv3x3.hip: M = 16 low-res pixels per MFMA tile (MI = 2 tiles per wave), N = input channels of the
+// forward conv, K = 4 gradient channels of one of the 16 taps.  The A operand walks the staged high-res halo tile with stride 2
+// (16 lanes x 8 bytes = 32 distinct even banks); the channel stride is odd so the second k-lane lands on the odd banks.
+struct DownArgs {
+  const float* gy;  // (N, Cg, 2H, 2W)
+  const float* wp;  // [Cg/8][16][8][OPF]
+  float* gx;        // (N, Cx, H, W)
+  int N, Cg, Cx, H, W;
+  int TH, TW, TN, lgTH, lgTW, THp, TWp;
+  int tiles_x, tiles_y, tiles_n;
+  int plane, ch_stride, tab_floats;
+  int OPF, nchunk;
+};
+
+constexpr int DN_MI = 2;
+constexpr int DN_NIN = 24;  // halo positions per thread in flight (plane <= 768)
+
+template <int NI>
+__global__ void __launch_bounds__(256) downconv4x4s2_mfma(const DownArgs a) {
+  constexpr int MI = DN_MI;
+  constexpr int OPL = (NI & 1) ? NI * 16 : NI * 16 + 16;
+  constexpr int NW4 = (16 * CC * NI * 4 + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int* tab = reinterpret_cast<int*>(smem);
+  float* in_t = smem + a.tab_floats;
+  float* w_t = in_t + CC * a.ch_stride;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 15, rq = lane >> 4;
+  const int bid = mg_xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = bid % a.tiles_x;
+  const int t2 = bid / a.tiles_x;
+  const int ty = t2 % a.tiles_y;
+  const int tn = t2 / a.tiles_y;
+  const int Hh = 2 * a.H, Wh = 2 * a.W;
+  const int HWh = Hh * Wh;
+  const float* gn = a.gy + (size_t)tn * a.TN * a.Cg * HWh;
+
+  {
+    const int THpTWp = a.THp * a.TWp;
+    for (int pos = tid; pos < a.plane; pos += 256) {
+      const int n_l = pos / THpTWp;
+      const int rem = pos - n_l * THpTWp;
+      const int rr = rem / a.TWp;
+      const int cc = rem - rr * a.TWp;
+      const int n = tn * a.TN + n_l, Y = 2 * ty * a.TH + rr - 1, X = 2 * tx * a.TW + cc - 1;
+      const bool ok = (n < a.N) && (Y >= 0) && (Y < Hh) && (X >= 0) && (X < Wh);
+      tab[pos] = ok ? n_l * a.Cg * HWh + Y * Wh + X : -1;
+    }
+  }
+
+  int pix_off[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int p = (wave * MI + mi) * 16 + col;
+    const int c = p & (a.TW - 1);
+    const int r = (p >> a.lgTW) & (a.TH - 1);
+    const int n_l = p >> (a.lgTW + a.lgTH);
+    pix_off[mi] = (n_l * a.THp + 2 * r) * a.TWp + 2 * c + rq * a.ch_stride;
+  }
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int cl_ = tid >> 5, l32_ = tid & 31;
+  float rin[DN_NIN];
+  f32x4 rw[NW4];
+  auto load_chunk = [&](int ch) {
+    const int c = ch * CC + cl_;
+    const bool cok = c < a.Cg;
+    const float* gc = gn + (size_t)c * HWh;
+#pragma unroll
+    for (int j = 0; j < DN_NIN; ++j) {
+      const int pos = l32_ + 32 * j;
+      float v = 0.f;
+      if (pos < a.plane) {
+        const int off = tab[pos];
+        if (cok && off >= 0) v = gc[off];
+      }
+      rin[j] = v;
+    }
+    const float* src = a.wp + (size_t)ch * (16 * CC) * a.OPF;
+#pragma unroll
+    for (int j = 0; j < NW4; ++j) {
+      const int e = tid + 256 * j;
+      if (e < 16 * CC * NI * 4) {
+        const int row = e / (NI * 4);
+        const int jj = e - row * (NI * 4);
+        rw[j] = *reinterpret_cast<const f32x4*>(src + (size_t)row * a.OPF + 4 * jj);
+      }
+    }
+  };
+  auto store_chunk = [&]() {
+    float* dst = in_t + cl_ * a.ch_stride;
+#pragma unroll
+    for (int j = 0; j < DN_NIN; ++j) {
+      const int pos = l32_ + 32 * j;
+      if (pos < a.plane) dst[pos] = rin[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NW4; ++j) {
+      const int e = tid + 256 * j;
+      if (e < 16 * CC * NI * 4) {
+        const int row = e / (NI * 4);
+        const int jj = e - row * (NI * 4);
+        *reinterpret_cast<f32x4*>(w_t + row * OPL + 4 * jj) = rw[j];
+      }
+    }
+  };
+  auto compute_chunk = [&]() {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int tap = (t >> 2) * a.TWp + (t & 3);
+#pragma unroll
+      for (int ks = 0; ks < CC / 4; ++ks) {
+        float av[MI], bv[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) av[mi] = in_t[pix_off[mi] + ks * 4 * a.ch_stride + tap];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bv[ni] = w_t[(t * CC + ks * 4 + rq) * OPL + ni * 16 + col];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+      }
+    }
+  };
+
+  __syncthreads();
+  load_chunk(0);
+  for (int ch = 0; ch < a.nchunk; ++ch) {
+    __syncthreads();
+    store_chunk();
+    __syncthreads();
+    if (ch + 1 < a.nchunk) load_chunk(ch + 1);
+    compute_chunk();
+  }
+
+  const bool vec = (a.TW >= 4) && ((a.W & 3) == 0);
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int pb = (wave * MI + mi) * 16 + rq * 4;
+    if (vec) {
+      const int c = pb & (a.TW - 1);
+      const int r = (pb >> a.lgTW) & (a.TH - 1);
+      const int n_l = pb >> (a.lgTW + a.lgTH);
+      const int n = tn * a.TN + n_l, Y = ty * a.TH + r, X = tx * a.TW + c;
+      if ((n < a.N) && (Y < a.H) && (X < a.W)) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int o = ni * 16 + col;
+          if (o < a.Cx) *reinterpret_cast<f32x4*>(a.gx + (((size_t)n * a.Cx + o) * a.H + Y) * a.W + X) = acc[mi][ni];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int pl = pb + g;
+        const int c = pl & (a.TW - 1);
+        const int r = (pl >> a.lgTW) & (a.TH - 1);
+        const int n_l = pl >> (a.lgTW + a.lgTH);
+        const int n = tn * a.TN + n_l, Y = ty * a.TH + r, X = tx * a.TW + c;
+        if ((n < a.N) && (Y < a.H) && (X < a.W)) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            const int o = ni * 16 + col;
+            if (o < a.Cx) a.gx[(((size_t)n * a.Cx + o) * a.H + Y) * a.W + X] = acc[mi][ni][g];
+          }
+        }
+      }
+    }
+  }
+}
+
+// K4 weights of the data-gradient form, LDS image layout [Cg/8][16][8][OPF]; w is the module weight [Co][Ci][3][3], Cg = Co, Cx = Ci.
+__global__ void downconv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int OPF,
+                                     size_t total) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int c = (int)(e % OPF);  // forward input channel = output channel of this conv
+  size_t r = e / OPF;
+  const int cl = (int)(r % CC);
+  r /= CC;
+  const int t = (int)(r % 16);
+  const int ch = (int)(r / 16);
+  const int o = ch * CC + cl;  // gradient (forward output) channel
+  float v = 0.f;
+  if (o < Co && c < Ci) {
+    const int u = t >> 2, vv = t & 3;
+    // offset u-1: -1 -> (p 1, t 1), 0 -> (0, 1), +1 -> (1, 0), +2 -> (0, 0);  taps of (p, t): p=0: t=0 {0}, t=1 {1,2}; p=1: t=0 {0,1}, t=1 {2}
+    const int py = (u == 0 || u == 2) ? 1 : 0, ta = (u <= 1) ? 1 : 0;
+    const int px = (vv == 0 || vv == 2) ? 1 : 0, tb = (vv <= 1) ? 1 : 0;
+    const int ky0 = py == 0 ? (ta == 0 ? 0 : 1) : (ta == 0 ? 0 : 2);
+    const int ky1 = py == 0 ? (ta == 0 ? 0 : 2) : (ta == 0 ? 1 : 2);
+    const int kx0 = px == 0 ? (tb == 0 ? 0 : 1) : (tb == 0 ? 0 : 2);
+    const int kx1 = px == 0 ? (tb == 0 ? 0 : 2) : (tb == 0 ? 1 : 2);
+    const float* wk = w + ((size_t)o * Ci + c) * 9;
+    for (int ky = ky0; ky <= ky1; ++ky)
+      for (int kx = kx0; kx <= kx1; ++kx) v += wk[ky * 3 + kx];
+  }
+  wp[e] = v;
+}
+
+template <int NI>
+int launch_down(const DownArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&downconv4x4s2_mfma<NI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((downconv4x4s2_mfma<NI>), grid, dim3(256), lds, s, a);
+  MG_CHECK_LAUNCH("mg_upconv3x3_dgrad");
+  return MG_OK;
+}
+
 // Effective sub-pixel weights in the LDS image layout.  w is the module weight [Co][Ci][3][3].
 __global__ void upconv3x3_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int OPF,
                                       size_t total) {
@@ -374,5 +601,60 @@ extern "C" int mg_upconv3x3(const float* x, const float* wp, const float* bias, 
     case 8: return launch_up<8>(a, grid, lds, s);
     case 9: return launch_up<9>(a, grid, lds, s);
     default: return launch_up<10>(a, grid, lds, s);
+  }
+}
+
+extern "C" size_t mg_upconv3x3_dgrad_packed_floats(int Cin, int Cout) {
+  return (size_t)mg_cdiv(Cout, CC) * 16 * CC * (size_t)(16 * mg_cdiv(Cin, 16));
+}
+
+extern "C" int mg_upconv3x3_dgrad_pack(const float* w, float* wp, int Co, int Ci, mg_stream_t stream) {
+  MG_CHECK_ARG(w && wp && Co > 0 && Ci > 0, "mg_upconv3x3_dgrad_pack: bad arguments");
+  const int OPF = 16 * mg_cdiv(Ci, 16);
+  const size_t total = mg_upconv3x3_dgrad_packed_floats(Ci, Co);
+  hipLaunchKernelGGL(downconv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, wp,
+                     Co, Ci, OPF, total);
+  MG_CHECK_LAUNCH("mg_upconv3x3_dgrad_pack");
+  return MG_OK;
+}
+
+extern "C" int mg_upconv3x3_dgrad(const float* gy, const float* wp, float* gx, int N, int Cin, int Cout, int Hin, int Win,
+                                  mg_stream_t stream) {
+  MG_CHECK_ARG(gy && wp && gx && N > 0 && Cin > 0 && Cout > 0 && Hin > 0 && Win > 0, "mg_upconv3x3_dgrad: bad arguments");
+  MG_CHECK_ARG(Cin <= 160, "mg_upconv3x3_dgrad: Cin=%d > 160 unsupported", Cin);
+  MG_CHECK_ARG((long long)N * Cout * 4 * Hin * Win < (1ll << 31), "mg_upconv3x3_dgrad: tensor too large");
+  DownArgs a;
+  a.gy = gy; a.wp = wp; a.gx = gx;
+  a.N = N; a.Cg = Cout; a.Cx = Cin; a.H = Hin; a.W = Win;
+  const int NI = mg_cdiv(Cin, 16);
+  a.OPF = NI * 16;
+  a.nchunk = mg_cdiv(Cout, CC);
+  const int P = 64 * DN_MI;
+  a.TW = mg_pow2_ceil(Win) < 32 ? mg_pow2_ceil(Win) : 32;
+  a.TH = mg_pow2_ceil(Hin) < P / a.TW ? mg_pow2_ceil(Hin) : P / a.TW;
+  a.TN = P / (a.TW * a.TH);
+  a.lgTW = mg_ilog2(a.TW); a.lgTH = mg_ilog2(a.TH);
+  a.THp = 2 * a.TH + 2; a.TWp = 2 * a.TW + 2;
+  a.tiles_x = mg_cdiv(Win, a.TW); a.tiles_y = mg_cdiv(Hin, a.TH); a.tiles_n = mg_cdiv(N, a.TN);
+  a.plane = a.TN * a.THp * a.TWp;
+  MG_CHECK_ARG(a.plane <= 32 * DN_NIN, "mg_upconv3x3_dgrad: halo tile too large (plane %d)", a.plane);
+  a.ch_stride = a.plane | 1;  // odd: the stride-2 operand reads of the two k-lanes of a half-wave use disjoint bank parities
+  a.tab_floats = (a.plane + 3) & ~3;
+  const int OPL = (NI & 1) ? NI * 16 : NI * 16 + 16;
+  const size_t lds = (size_t)(a.tab_floats + ((CC * a.ch_stride + 3) & ~3) + 16 * CC * OPL) * sizeof(float);
+  MG_CHECK_ARG(lds <= 160 * 1024, "mg_upconv3x3_dgrad: LDS tile too large");
+  dim3 grid(a.tiles_x * a.tiles_y * a.tiles_n);
+  hipStream_t s = (hipStream_t)stream;
+  switch (NI) {
+    case 1: return launch_down<1>(a, grid, lds, s);
+    case 2: return launch_down<2>(a, grid, lds, s);
+    case 3: return launch_down<3>(a, grid, lds, s);
+    case 4: return launch_down<4>(a, grid, lds, s);
+    case 5: return launch_down<5>(a, grid, lds, s);
+    case 6: return launch_down<6>(a, grid, lds, s);
+    case 7: return launch_down<7>(a, grid, lds, s);
+    case 8: return launch_down<8>(a, grid, lds, s);
+    case 9: return launch_down<9>(a, grid, lds, s);
+    default: return launch_down<10>(a, grid, lds, s);
   }
 }

@@ -51,6 +51,16 @@ class PackCache:
             self._c[key] = ent
         return ent[1]
 
+    def get_up_dgrad(self, w: torch.Tensor) -> torch.Tensor:
+        """4x4 stride-2 effective kernel of the upsample-conv data gradient (ops.upconv3x3_dgrad)."""
+        key = (id(w), "updg")
+        tag = (w.data_ptr(), w._version, w.device)
+        ent = self._c.get(key)
+        if ent is None or ent[0] != tag:
+            ent = (tag, ops.pack_upconv3x3_dgrad(w.detach()))
+            self._c[key] = ent
+        return ent[1]
+
     def clear(self):
         self._c.clear()
 
@@ -142,8 +152,10 @@ def gen_backward(W: GenWeights, ctx, g_out: torch.Tensor, cache: PackCache, sink
         gw2, acc = sink.slot(w2)
         gb2, _ = sink.slot(b2)
         ops.conv3x3_wgrad(p1, gpre2, gw2, gb2, ups=True, accumulate=acc)
-        gup = ops.conv3x3(gpre2, cache.get(w2, True), None, ci)
-        gp1 = ops.upsample2x_bwd(gup)
+        if ops.upconv3x3_dgrad_supported(p1.shape[2], p1.shape[3]):
+            gp1 = ops.upconv3x3_dgrad(gpre2, cache.get_up_dgrad(w2), ci)  # stride-2 4x4 form: no high-res intermediate
+        else:
+            gp1 = ops.upsample2x_bwd(ops.conv3x3(gpre2, cache.get(w2, True), None, ci))
         gpre1 = ops.pixelnorm_lrelu_bwd(gp1, p1, rn1, from_p=True)
         gw1, acc = sink.slot(w1)
         gb1, _ = sink.slot(b1)

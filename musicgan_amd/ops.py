@@ -3,6 +3,7 @@ every call is asynchronous on the caller's current stream.  No fallback path exi
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -114,6 +115,37 @@ def upconv3x3(x, wp, bias, cout: int, *, lrelu=False, pixnorm=False, want_y=True
     check(_lib.load().mg_upconv3x3(_p(x), _p(wp), _p(bias), _p(y), _p(p), _p(rn), n, cin, cout, hin, win, flags, SLOPE, _s()),
           "mg_upconv3x3")
     return (y, p, rn) if pixnorm else y
+
+
+def pack_upconv3x3_dgrad(w: torch.Tensor) -> torch.Tensor:
+    _chk(w)
+    co, ci = w.shape[0], w.shape[1]
+    lib = _lib.load()
+    wp = torch.empty(lib.mg_upconv3x3_dgrad_packed_floats(ci, co), dtype=torch.float32, device=w.device)
+    check(lib.mg_upconv3x3_dgrad_pack(_p(w), _p(wp), co, ci, _s()), "mg_upconv3x3_dgrad_pack")
+    return wp
+
+
+def upconv3x3_dgrad_supported(hin: int, win: int) -> bool:
+    """Mirrors the tile choice of mg_upconv3x3_dgrad: 128 low-res pixels per workgroup, the high-res halo tile of one
+    8-channel chunk must fit the 24-register prefetch (images below 8x8 do not; they take the plain dgrad + block-sum path)."""
+    if os.environ.get("MG_UPCONV_DGRAD", "1") == "0":  # A/B switch for measurements
+        return False
+    p2 = lambda v: 1 << max(0, (v - 1).bit_length())
+    tw = min(32, p2(win))
+    th = min(p2(hin), 128 // tw)
+    tn = 128 // (tw * th)
+    return tn * (2 * th + 2) * (2 * tw + 2) <= 768
+
+
+def upconv3x3_dgrad(gy, wp, cin: int):
+    """Gradient of Upsample(x2) -> Conv3x3 w.r.t. its low-resolution input: (N,Cout,2H,2W) -> (N,Cin,H,W)."""
+    _chk(gy, wp)
+    n, cout, h2, w2 = gy.shape
+    gx = torch.empty((n, cin, h2 // 2, w2 // 2), dtype=torch.float32, device=gy.device)
+    check(_lib.load().mg_upconv3x3_dgrad(_p(gy), _p(wp), _p(gx), n, cin, cout, h2 // 2, w2 // 2, _s()),
+          "mg_upconv3x3_dgrad")
+    return gx
 
 
 def conv3x3_wgrad(x, gy, gw, gb, *, ups=False, accumulate=False, bias_n: int = 0):

@@ -311,3 +311,28 @@ def test_upconv3x3_subpixel_matches_upsample_conv(shape):
     report("upconv rn", rn, 1.0 / nr, 4e-6)
     y2 = ops.upconv3x3(x.to(DEV), wp, None, co)
     report("upconv plain", y2, F.conv2d(xd, wt.double(), None, padding=1), 3e-6)
+
+
+def test_upconv3x3_dgrad_small_images_are_refused():
+    ops = _ops()
+    assert not ops.upconv3x3_dgrad_supported(2, 2) and not ops.upconv3x3_dgrad_supported(4, 4)
+    assert ops.upconv3x3_dgrad_supported(8, 8) and ops.upconv3x3_dgrad_supported(64, 64)
+    wp = ops.pack_upconv3x3_dgrad(torch.randn(16, 8, 3, 3, device=DEV))
+    with pytest.raises(Exception, match="halo tile too large"):
+        ops.upconv3x3_dgrad(torch.randn(2, 16, 4, 4, device=DEV), wp, 8)
+
+
+@pytest.mark.parametrize("shape", [(3, 128, 112, 8, 8), (2, 112, 96, 8, 8), (2, 96, 80, 16, 16), (5, 20, 17, 8, 16),
+                                   (2, 80, 64, 32, 32), (1, 64, 48, 64, 64), (2, 24, 40, 6, 10), (1, 16, 8, 3, 5)])
+def test_upconv3x3_dgrad_matches_autograd(shape):
+    """mg_upconv3x3_dgrad (one 4x4 stride-2 conv over gy) == d/dx of Conv2d(3x3)(Upsample(x2)(x))."""
+    ops = _ops()
+    n, ci, co, h, w = shape  # low-res input size
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(n, ci, h, w, generator=g).double().requires_grad_(True)
+    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(9 * ci)
+    gy = torch.randn(n, co, 2 * h, 2 * w, generator=g)
+    (F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), wt.double(), None, padding=1) * gy.double()).sum().backward()
+    wp = ops.pack_upconv3x3_dgrad(wt.to(DEV))
+    gx = ops.upconv3x3_dgrad(gy.to(DEV), wp, ci)
+    report("upconv dgrad", gx, x.grad, 3e-6)
