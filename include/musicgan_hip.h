@@ -63,6 +63,14 @@ int mg_upconv3x3_pack(const float* w, float* wp, int Co, int Ci, mg_stream_t str
 int mg_upconv3x3(const float* x, const float* wp, const float* bias, float* y, float* p, float* rn, int N, int Cin, int Cout,
                  int Hin, int Win, int flags, float slope, mg_stream_t stream);
 
+/* The same convolution (no UPS_IN; even H, W) in Winograd F(2x2,3x3) form: 16 instead of 36 multiplies per 2x2 output tile
+ * and channel pair, fp32 throughout (rounding within ~1.2x rms of the direct form).  Same arguments, flags and fused epilogues
+ * as mg_conv3x3; PIXNORM needs Cout <= 64.  up from mg_wino3x3_pack (dgrad = 1: filters of the data-gradient convolution). */
+size_t mg_wino3x3_packed_floats(int Cin, int Cout);
+int mg_wino3x3_pack(const float* w, float* up, int Co, int Ci, int dgrad, mg_stream_t stream);
+int mg_wino3x3(const float* x, const float* up, const float* bias, const float* aux, float* y, float* p, float* rn, int N,
+               int Cin, int Cout, int H, int W, int flags, float slope, mg_stream_t stream);
+
 /* Data gradient of Upsample(x2) -> Conv3x3 w.r.t. the LOW-resolution input: one stride-2 convolution with the 4x4 effective
  * kernel over gy (N,Cout,2Hin,2Win) -> gx (N,Cin,Hin,Win); replaces conv-dgrad at 2Hx2W + the 2x2 block sums of Upsample's
  * backward.  wp from mg_upconv3x3_dgrad_pack(w [Co][Ci][3][3]). */

@@ -41,6 +41,24 @@ class PackCache:
             self._c[key] = ent
         return ent[1]
 
+    def get_wino(self, w: torch.Tensor, dgrad: bool) -> torch.Tensor:
+        """Winograd-domain filters U = G g G^T (ops.pack_wino3x3)."""
+        key = (id(w), "wino", dgrad)
+        tag = (w.data_ptr(), w._version, w.device)
+        ent = self._c.get(key)
+        if ent is None or ent[0] != tag:
+            ent = (tag, ops.pack_wino3x3(w.detach(), dgrad))
+            self._c[key] = ent
+        return ent[1]
+
+    def conv(self, x: torch.Tensor, w: torch.Tensor, dgrad: bool, bias, cout: int, **kw):
+        """ops.conv3x3 with the kernel chosen per shape: Winograd F(2x2,3x3) where it is supported and pays (large maps, no
+        fused up-sampling), the direct implicit GEMM otherwise.  Only the form that is used gets packed."""
+        n, _, h, wd = x.shape
+        if ops.wino3x3_supported(n, cout, h, wd, ups=kw.get("ups", False), pixnorm=kw.get("pixnorm", False)):
+            return ops.conv3x3(x, None, bias, cout, wino=self.get_wino(w, dgrad), **kw)
+        return ops.conv3x3(x, self.get(w, dgrad), bias, cout, **kw)
+
     def get_up(self, w: torch.Tensor) -> torch.Tensor:
         """Effective sub-pixel weights of Upsample(x2) -> Conv3x3 (ops.upconv3x3)."""
         key = (id(w), "up")
@@ -110,11 +128,11 @@ def gen_forward(W: GenWeights, z: torch.Tensor, alpha: float, cache: PackCache, 
     for (w1, b1, w2, b2) in W.blocks:
         ci, co = w1.shape[0], w2.shape[0]
         # only the normalised outputs p and the per-pixel 1/norm are kept: the backward derives mask and x_hat from p
-        _, p1, rn1 = ops.conv3x3(x, cache.get(w1, False), b1, ci, lrelu=True, pixnorm=True, want_y=False)
+        _, p1, rn1 = cache.conv(x, w1, False, b1, ci, lrelu=True, pixnorm=True, want_y=False)
         if ops.upconv3x3_supported(co, p1.shape[3]):  # sub-pixel form: 2.25x fewer MFMAs than conv over the upsampled map
             _, p2, rn2 = ops.upconv3x3(p1, cache.get_up(w2), b2, co, lrelu=True, pixnorm=True, want_y=False)
         else:
-            _, p2, rn2 = ops.conv3x3(p1, cache.get(w2, False), b2, co, ups=True, lrelu=True, pixnorm=True, want_y=False)
+            _, p2, rn2 = cache.conv(p1, w2, False, b2, co, ups=True, lrelu=True, pixnorm=True, want_y=False)
         if save:
             saved.append((x, rn1, p1, rn2, p2))
         x_in_last, x = x, p2
@@ -155,13 +173,13 @@ def gen_backward(W: GenWeights, ctx, g_out: torch.Tensor, cache: PackCache, sink
         if ops.upconv3x3_dgrad_supported(p1.shape[2], p1.shape[3]):
             gp1 = ops.upconv3x3_dgrad(gpre2, cache.get_up_dgrad(w2), ci)  # stride-2 4x4 form: no high-res intermediate
         else:
-            gp1 = ops.upsample2x_bwd(ops.conv3x3(gpre2, cache.get(w2, True), None, ci))
+            gp1 = ops.upsample2x_bwd(cache.conv(gpre2, w2, True, None, ci))
         gpre1 = ops.pixelnorm_lrelu_bwd(gp1, p1, rn1, from_p=True)
         gw1, acc = sink.slot(w1)
         gb1, _ = sink.slot(b1)
         ops.conv3x3_wgrad(xin, gpre1, gw1, gb1, accumulate=acc)
         if i > 0:
-            g = ops.conv3x3(gpre1, cache.get(w1, True), None, ci)
+            g = cache.conv(gpre1, w1, True, None, ci)
             if g_old is not None and i == last:
                 gwo, acc = sink.slot(W.old_head[0])
                 gbo, _ = sink.slot(W.old_head[1])
@@ -169,7 +187,7 @@ def gen_backward(W: GenWeights, ctx, g_out: torch.Tensor, cache: PackCache, sink
                 extra = ops.conv1x1(g_old, W.old_head[0], None, xin.shape[1], transposed=True, tanh_bwd_in=old)
                 g = ops.axpby(1.0, g, 1.0, extra, out=g)
         elif need_gz:
-            gz = ops.conv3x3(gpre1, cache.get(w1, True), None, ci)
+            gz = cache.conv(gpre1, w1, True, None, ci)
     return gz
 
 
@@ -203,8 +221,8 @@ def disc_forward(W: DiscWeights, x: torch.Tensor, alpha: float, cache: PackCache
     xp = o = None
     for i, (w1, b1, w2, b2) in enumerate(W.blocks):
         c1 = w1.shape[0]
-        a1, q1 = ops.conv3x3(inp, cache.get(w1, False), b1, c1, lrelu=True, pool=True)  # AvgPool2d fused in the epilogue
-        a2 = ops.conv3x3(q1, cache.get(w2, False), b2, c1, lrelu=True)
+        a1, q1 = cache.conv(inp, w1, False, b1, c1, lrelu=True, pool=True)  # AvgPool2d fused in the epilogue
+        a2 = cache.conv(q1, w2, False, b2, c1, lrelu=True)
         if save:
             saved.append((inp, a1, q1, a2))
         inp = a2
@@ -252,7 +270,7 @@ def disc_backward(W: DiscWeights, ctx, g_out: torch.Tensor, cache: PackCache, si
             gw2, acc = sink.slot(w2)
             gb2, _ = sink.slot(b2)
             ops.conv3x3_wgrad(q1, gpre2, gw2, gb2, accumulate=acc)
-        gq1 = ops.conv3x3(gpre2, cache.get(w2, True), None, c1)
+        gq1 = cache.conv(gpre2, w2, True, None, c1)
         gpre1 = ops.avgpool2_bwd(gq1, a1)
         if sink is not None:
             gw1, acc = sink.slot(w1)
@@ -263,13 +281,13 @@ def disc_backward(W: DiscWeights, ctx, g_out: torch.Tensor, cache: PackCache, si
         if i > 0:
             a2_prev = saved[i - 1][3]
             if i == 1 and W.old_stem is not None:  # inp is the fade-in blend of a2_prev and the old stem path
-                gblend = ops.conv3x3(gpre1, cache.get(w1, True), None, cin)
+                gblend = cache.conv(gpre1, w1, True, None, cin)
                 gpre2 = ops.lrelu_bwd(ops.axpby(alpha, gblend), a2_prev)
                 gpre_o = ops.lrelu_bwd(ops.axpby(1.0 - alpha, gblend), o)
             else:
-                gpre2 = ops.conv3x3(gpre1, cache.get(w1, True), None, cin, mask_aux=a2_prev)
+                gpre2 = cache.conv(gpre1, w1, True, None, cin, mask_aux=a2_prev)
         else:
-            gpre_s = ops.conv3x3(gpre1, cache.get(w1, True), None, cin, mask_aux=h0)
+            gpre_s = cache.conv(gpre1, w1, True, None, cin, mask_aux=h0)
     if sink is not None:
         gws, acc = sink.slot(W.stem[0])
         gbs, _ = sink.slot(W.stem[1])
@@ -310,10 +328,10 @@ def disc_gp_param_grads(W: DiscWeights, ctx, hs, u0: torch.Tensor, cache: PackCa
         c1 = w1.shape[0]
         gw1, acc = sink.slot(w1)
         ops.conv3x3_wgrad(t, gpre1, gw1, None, accumulate=acc)
-        t1, tq = ops.conv3x3(t, cache.get(w1, False), None, c1, mask_aux=a1, pool=True)
+        t1, tq = cache.conv(t, w1, False, None, c1, mask_aux=a1, pool=True)
         gw2, acc = sink.slot(w2)
         ops.conv3x3_wgrad(tq, gpre2, gw2, None, accumulate=acc)
-        t = ops.conv3x3(tq, cache.get(w2, False), None, c1, mask_aux=a2)
+        t = cache.conv(tq, w2, False, None, c1, mask_aux=a2)
         if i == 0 and to is not None:
             t = ops.axpby(alpha, t, 1.0 - alpha, to, out=t)
     ones = torch.ones((n, 1), dtype=torch.float32, device=x.device)
@@ -366,8 +384,8 @@ def disc_step_fused(W: DiscWeights, x_real: torch.Tensor, x_fake: torch.Tensor, 
     for i, (w1, b1, w2, b2) in enumerate(W.blocks):
         inp, a1, q1, a2 = saved[i]
         c1 = w1.shape[0]
-        ops.conv3x3(inp[sl], cache.get(w1, False), None, c1, mask_aux=a1[sl], out=a1[sl], pool_out=q1[sl])
-        ops.conv3x3(q1[sl], cache.get(w2, False), None, c1, mask_aux=a2[sl], out=a2[sl])
+        cache.conv(inp[sl], w1, False, None, c1, mask_aux=a1[sl], out=a1[sl], pool_out=q1[sl])
+        cache.conv(q1[sl], w2, False, None, c1, mask_aux=a2[sl], out=a2[sl])
         if i == 0 and W.old_stem is not None:
             target = saved[1][0][sl] if nb > 1 else flat[sl].reshape(a2[sl].shape)
             ops.axpby(alpha, a2[sl], 1.0 - alpha, o[sl], out=target)

@@ -57,9 +57,33 @@ def pack_conv3x3(w: torch.Tensor, dgrad: bool) -> torch.Tensor:
     return wp
 
 
+def pack_wino3x3(w: torch.Tensor, dgrad: bool) -> torch.Tensor:
+    """U = G g G^T of every filter in MFMA operand order (mg_wino3x3_pack)."""
+    _chk(w)
+    co, ci = w.shape[0], w.shape[1]
+    lib = _lib.load()
+    cin_call, cout_call = (co, ci) if dgrad else (ci, co)
+    up = torch.empty(lib.mg_wino3x3_packed_floats(cin_call, cout_call), dtype=torch.float32, device=w.device)
+    check(lib.mg_wino3x3_pack(_p(w), _p(up), co, ci, int(dgrad), _s()), "mg_wino3x3_pack")
+    return up
+
+
+def wino3x3_supported(n: int, cout: int, h: int, w: int, *, ups=False, pixnorm=False) -> bool:
+    """Whether conv3x3(..., wino=) may be used: even sizes, enough 2x2 tiles to fill the chip, and for the fused PixelNorm
+    all channels of a pixel inside one workgroup."""
+    if os.environ.get("MG_WINO", "1") == "0" or ups or (h % 2) or (w % 2):
+        return False
+    if pixnorm and cout > 64:
+        return False
+    if os.environ.get("MG_WINO_ANY_COUT", "0") == "0" and cout % 64:
+        return False  # the kernel tiles 64 output channels per workgroup; other widths currently lose to padding
+    return n * h * w >= int(os.environ.get("MG_WINO_MIN_PIXELS", "65536"))  # fewer 2x2 tiles do not fill the chip
+
+
 def conv3x3(x, wp, bias, cout: int, *, ups=False, lrelu=False, mask_aux=None, pixnorm=False, want_y=True, out=None,
-            pool=False, pool_out=None):
-    """Returns y, or (y, p, rn) with pixnorm, or (y, pooled) with pool (AvgPool2d(2,2) of y fused in the epilogue).  Output
+            pool=False, pool_out=None, wino=None):
+    """`wino` (optional, from pack_wino3x3): run the Winograd F(2x2,3x3) kernel instead of the direct one (`wp` is then unused).
+    Returns y, or (y, p, rn) with pixnorm, or (y, pooled) with pool (AvgPool2d(2,2) of y fused in the epilogue).  Output
     spatial size = input (x2 with ups).  `out` (optional) receives y; it may alias mask_aux (the mask is read and the result
     written by the same lane); `pool_out` (optional) receives the pooled tensor."""
     _chk(x, wp, bias, mask_aux, out, pool_out)
@@ -78,8 +102,13 @@ def conv3x3(x, wp, bias, cout: int, *, ups=False, lrelu=False, mask_aux=None, pi
     if pool:
         p = pool_out if pool_out is not None else torch.empty((n, cout, h // 2, w // 2), dtype=torch.float32,
                                                               device=x.device)
-    check(_lib.load().mg_conv3x3(_p(x), _p(wp), _p(bias), _p(mask_aux), _p(y), _p(p), _p(rn), n, cin, cout, h, w, flags,
-                                 SLOPE, _s()), "mg_conv3x3")
+    if wino is not None:
+        _chk(wino)
+        check(_lib.load().mg_wino3x3(_p(x), _p(wino), _p(bias), _p(mask_aux), _p(y), _p(p), _p(rn), n, cin, cout, h, w, flags,
+                                     SLOPE, _s()), "mg_wino3x3")
+    else:
+        check(_lib.load().mg_conv3x3(_p(x), _p(wp), _p(bias), _p(mask_aux), _p(y), _p(p), _p(rn), n, cin, cout, h, w, flags,
+                                     SLOPE, _s()), "mg_conv3x3")
     if pool:
         return y, p
     return (y, p, rn) if pixnorm else y

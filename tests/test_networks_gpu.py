@@ -60,8 +60,18 @@ def grad_atol(k, ref64, ref32):
     return max(GRAD_TOL * own, 5.0 * maxabs_err(ref32[k], ref64[k]), 5e-5 * gmax)
 
 
+@pytest.fixture(params=["auto", "wino_everywhere"])
+def conv_mode(request, monkeypatch):
+    """The engine picks Winograd F(2x2,3x3) only for large maps with 64-multiple widths; "wino_everywhere" forces it onto every
+    3x3 convolution it supports (any even size, any width) so the small golden cases exercise it end to end."""
+    if request.param != "auto":
+        monkeypatch.setenv("MG_WINO_MIN_PIXELS", "1")
+        monkeypatch.setenv("MG_WINO_ANY_COUT", "1")
+    return request.param
+
+
 @pytest.mark.parametrize("case", PROGAN_CASES)
-def test_train_step_matches_reference_golden(case):
+def test_train_step_matches_reference_golden(case, conv_mode):
     from musicgan_amd import networks
     from musicgan_amd.optim import FusedAdam
     from oracle import progan as O
@@ -193,7 +203,7 @@ def test_nonsquare_generator_forward():
         assert maxrel(gen(z, 0.37), torch.from_numpy(g["ns_out_a037"])) <= FWD_TOL
 
 
-def test_level4_step_against_oracle():
+def test_level4_step_against_oracle(conv_mode):
     """BASELINE.json configs[1] shape family (2x64x64) at a small batch: product vs the fp64 CPU oracle."""
     from musicgan_amd import networks
     from musicgan_amd.networks import Discriminator, Generator
@@ -232,7 +242,7 @@ def test_level4_step_against_oracle():
 
 
 @pytest.mark.parametrize("case", ["l1_rc8_fade", "l3_rc32_fade", "l2_direct"])
-def test_fused_d_step_equals_module_path(case):
+def test_fused_d_step_equals_module_path(case, conv_mode):
     """ProGANStepper's fused critic step (one batched pass over [real|fake|interpolated], in-place tangent pass, one wgrad
     launch per layer) produces the gradients of the reference-shaped module path and of the fp64 oracle."""
     from musicgan_amd.optim import FusedAdam

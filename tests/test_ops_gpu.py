@@ -336,3 +336,73 @@ def test_upconv3x3_dgrad_matches_autograd(shape):
     wp = ops.pack_upconv3x3_dgrad(wt.to(DEV))
     gx = ops.upconv3x3_dgrad(gy.to(DEV), wp, ci)
     report("upconv dgrad", gx, x.grad, 3e-6)
+
+
+WINO_SHAPES = [(2, 8, 8, 2, 2), (3, 32, 128, 4, 4), (2, 112, 96, 8, 8), (2, 96, 80, 16, 16), (2, 48, 64, 32, 32),
+               (1, 64, 48, 64, 64), (2, 24, 40, 6, 10), (3, 20, 17, 2, 12), (1, 144, 160, 16, 8), (5, 16, 32, 4, 2),
+               (1, 72, 112, 24, 40)]
+
+
+@pytest.mark.parametrize("cfg", ["", "2", "3", "4"])
+@pytest.mark.parametrize("shape", WINO_SHAPES)
+def test_wino3x3_fwd_dgrad_mask_pool(shape, cfg, monkeypatch):
+    """mg_wino3x3 (Winograd F(2x2,3x3)) against fp64 conv2d: forward + bias + LeakyReLU (+ fused AvgPool2d), plain, data
+    gradient through the transposed/flipped pack, and the masked (tangent / dgrad) epilogue -- for every out-channel tiling."""
+    ops = _ops()
+    if cfg:
+        monkeypatch.setenv("MG_WINO_CFG", cfg)
+    n, ci, co, h, w = shape
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(9 * ci)
+    b = torch.randn(co, generator=g)
+    ref = F.leaky_relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1), 0.2)
+    up = ops.pack_wino3x3(wt.to(DEV), dgrad=False)
+    y, q = ops.conv3x3(x.to(DEV), None, b.to(DEV), co, lrelu=True, pool=True, wino=up)
+    report("wino fwd", y, ref, 2e-6)
+    report("wino fwd pooled", q, F.avg_pool2d(ref, 2), 2e-6)
+    y2 = ops.conv3x3(x.to(DEV), None, None, co, wino=up)
+    report("wino plain", y2, F.conv2d(x.double(), wt.double(), None, padding=1), 2e-6)
+    gy = torch.randn(n, co, h, w, generator=g)
+    act = torch.randn(n, ci, h, w, generator=g)
+    refd = F.conv_transpose2d(gy.double(), wt.double(), padding=1)
+    upd = ops.pack_wino3x3(wt.to(DEV), dgrad=True)
+    gx = ops.conv3x3(gy.to(DEV), None, None, ci, wino=upd)
+    report("wino dgrad", gx, refd, 2e-6)
+    buf = act.to(DEV).clone()
+    gxm, gq = ops.conv3x3(gy.to(DEV), None, None, ci, mask_aux=buf, out=buf, pool=True, wino=upd)  # in place over the mask
+    refm = refd * torch.where(act > 0, 1.0, 0.2).double()
+    report("wino dgrad+mask", gxm, refm, 2e-6)
+    report("wino dgrad+mask pooled", gq, F.avg_pool2d(refm, 2), 2e-6)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 8, 2, 2), (2, 64, 64, 32, 32), (1, 80, 48, 64, 16), (3, 24, 33, 6, 10),
+                                   (2, 32, 16, 16, 16)])
+def test_wino3x3_pixnorm(shape):
+    ops = _ops()
+    n, ci, co, h, w = shape
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(9 * ci)
+    b = torch.randn(co, generator=g)
+    yr = F.leaky_relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1), 0.2)
+    nr = torch.sqrt(yr.pow(2).mean(dim=1, keepdim=True) + 1e-8)
+    up = ops.pack_wino3x3(wt.to(DEV), dgrad=False)
+    y, p, rn = ops.conv3x3(x.to(DEV), None, b.to(DEV), co, lrelu=True, pixnorm=True, wino=up)
+    report("wino pn y", y, yr, 2e-6)
+    report("wino pn p", p, yr / nr, 3e-6)
+    report("wino pn rn", rn, 1.0 / nr, 3e-6)
+    _, p2, rn2 = ops.conv3x3(x.to(DEV), None, b.to(DEV), co, lrelu=True, pixnorm=True, want_y=False, wino=up)
+    assert torch.equal(p, p2) and torch.equal(rn, rn2)
+
+
+def test_wino3x3_refuses_what_it_cannot_do():
+    ops = _ops()
+    up = ops.pack_wino3x3(torch.randn(80, 8, 3, 3, device=DEV), dgrad=False)
+    x = torch.randn(1, 8, 4, 4, device=DEV)
+    with pytest.raises(Exception, match="PIXNORM needs Cout <= 64"):
+        ops.conv3x3(x, None, None, 80, lrelu=True, pixnorm=True, wino=up)
+    with pytest.raises(Exception, match="must be even"):
+        ops.conv3x3(torch.randn(1, 8, 3, 4, device=DEV), None, None, 80, wino=up)
+    with pytest.raises(Exception, match="UPS_IN unsupported"):
+        ops.conv3x3(x, None, None, 80, ups=True, wino=up)

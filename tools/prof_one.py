@@ -20,6 +20,9 @@ elif case == "w20":    # wgrad 48->64 @128
 elif case == "w54":
     x = R(N, 64, 64, 64); gy = R(N, 48, 128, 128); gw = torch.empty(48, 64, 3, 3, device=dev); gb = torch.empty(48, device=dev)
     fn = lambda: ops.conv3x3_wgrad(x, gy, gw, gb, ups=True)
+elif case == "wino":   # Winograd conv 48->64 @128 + lrelu + fused pool
+    x = R(N, 48, 128, 128); up = ops.pack_wino3x3(R(64, 48, 3, 3) * 0.05, False); b = R(64)
+    fn = lambda: ops.conv3x3(x, None, b, 64, lrelu=True, pool=True, wino=up)
 elif case == "stft":
     wav = torch.rand(44100 * 600, device=dev) - 0.5
     fn = lambda: ops.stft_1024(wav)
