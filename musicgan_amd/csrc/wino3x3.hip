@@ -6,15 +6,21 @@
 //
 //   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A      d: 4x4 input patch (stride 2), g: 3x3 filter, Y: 2x2 outputs
 //
-// Per Winograd component xi (16 of them) this is a GEMM  M_xi[tile, out-ch] = V_xi[tile, c] * U_xi[c, out-ch]:
-//   M (A rows)  = 16 tiles per wave (one 16x16x4 MFMA tile), 4 tile groups per workgroup = 64 tiles = 256 output pixels
-//   N (B cols)  = NIW x 16 output channels per wave, WC channel groups per workgroup
+// Per Winograd component xi (16 of them) this is a GEMM  M_xi[out-ch, tile] = U_xi[c, out-ch]^T * V_xi[tile, c]:
+//   M (A rows)  = NIW x 16 output channels per wave, WC channel groups per workgroup
+//   N (B cols)  = 16 tiles per wave (one 16x16x4 MFMA tile), WT = 2 tile groups per workgroup = 32 tiles = 128 output pixels
 //   K           = input channels, 8 per LDS chunk (two MFMA k-steps: lane k-index rq holds channels 2rq and 2rq+1)
-// A wave keeps all 16 components of its (tile, channel) block in registers (16 x NIW accumulator tiles), so the output
-// transform, bias, LeakyReLU, PixelNorm, mask and 2x2 average pool are in-register epilogues; the input transform is done once
-// per (tile, channel) by the staging threads on the way from HBM to LDS; U = G g G^T is pre-computed by the pack kernel.
-// LDS images are laid out in operand order ([component][lane][2 k-steps]) so every operand read is one conflict-free
-// ds_read_b64 and the weight image is a verbatim copy of the packed global layout.
+// A wave keeps all 16 components of its (channel, tile) block in registers (16 x NIW accumulator tiles), so the output
+// transform, bias, LeakyReLU, PixelNorm, mask and 2x2 average pool are in-register epilogues, and because the filter fragment
+// is the A operand a lane ends up with 4 out-channels of ONE tile: the 16 lanes of a row group hold 16 consecutive tiles, and
+// every global store / mask load is a run of contiguous bytes per out-channel row.  The input transform is done once per
+// (tile, channel) by the staging threads on the way from HBM to LDS; U = G g G^T is pre-computed by the pack kernel.
+// LDS images are laid out in operand order ([component pair][lane][k-step][component parity]) so one conflict-free
+// ds_read_b128 feeds the operands of two components, and the weight image is a verbatim copy of the packed global layout.
+// Input patches come in through buffer loads: positions in the zero padding (and ragged tiles / channels) carry an
+// out-of-range offset and read back as 0.0 from the hardware bounds check, so the staging code has no masks or branches.
+// Workgroups are small (2 x WC waves, <= 256 registers) so that two of them share a CU: one's staging and epilogue run under
+// the other's matrix instructions ("issue early / write late" register prefetch of the next chunk inside each).
 // fp32 throughout; rounding differs from the direct form by ~1.2x rms (measured against fp64, tests/test_ops_gpu.py).
 #include <cstdlib>
 #include <type_traits>
@@ -24,7 +30,8 @@
 namespace {
 
 constexpr int WCC = 8;  // input channels per LDS chunk
-constexpr int WT = 4;   // tile groups (16 tiles each) per workgroup
+constexpr int WT = 2;   // tile groups (16 tiles each) per workgroup
+constexpr int TPB = WT * 16;  // tiles per workgroup
 constexpr float PN_EPS = 1e-8f;
 
 struct WinoArgs {
@@ -38,63 +45,75 @@ struct WinoArgs {
   int N, Cin, Cout, H, W;
   int flags;
   float slope;
-  int TBW, TBH, TBN, lgTBW, lgTBH;  // tile-block geometry in TILES: TBW * TBH * TBN == 64
+  int TBW, TBH, TBN, lgTBW, lgTBH;  // tile-block geometry in TILES: TBW * TBH * TBN == TPB
   int blocks_x, blocks_y, blocks_n;
   int nchunk;
   int NT;  // out-channel tiles in the packed weights (padded)
 };
 
 template <int NIW, int WC>
-__global__ void __launch_bounds__(256 * WC) wino3x3_mfma(const WinoArgs a) {
-  constexpr int NTHR = 256 * WC;
-  constexpr int NWAVE = 4 * WC;
-  constexpr int NITEM = WCC / NWAVE;  // (tile, channel) items transformed per thread and chunk
-  constexpr int NU4 = NIW * 2;        // 16-byte pieces of the weight image per thread and chunk
-  constexpr int V_FLOATS = 16 * WT * 128;
-  constexpr int STAGE = V_FLOATS + WC * NIW * 2048;  // one pipeline stage: V image + U image
+__global__ void __launch_bounds__(64 * WT * WC, 2) wino3x3_mfma(const WinoArgs a) {
+  constexpr int NTHR = 64 * WT * WC;
+  constexpr int NITEMS = TPB * WCC;                    // (tile, channel) items per chunk
+  constexpr int NITEM = (NITEMS + NTHR - 1) / NTHR;    // ... per thread
+  constexpr int V_FLOATS = 16 * TPB * WCC;             // [WT][8 comp pairs][64 lanes][4]
+  constexpr int U4 = WC * NIW * 512;                   // 16-byte pieces of the weight image
+  constexpr int NU4 = (U4 + NTHR - 1) / NTHR;          // ... per thread
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  // stage s: Vs = smem + s*STAGE  [16 comps][WT][64 lanes][2],  Us = Vs + V_FLOATS  [WC*NIW tiles][16 comps][64 lanes][2]
-  float* red = smem + 2 * STAGE;  // PixelNorm cross-wave partial sums [WC][64 tiles][4]
+  float* Vs = smem;
+  float* Us = smem + V_FLOATS;  // [WC*NIW tiles][8 comp pairs][64 lanes][4]
+  float* red = Us + U4 * 4;     // PixelNorm cross-wave partial sums [WC][TPB][4]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 15, rq = lane >> 4;
-  const int wt = wave & 3, wc = wave >> 2;
+  const int wt = wave % WT, wc = wave / WT;
   const int ct0 = blockIdx.y * (WC * NIW);
   const int HW = a.H * a.W;
   const int Ht = a.H >> 1, Wt = a.W >> 1;
-  const int nblk = a.blocks_x * a.blocks_y * a.blocks_n;
-  const int first = mg_xcd_remap(blockIdx.x, gridDim.x);
-  const int nmine = (nblk - first + (int)gridDim.x - 1) / (int)gridDim.x;  // spatial blocks first, first+grid, ...
-  const int Q = nmine * a.nchunk;                                          // pipeline steps of this workgroup
+  const int bid = mg_xcd_remap(blockIdx.x, gridDim.x);
+  const int bx = bid % a.blocks_x;
+  const int t2 = bid / a.blocks_x;
+  const int by = t2 % a.blocks_y;
+  const int bn = t2 / a.blocks_y;
 
-  // staging geometry of one block: this thread transforms tile `lane`, for input channels wave + k*NWAVE of every chunk
-  unsigned voff[16];   // byte offsets of the 4x4 patch from the block's first image (0 where masked)
-  unsigned okmask = 0;
-  size_t img0 = 0;     // element offset of the block's first image
-  auto geometry = [&](int blk) {
-    const int bx = blk % a.blocks_x;
-    const int t2 = blk / a.blocks_x;
-    const int by = t2 % a.blocks_y;
-    const int bn = t2 / a.blocks_y;
-    const int txl = lane & (a.TBW - 1);
-    const int tyl = (lane >> a.lgTBW) & (a.TBH - 1);
-    const int nl = lane >> (a.lgTBW + a.lgTBH);
-    const int n = bn * a.TBN + nl, TY = by * a.TBH + tyl, TX = bx * a.TBW + txl;
-    const bool ok = (n < a.N) && (TY < Ht) && (TX < Wt);
-    const int y0 = 2 * TY - 1, x0 = 2 * TX - 1;
-    const int base = nl * a.Cin * HW + y0 * a.W + x0;
-    okmask = 0;
+  // staging geometry: item it = tid + k*NTHR -> tile it % TPB, chunk-local channel it / TPB, so lanes l and l+1 of a
+  // half-wave hold horizontally adjacent tiles of one channel.  Each item loads only its OWN two pixel columns of the 4 patch
+  // rows (one aligned 8-byte load per row: 16 lanes = 128 contiguous bytes) and takes the left / right halo column from
+  // the neighbour lane (DPP wave shift); the lanes on the left / right edge of the tile block load theirs from memory.
+  // Offsets are bytes from the block's first image; 0x80000000 (beyond any num_records) marks the zero padding, tiles that
+  // do not exist, item indices past the chunk and -- for the halo loads -- every lane that has a neighbour.
+  unsigned voffP[NITEM][4], voffL[NITEM][4], voffR[NITEM][4];
+  bool ledge[NITEM], redge[NITEM];
+  int vdst[NITEM];  // LDS float offset of the item's first component pair
+  const int n0 = bn * a.TBN;
+  const int nimg = (a.N - n0) < a.TBN ? (a.N - n0) : a.TBN;
+  const float* img_base = a.x + (size_t)n0 * a.Cin * HW;
+  const unsigned img_bytes = (unsigned)nimg * (unsigned)(a.Cin * HW) * 4u;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+  for (int k = 0; k < NITEM; ++k) {
+    const int it = tid + k * NTHR;
+    const int tl = it % TPB, cl = it / TPB;
+    const int txl = tl & (a.TBW - 1);
+    const int tyl = (tl >> a.lgTBW) & (a.TBH - 1);
+    const int nl = tl >> (a.lgTBW + a.lgTBH);
+    const int TY = by * a.TBH + tyl, TX = bx * a.TBW + txl;
+    const bool ok = (it < NITEMS) && (nl < nimg) && (TY < Ht) && (TX < Wt);
+    const int base = (nl * a.Cin + cl) * HW + 2 * TX;
+    ledge[k] = txl == 0;
+    redge[k] = txl == a.TBW - 1;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bool v = ok && (y0 + r >= 0) && (y0 + r < a.H) && (x0 + j >= 0) && (x0 + j < a.W);
-        voff[r * 4 + j] = v ? (unsigned)(base + r * a.W + j) * 4u : 0u;
-        okmask |= v ? (1u << (r * 4 + j)) : 0u;
-      }
-    img0 = (size_t)bn * a.TBN * a.Cin * HW;
-  };
+    for (int r = 0; r < 4; ++r) {
+      const int Y = 2 * TY - 1 + r;
+      const bool rv = ok && (Y >= 0) && (Y < a.H);
+      const unsigned o = (unsigned)(base + Y * a.W) * 4u;
+      voffP[k][r] = rv ? o : 0x80000000u;
+      voffL[k][r] = (rv && ledge[k] && TX > 0) ? o - 4u : 0x80000000u;
+      voffR[k][r] = (rv && redge[k] && 2 * TX + 2 < a.W) ? o + 8u : 0x80000000u;
+    }
+    // [tile group][component pair][lane' = (cl>>1)*16 + tile%16][k-step = cl&1][parity]
+    vdst[k] = (it < NITEMS) ? (((tl >> 4) * 8 * 64 + (cl >> 1) * 16 + (tl & 15)) * 4 + (cl & 1) * 2) : -1;
+  }
 
   f32x4 acc[16][NIW];
 #pragma unroll
@@ -102,332 +121,322 @@ __global__ void __launch_bounds__(256 * WC) wino3x3_mfma(const WinoArgs a) {
 #pragma unroll
     for (int ni = 0; ni < NIW; ++ni) acc[c][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  float rin[NITEM][16];
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 rP[NITEM][4];
+  float rL[NITEM][4], rR[NITEM][4];
   f32x4 rw[NU4];
 
-  // branch-free: masked positions read element 0 of the channel plane and are zeroed on the way to LDS
-  auto load_in = [&](int ch) {
+  auto load_chunk = [&](int ch) {
+#ifndef WINO_EXP_NOV
+    const int soff = ch * WCC * HW * 4;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img_base), 0, (int)img_bytes, 0x00020000);
 #pragma unroll
     for (int k = 0; k < NITEM; ++k) {
-      int c = ch * WCC + wave + k * NWAVE;
-      c = c < a.Cin ? c : a.Cin - 1;
-      const char* xc = reinterpret_cast<const char*>(a.x + img0 + (size_t)c * HW);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) rin[k][e] = *reinterpret_cast<const float*>(xc + voff[e]);
+      for (int r = 0; r < 4; ++r) {
+        rP[k][r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voffP[k][r], soff, 0));
+#ifndef WINO_EXP_NOEDGE
+        rL[k][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voffL[k][r], soff, 0));
+        rR[k][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voffR[k][r], soff, 0));
+#else
+        rL[k][r] = 0.f; rR[k][r] = 0.f;
+#endif
+      }
     }
-  };
-  auto load_u = [&](int ch) {
+#endif
+#ifndef WINO_EXP_NOU
     const f32x4* src = reinterpret_cast<const f32x4*>(a.up + ((size_t)ch * a.NT + ct0) * 2048);
 #pragma unroll
-    for (int j = 0; j < NU4; ++j) rw[j] = src[tid + NTHR * j];
+    for (int j = 0; j < NU4; ++j)
+      if (NU4 * NTHR == U4 || tid + NTHR * j < U4) rw[j] = src[tid + NTHR * j];
+#endif
   };
-  auto store_in = [&](int ch, float* Vs) {
+
+  auto store_chunk = [&](int ch) {
+#ifndef WINO_EXP_NOV
+    if (a.Cin - ch * WCC < WCC) {  // ragged last chunk: channels that do not exist must read as zero (the loads see real data)
+      const int lim = a.Cin - ch * WCC;
+#pragma unroll
+      for (int k = 0; k < NITEM; ++k)
+        if ((tid + k * NTHR) / TPB >= lim) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            rP[k][r] = f32x2{0.f, 0.f};
+            rL[k][r] = 0.f;
+            rR[k][r] = 0.f;
+          }
+        }
+    }
 #pragma unroll
     for (int k = 0; k < NITEM; ++k) {
-      const int cl = wave + k * NWAVE;
-      const bool cok = ch * WCC + cl < a.Cin;
-      float d[16], t[16], v[16];
+      // patch row r = {left halo | own pair P | right halo}; kept as two register pairs E = (left, right), P = (own x, own y) so
+      // that B^T d B is 16 packed adds: rows act element-wise on the pairs, columns are
+      //   (v0, v3) = (e0 - p1, p0 - e1)      (v1, v2) = (p0 + p1, p1 - p0)
+      f32x2 E[4], P[4];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) d[e] = (cok && ((okmask >> e) & 1u)) ? rin[k][e] : 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {  // B^T d  (rows)
-        t[j] = d[j] - d[8 + j];
-        t[4 + j] = d[4 + j] + d[8 + j];
-        t[8 + j] = d[8 + j] - d[4 + j];
-        t[12 + j] = d[4 + j] - d[12 + j];
+      for (int r = 0; r < 4; ++r) {
+        P[r] = rP[k][r];
+        const float own_x = rP[k][r][0], own_y = rP[k][r][1];
+        const float fl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, own_y), 0x138, 0xf, 0xf, false));  // lane-1
+        const float fr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, own_x), 0x130, 0xf, 0xf, false));  // lane+1
+        E[r] = f32x2{ledge[k] ? rL[k][r] : fl, redge[k] ? rR[k][r] : fr};
       }
+      f32x2 UE[4], UP[4];  // B^T d (rows)
+      UE[0] = E[0] - E[2];  UP[0] = P[0] - P[2];
+      UE[1] = E[1] + E[2];  UP[1] = P[1] + P[2];
+      UE[2] = E[2] - E[1];  UP[2] = P[2] - P[1];
+      UE[3] = E[1] - E[3];  UP[3] = P[1] - P[3];
+      if (NITEM * NTHR == NITEMS || vdst[k] >= 0) {
+        float* dst = Vs + vdst[k];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {  // (B^T d) B  (columns)
-        v[4 * i] = t[4 * i] - t[4 * i + 2];
-        v[4 * i + 1] = t[4 * i + 1] + t[4 * i + 2];
-        v[4 * i + 2] = t[4 * i + 2] - t[4 * i + 1];
-        v[4 * i + 3] = t[4 * i + 1] - t[4 * i + 3];
+        for (int i = 0; i < 4; ++i) {  // (B^T d) B (columns); component slots of row i: [v0, v3 | v1, v2]
+          const f32x2 ps = __builtin_shufflevector(UP[i], UP[i], 1, 0);  // (p1, p0)
+          const f32x2 v03 = f32x2{UE[i][0], -UE[i][1]} + f32x2{-ps[0], ps[1]};
+          const f32x2 v12 = UP[i] + f32x2{ps[0], -ps[1]};
+#ifndef WINO_EXP_NOLDSW
+          *reinterpret_cast<f32x2*>(dst + (2 * i) * 256) = v03;
+          *reinterpret_cast<f32x2*>(dst + (2 * i + 1) * 256) = v12;
+#else
+          if (a.N < 0) { *reinterpret_cast<f32x2*>(dst + (2 * i) * 256) = v03; *reinterpret_cast<f32x2*>(dst + (2 * i + 1) * 256) = v12; }
+#endif
+        }
       }
-      float* dst = Vs + (((lane >> 4) * 64 + (cl >> 1) * 16 + (lane & 15)) * 2 + (cl & 1));
-#pragma unroll
-      for (int c = 0; c < 16; ++c) dst[c * (WT * 128)] = v[c];
     }
-  };
-  auto store_u = [&](float* Us) {
+#endif
+#ifndef WINO_EXP_NOU
     f32x4* dstw = reinterpret_cast<f32x4*>(Us);
 #pragma unroll
-    for (int j = 0; j < NU4; ++j) dstw[tid + NTHR * j] = rw[j];
+    for (int j = 0; j < NU4; ++j)
+      if (NU4 * NTHR == U4 || tid + NTHR * j < U4) dstw[tid + NTHR * j] = rw[j];
+#endif
   };
-  auto compute_part = [&](const float* Vs, const float* Us, auto part_) {
-    constexpr int PART = decltype(part_)::value;
-    const float* va = Vs + wt * 128 + lane * 2;
-    const float* ub = Us + (wc * NIW) * 2048 + lane * 2;
+
+  auto compute_chunk = [&]() {
+    const float* va = Vs + wt * 2048 + lane * 4;
+    const float* ub = Us + (wc * NIW) * 2048 + lane * 4;
 #pragma unroll
-    for (int c = PART * 4; c < PART * 4 + 4; ++c) {
-      const float2 av = *reinterpret_cast<const float2*>(va + c * (WT * 128));
-      float2 bv[NIW];
+    for (int cp = 0; cp < 8; ++cp) {
+      const f32x4 av = *reinterpret_cast<const f32x4*>(va + cp * 256);  // {c0 k0, c1 k0, c0 k1, c1 k1}
+      f32x4 bv[NIW];
 #pragma unroll
-      for (int ni = 0; ni < NIW; ++ni) bv[ni] = *reinterpret_cast<const float2*>(ub + (ni * 16 + c) * 128);
+      for (int ni = 0; ni < NIW; ++ni) bv[ni] = *reinterpret_cast<const f32x4*>(ub + ni * 2048 + cp * 256);
 #pragma unroll
-      for (int ni = 0; ni < NIW; ++ni) acc[c][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv[ni].x, acc[c][ni], 0, 0, 0);
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int ni = 0; ni < NIW; ++ni) acc[c][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv[ni].y, acc[c][ni], 0, 0, 0);
+        for (int par = 0; par < 2; ++par)
+#pragma unroll
+          for (int ni = 0; ni < NIW; ++ni)
+            acc[2 * cp + par][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[ni][ks * 2 + par], av[ks * 2 + par], acc[2 * cp + par][ni], 0, 0, 0);
     }
   };
 
-  // ---------------------------------------------------------------- epilogue: A^T M A, then the fused point-wise tail
-  auto epilogue = [&](int eblk) {
-  const int bx = eblk % a.blocks_x;
-  const int et2 = eblk / a.blocks_x;
-  const int by = et2 % a.blocks_y;
-  const int bn = et2 / a.blocks_y;
-  const bool lrelu = (a.flags & MG_CONV_LRELU) != 0;
-  const bool mask_aux = (a.flags & MG_CONV_MASK_AUX) != 0;
-  const bool pixnorm = (a.flags & MG_CONV_PIXNORM) != 0;
-  const bool pool = (a.flags & MG_CONV_POOL_OUT) != 0;
-
-  float o[NIW][4][4];  // [ni][g = tile 4*rq+g of the wave][2*i + j = pixel (i, j) of the tile]
-#pragma unroll
-  for (int ni = 0; ni < NIW; ++ni) {
-    const int oc = (ct0 + wc * NIW + ni) * 16 + col;
-    const float bvv = (a.bias != nullptr && oc < a.Cout) ? a.bias[oc] : 0.f;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float s0[4], s1[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float m0 = acc[j][ni][g], m1 = acc[4 + j][ni][g], m2 = acc[8 + j][ni][g], m3 = acc[12 + j][ni][g];
-        s0[j] = (m0 + m1) + m2;
-        s1[j] = (m1 - m2) - m3;
-      }
-      float r4[4];
-      r4[0] = (s0[0] + s0[1]) + s0[2];
-      r4[1] = (s0[1] - s0[2]) - s0[3];
-      r4[2] = (s1[0] + s1[1]) + s1[2];
-      r4[3] = (s1[1] - s1[2]) - s1[3];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float v = r4[q] + bvv;
-        if (lrelu) v = mg_lrelu(v, a.slope);
-        o[ni][g][q] = v;
-      }
-    }
+  load_chunk(0);
+  for (int ch = 0; ch < a.nchunk; ++ch) {
+    __syncthreads();  // previous chunk's operand reads done
+    store_chunk(ch);
+    __syncthreads();
+    load_chunk(ch + 1 < a.nchunk ? ch + 1 : ch);  // in flight during the MFMA phase below (the last one is a harmless repeat)
+#ifndef WINO_EXP_NOMFMA
+    compute_chunk();
+#endif
   }
 
-  float rnv[4][4];
-  if (pixnorm) {
+  // ---------------------------------------------------------------- epilogue: A^T M A, then the fused point-wise tail
+  const float slope_eff = (a.flags & MG_CONV_LRELU) ? a.slope : 1.0f;  // branch-free LeakyReLU switch
+  const int tl = wt * 16 + col;
+  const int txl = tl & (a.TBW - 1);
+  const int tyl = (tl >> a.lgTBW) & (a.TBH - 1);
+  const int nl = tl >> (a.lgTBW + a.lgTBH);
+  const int n = n0 + nl, TY = by * a.TBH + tyl, TX = bx * a.TBW + txl;
+  const bool tok = (n < a.N) && (TY < Ht) && (TX < Wt);
+  const int oc0 = (ct0 + wc * NIW) * 16 + rq * 4;  // out-channel of (ni, g) = oc0 + ni*16 + g
+  const size_t pix0 = ((size_t)n * a.Cout * a.H + 2 * TY) * a.W + 2 * TX;  // + oc*H*W + i*W
+  const size_t pp0 = ((size_t)n * a.Cout * Ht + TY) * Wt + TX;            // + oc*Ht*Wt   (pooled tensor)
+
+  // A^T M A + bias + LeakyReLU of out-channel tile ni -> on[g][2*i + j: pixel (i, j) of the lane's 2x2 tile].  The accumulator
+  // of Winograd component (xi, nu) is acc[4*xi + slot(nu)] with slots [nu0, nu3, nu1, nu2] (see store_chunk); all math runs on
+  // the f32x4 accumulators (g = 4 out-channels) so it packs.
+  auto transform = [&](int ni, float (&on)[4][4]) {
+    f32x4 bv4;
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < 4; ++g) {
+      const int oc = oc0 + ni * 16 + g;
+      bv4[g] = (a.bias != nullptr && oc < a.Cout) ? a.bias[oc] : 0.f;
+    }
+    constexpr int SL[4] = {0, 2, 3, 1};  // slot of column nu
+    f32x4 s0[4], s1[4];
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+      const f32x4 m0 = acc[SL[nu]][ni], m1 = acc[4 + SL[nu]][ni], m2 = acc[8 + SL[nu]][ni], m3 = acc[12 + SL[nu]][ni];
+      s0[nu] = (m0 + m1) + m2;
+      s1[nu] = (m1 - m2) - m3;
+    }
+    f32x4 r4[4];
+    r4[0] = (s0[0] + s0[1]) + s0[2];
+    r4[1] = (s0[1] - s0[2]) - s0[3];
+    r4[2] = (s1[0] + s1[1]) + s1[2];
+    r4[3] = (s1[1] - s1[2]) - s1[3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = r4[q] + bv4;
+      const f32x4 w = v * slope_eff;  // 0 < slope <= 1: leaky_relu(v) == max(v, slope*v)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) on[g][q] = fmaxf(v[g], w[g]);
+    }
+  };
+  // one specialised copy of the store loop per epilogue kind, selected once (no flag tests inside the unrolled loops).
+  // Stores are issue-bound per instruction, so lane pairs (tiles 2k, 2k+1 of a row) first trade half of their 2x2 outputs
+  // through DPP: the even lane ends up with image row 2TY of both tiles, the odd lane with row 2TY+1 -- 16 contiguous bytes
+  // per lane, 128 per 8 lanes -- and each (tile, out-channel) costs one dwordx4 store (and mask load) instead of two dwordx2.
+  const bool odd = (lane & 1) != 0;
+  const bool wide = (a.TBW >= 2) && ((Wt & 1) == 0);  // tile pairs exist and share validity
+  auto swap1 = [&](float x) {  // value of lane ^ 1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));
+  };
+  const size_t pixw = odd ? pix0 - 2 + a.W : pix0;  // even: row 2TY of the pair; odd: row 2TY+1 of the pair
+  auto store_tile = [&](int ni, float (&on)[4][4], const float (&rnv)[4], auto mask_, auto pn_, auto pool_, auto hasy_) {
+    constexpr bool MASK = decltype(mask_)::value, PN = decltype(pn_)::value, POOL = decltype(pool_)::value,
+                   HASY = decltype(hasy_)::value;
+    if (wide) {
+      f32x4 rnw = f32x4{1.f, 1.f, 1.f, 1.f};
+      if constexpr (PN) {
+        const float r0 = swap1(odd ? rnv[0] : rnv[2]), r1 = swap1(odd ? rnv[1] : rnv[3]);
+        rnw = odd ? f32x4{r0, r1, rnv[2], rnv[3]} : f32x4{rnv[0], rnv[1], r0, r1};
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int oc = oc0 + ni * 16 + g;
+#ifdef WINO_EXP_NOSTORE
+        const bool act = tok && oc < a.Cout && a.N < 0;
+#else
+        const bool act = tok && oc < a.Cout;
+#endif
+        const float r0 = swap1(odd ? on[g][0] : on[g][2]), r1 = swap1(odd ? on[g][1] : on[g][3]);
+        f32x4 v = odd ? f32x4{r0, r1, on[g][2], on[g][3]} : f32x4{on[g][0], on[g][1], r0, r1};
+        const size_t idx = pixw + (size_t)oc * HW;
+        if constexpr (MASK) {
+          f32x4 ax = f32x4{1.f, 1.f, 1.f, 1.f};
+          if (act) ax = *reinterpret_cast<const f32x4*>(a.aux + idx);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= mg_lrelu_mask(ax[e], a.slope);
+        }
+        float pooled = 0.f;
+        if constexpr (POOL) {  // the pair's two pooled pixels: each lane holds one image row of both
+          const float pe = v[0] + v[1], po = v[2] + v[3];
+          pooled = ((odd ? po : pe) + swap1(odd ? pe : po)) * 0.25f;
+        }
+        if (act) {
+          if constexpr (HASY) *reinterpret_cast<f32x4*>(a.y + idx) = v;
+          if constexpr (PN) *reinterpret_cast<f32x4*>(a.p + idx) = v * rnw;
+          if constexpr (POOL) a.p[pp0 + (size_t)oc * (Ht * Wt)] = pooled;
+        }
+      }
+      return;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int oc = oc0 + ni * 16 + g;
+      if (tok && oc < a.Cout) {
+        const size_t idx0 = pix0 + (size_t)oc * HW;
+        float2 v0 = make_float2(on[g][0], on[g][1]), v1 = make_float2(on[g][2], on[g][3]);
+        if constexpr (MASK) {
+          const float2 a0 = *reinterpret_cast<const float2*>(a.aux + idx0);
+          const float2 a1 = *reinterpret_cast<const float2*>(a.aux + idx0 + a.W);
+          v0.x *= mg_lrelu_mask(a0.x, a.slope);
+          v0.y *= mg_lrelu_mask(a0.y, a.slope);
+          v1.x *= mg_lrelu_mask(a1.x, a.slope);
+          v1.y *= mg_lrelu_mask(a1.y, a.slope);
+        }
+        if constexpr (HASY) {
+          *reinterpret_cast<float2*>(a.y + idx0) = v0;
+          *reinterpret_cast<float2*>(a.y + idx0 + a.W) = v1;
+        }
+        if constexpr (PN) {
+          *reinterpret_cast<float2*>(a.p + idx0) = make_float2(v0.x * rnv[0], v0.y * rnv[1]);
+          *reinterpret_cast<float2*>(a.p + idx0 + a.W) = make_float2(v1.x * rnv[2], v1.y * rnv[3]);
+        }
+        if constexpr (POOL) a.p[pp0 + (size_t)oc * (Ht * Wt)] = ((v0.x + v0.y) + (v1.x + v1.y)) * 0.25f;
+      }
+    }
+  };
+  // no PixelNorm: one out-channel tile at a time (16 live outputs)
+  auto tail = [&](auto mask_, auto pool_) {
+    const float one[4] = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+    for (int ni = 0; ni < NIW; ++ni) {
+      float on[4][4];
+      transform(ni, on);
+      store_tile(ni, on, one, mask_, std::false_type{}, pool_, std::true_type{});
+    }
+  };
+  // PixelNorm: all channels of the pixel first (sum of squares over ni, g in-lane, rq by shuffles, wave groups via LDS)
+  auto tail_pn = [&](auto hasy_) {
+    float o[NIW][4][4];
+#pragma unroll
+    for (int ni = 0; ni < NIW; ++ni) transform(ni, o[ni]);
+    float rnv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // padded out-channels hold exact zeros (zero filters, no bias) and add nothing
+      float t = 0.f;
+#pragma unroll
+      for (int ni = 0; ni < NIW; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) t += o[ni][g][q] * o[ni][g][q];
+      t += __shfl_xor(t, 16);
+      t += __shfl_xor(t, 32);
+      rnv[q] = t;
+      if (WC > 1 && rq == 0) red[(wc * TPB + tl) * 4 + q] = t;
+    }
+    if (WC > 1) {
+      __syncthreads();
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float t = 0.f;
 #pragma unroll
-        for (int ni = 0; ni < NIW; ++ni) t += o[ni][g][q] * o[ni][g][q];
-        t += __shfl_xor(t, 1);
-        t += __shfl_xor(t, 2);
-        t += __shfl_xor(t, 4);
-        t += __shfl_xor(t, 8);
-        rnv[g][q] = t;
-        if (WC > 1 && col == 0) red[((wc * 64 + wt * 16 + rq * 4 + g) * 4) + q] = t;
+        for (int w2 = 0; w2 < WC; ++w2) t += red[(w2 * TPB + tl) * 4 + q];
+        rnv[q] = t;
       }
-    if (WC > 1) {
-      __syncthreads();
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float t = 0.f;
-#pragma unroll
-          for (int w2 = 0; w2 < WC; ++w2) t += red[((w2 * 64 + wt * 16 + rq * 4 + g) * 4) + q];
-          rnv[g][q] = t;
-        }
     }
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int q = 0; q < 4; ++q) rnv[q] = 1.0f / sqrtf(rnv[q] / (float)a.Cout + PN_EPS);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) rnv[g][q] = 1.0f / sqrtf(rnv[g][q] / (float)a.Cout + PN_EPS);
+    for (int ni = 0; ni < NIW; ++ni) store_tile(ni, o[ni], rnv, std::false_type{}, std::true_type{}, std::false_type{}, hasy_);
+    if (tok && rq == 0 && wc == 0 && a.rn != nullptr && blockIdx.y == 0) {
+      const size_t r0 = ((size_t)n * a.H + 2 * TY) * a.W + 2 * TX;
+      *reinterpret_cast<float2*>(a.rn + r0) = make_float2(rnv[0], rnv[1]);
+      *reinterpret_cast<float2*>(a.rn + r0 + a.W) = make_float2(rnv[2], rnv[3]);
+    }
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+#ifdef WINO_EXP_NOEPI
+  if (a.N < 0) {  // keeps the accumulators alive
+    f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+#pragma unroll
+      for (int ni = 0; ni < NIW; ++ni) t += acc[c][ni];
+    a.y[tid] = (t[0] + t[1]) + (t[2] + t[3]);
   }
-
-  const int Hp = Ht, Wp = Wt;
-  const bool vec = (a.TBW >= 4) && ((a.W & 7) == 0);
-  if (vec) {
-    // the lane's 4 tiles are consecutive in x: 8 output pixels per row = two 16-byte stores
-    const int tl = wt * 16 + rq * 4;
-    const int txl = tl & (a.TBW - 1);
-    const int tyl = (tl >> a.lgTBW) & (a.TBH - 1);
-    const int nl = tl >> (a.lgTBW + a.lgTBH);
-    const int n = bn * a.TBN + nl, TY = by * a.TBH + tyl, TX = bx * a.TBW + txl;
-    if ((n < a.N) && (TY < Ht) && (TX < Wt)) {
-#pragma unroll
-      for (int ni = 0; ni < NIW; ++ni) {
-        const int oc = (ct0 + wc * NIW + ni) * 16 + col;
-        if (oc < a.Cout) {
-          const size_t plane = ((size_t)n * a.Cout + oc);
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const size_t idx = (plane * a.H + 2 * TY + i) * a.W + 2 * TX;
-            f32x4 v0 = f32x4{o[ni][0][2 * i], o[ni][0][2 * i + 1], o[ni][1][2 * i], o[ni][1][2 * i + 1]};
-            f32x4 v1 = f32x4{o[ni][2][2 * i], o[ni][2][2 * i + 1], o[ni][3][2 * i], o[ni][3][2 * i + 1]};
-            if (mask_aux) {
-              const f32x4 a0 = *reinterpret_cast<const f32x4*>(a.aux + idx);
-              const f32x4 a1 = *reinterpret_cast<const f32x4*>(a.aux + idx + 4);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                v0[e] *= mg_lrelu_mask(a0[e], a.slope);
-                v1[e] *= mg_lrelu_mask(a1[e], a.slope);
-              }
-              o[ni][0][2 * i] = v0[0]; o[ni][0][2 * i + 1] = v0[1]; o[ni][1][2 * i] = v0[2]; o[ni][1][2 * i + 1] = v0[3];
-              o[ni][2][2 * i] = v1[0]; o[ni][2][2 * i + 1] = v1[1]; o[ni][3][2 * i] = v1[2]; o[ni][3][2 * i + 1] = v1[3];
-            }
-            if (a.y != nullptr) {
-              *reinterpret_cast<f32x4*>(a.y + idx) = v0;
-              *reinterpret_cast<f32x4*>(a.y + idx + 4) = v1;
-            }
-            if (pixnorm) {
-              const f32x4 r0 = f32x4{rnv[0][2 * i], rnv[0][2 * i + 1], rnv[1][2 * i], rnv[1][2 * i + 1]};
-              const f32x4 r1 = f32x4{rnv[2][2 * i], rnv[2][2 * i + 1], rnv[3][2 * i], rnv[3][2 * i + 1]};
-              *reinterpret_cast<f32x4*>(a.p + idx) = v0 * r0;
-              *reinterpret_cast<f32x4*>(a.p + idx + 4) = v1 * r1;
-            }
-          }
-          if (pool) {
-            f32x4 pv;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) pv[g] = ((o[ni][g][0] + o[ni][g][1]) + (o[ni][g][2] + o[ni][g][3])) * 0.25f;
-            *reinterpret_cast<f32x4*>(a.p + (plane * Hp + TY) * Wp + TX) = pv;
-          }
-        }
-      }
-      if (pixnorm && col == 0 && wc == 0 && a.rn != nullptr && blockIdx.y == 0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const size_t idx = ((size_t)n * a.H + 2 * TY + i) * a.W + 2 * TX;
-          *reinterpret_cast<f32x4*>(a.rn + idx) = f32x4{rnv[0][2 * i], rnv[0][2 * i + 1], rnv[1][2 * i], rnv[1][2 * i + 1]};
-          *reinterpret_cast<f32x4*>(a.rn + idx + 4) = f32x4{rnv[2][2 * i], rnv[2][2 * i + 1], rnv[3][2 * i], rnv[3][2 * i + 1]};
-        }
-      }
-    }
+  return;
+#endif
+  if (a.flags & MG_CONV_PIXNORM) {
+    if (a.y != nullptr) tail_pn(T_{});
+    else tail_pn(F_{});
+  } else if (a.flags & MG_CONV_MASK_AUX) {
+    if (a.flags & MG_CONV_POOL_OUT) tail(T_{}, T_{});
+    else tail(T_{}, F_{});
   } else {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int tl = wt * 16 + rq * 4 + g;
-      const int txl = tl & (a.TBW - 1);
-      const int tyl = (tl >> a.lgTBW) & (a.TBH - 1);
-      const int nl = tl >> (a.lgTBW + a.lgTBH);
-      const int n = bn * a.TBN + nl, TY = by * a.TBH + tyl, TX = bx * a.TBW + txl;
-      if ((n < a.N) && (TY < Ht) && (TX < Wt)) {
-#pragma unroll
-        for (int ni = 0; ni < NIW; ++ni) {
-          const int oc = (ct0 + wc * NIW + ni) * 16 + col;
-          if (oc < a.Cout) {
-            const size_t plane = ((size_t)n * a.Cout + oc);
-            float ps = 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const size_t idx = (plane * a.H + 2 * TY + (q >> 1)) * a.W + 2 * TX + (q & 1);
-              float v = o[ni][g][q];
-              if (mask_aux) v *= mg_lrelu_mask(a.aux[idx], a.slope);
-              ps += v;
-              if (a.y != nullptr) a.y[idx] = v;
-              if (pixnorm) a.p[idx] = v * rnv[g][q];
-            }
-            if (pool) a.p[(plane * Hp + TY) * Wp + TX] = ps * 0.25f;
-          }
-        }
-        if (pixnorm && col == 0 && wc == 0 && a.rn != nullptr && blockIdx.y == 0) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) a.rn[((size_t)n * a.H + 2 * TY + (q >> 1)) * a.W + 2 * TX + (q & 1)] = rnv[g][q];
-        }
-      }
-    }
-  }
-  };
-
-  if (Q <= 0) return;
-  // Pipeline over steps q = (block, chunk): in iteration q the MFMAs of step q run from LDS stage q&1 while step q+1 goes
-  // registers -> LDS stage (q+1)&1 and the global loads of step q+2 are issued.  Everything inside the iteration is
-  // branch-free (steps past the end re-load valid data and write a stage nobody reads) so that the staging instructions
-  // interleave with the matrix instructions; the geometry of a new block is computed in the tail of the iteration before.
-  const int gstride = (int)gridDim.x;
-  auto advance = [&](int& b, int& c) {
-    if (++c == a.nchunk) { c = 0; b += gstride; }
-  };
-  int blk = first, ch = 0;  // step q
-  int blk1 = blk, ch1 = ch;
-  advance(blk1, ch1);       // step q+1
-  int blk2 = blk1, ch2 = ch1;
-  advance(blk2, ch2);       // step q+2
-  unsigned okmask_st;
-  {
-    geometry(first);
-    load_in(0);
-    load_u(0);
-    store_in(0, smem);
-    store_u(smem + V_FLOATS);
-    const bool has1 = Q > 1;
-    if (has1 && ch1 == 0) geometry(blk1);
-    load_in(has1 ? ch1 : 0);
-    load_u(has1 ? ch1 : 0);
-    okmask_st = okmask;
-    if (Q > 2 && ch2 == 0) geometry(blk2);
-  }
-  __syncthreads();
-
-  for (int q = 0; q < Q; ++q) {
-    float* cur = smem + (q & 1) * STAGE;
-    float* nxt = smem + ((q + 1) & 1) * STAGE;
-    const int lch2 = (q + 2 < Q) ? ch2 : 0;  // past the end: any valid chunk of the current geometry
-
-#ifndef WINO_EXP_NOMFMA
-    compute_part(cur, cur + V_FLOATS, std::integral_constant<int, 0>{});
-#endif
-#ifndef WINO_EXP_NOSTAGE
-    {
-      const unsigned keep = okmask;
-      okmask = okmask_st;
-      store_in(ch1, nxt);
-      okmask = keep;
-    }
-    load_in(lch2);  // re-uses the registers just drained: almost a full iteration of latency cover
-    okmask_st = okmask;
-#endif
-#ifndef WINO_EXP_NOMFMA
-    compute_part(cur, cur + V_FLOATS, std::integral_constant<int, 1>{});
-#endif
-#ifndef WINO_EXP_NOSTAGE
-    store_u(nxt + V_FLOATS);
-    load_u(lch2);
-#endif
-#ifndef WINO_EXP_NOMFMA
-    compute_part(cur, cur + V_FLOATS, std::integral_constant<int, 2>{});
-    compute_part(cur, cur + V_FLOATS, std::integral_constant<int, 3>{});
-#endif
-
-    if (ch + 1 == a.nchunk) {
-#ifndef WINO_EXP_NOEPI
-      epilogue(blk);
-#else
-      if (a.N < 0) {  // keeps the accumulators alive
-        f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < 16; ++c)
-#pragma unroll
-          for (int ni = 0; ni < NIW; ++ni) t += acc[c][ni];
-        a.y[tid] = (t[0] + t[1]) + (t[2] + t[3]);
-      }
-#endif
-#pragma unroll
-      for (int c = 0; c < 16; ++c)
-#pragma unroll
-        for (int ni = 0; ni < NIW; ++ni) acc[c][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    blk = blk1; ch = ch1;
-    blk1 = blk2; ch1 = ch2;
-    advance(blk2, ch2);
-    if (ch2 == 0 && q + 3 < Q) geometry(blk2);  // step q+3 opens a new block: its loads are issued in the next iteration
-#ifndef WINO_EXP_NOBARRIER
-    __syncthreads();
-#endif
+    if (a.flags & MG_CONV_POOL_OUT) tail(F_{}, T_{});
+    else tail(F_{}, F_{});
   }
 }
 
 // U = G g G^T for every (out, in) channel pair, written in MFMA operand order:
-//   up[((ch*NT + ct)*16 + comp)*128 + lane*2 + ks]  with  in-channel = ch*8 + 2*(lane>>4) + ks,  out-channel = ct*16 + (lane&15)
+//   up[(((ch*NT + ct)*8 + slot/2)*64 + lane)*4 + ks*2 + slot%2],   slot = 4*xi + {0, 2, 3, 1}[nu]  (pairs (nu0,nu3), (nu1,nu2):
+// the order in which the packed input transform produces them)
+// with  in-channel = ch*8 + 2*(lane>>4) + ks,  out-channel = ct*16 + (lane&15)
 __global__ void wino3x3_pack_kernel(const float* __restrict__ w, float* __restrict__ up, int Co, int Ci, int dgrad,
                                     int cin_call, int cout_call, int NT, size_t total) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -456,27 +465,25 @@ __global__ void wino3x3_pack_kernel(const float* __restrict__ w, float* __restri
     h[6 + j] = 0.5f * ((g0 - g1) + g2);
     h[9 + j] = g2;
   }
-  float* dst = up + (((size_t)ch * NT + ct) * 16) * 128 + lane * 2 + ks;
+  float* dst = up + (((size_t)ch * NT + ct) * 8) * 256 + lane * 4 + ks * 2;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {  // (G g) G^T : 4x4
+  for (int i = 0; i < 4; ++i) {  // (G g) G^T : row xi = i, columns nu0..nu3 -> pairs (nu0, nu3), (nu1, nu2)
     const float h0 = h[3 * i], h1 = h[3 * i + 1], h2 = h[3 * i + 2];
-    dst[(size_t)(4 * i + 0) * 128] = h0;
-    dst[(size_t)(4 * i + 1) * 128] = 0.5f * ((h0 + h1) + h2);
-    dst[(size_t)(4 * i + 2) * 128] = 0.5f * ((h0 - h1) + h2);
-    dst[(size_t)(4 * i + 3) * 128] = h2;
+    *reinterpret_cast<float2*>(dst + (size_t)(2 * i) * 256) = make_float2(h0, h2);
+    *reinterpret_cast<float2*>(dst + (size_t)(2 * i + 1) * 256) = make_float2(0.5f * ((h0 + h1) + h2), 0.5f * ((h0 - h1) + h2));
   }
 }
 
 template <int NIW, int WC>
 int launch_wino(const WinoArgs& a, dim3 grid, hipStream_t s) {
-  constexpr size_t lds = (size_t)(2 * (16 * WT * 128 + WC * NIW * 2048) + WC * 256) * sizeof(float);
+  constexpr size_t lds = (size_t)(16 * TPB * WCC + WC * NIW * 2048 + WC * TPB * 4) * sizeof(float);
   static bool attr_set = false;  // benign race: idempotent
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino3x3_mfma<NIW, WC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((wino3x3_mfma<NIW, WC>), grid, dim3(256 * WC), lds, s, a);
+  hipLaunchKernelGGL((wino3x3_mfma<NIW, WC>), grid, dim3(64 * WT * WC), lds, s, a);
   MG_CHECK_LAUNCH("mg_wino3x3");
   return MG_OK;
 }
@@ -529,13 +536,14 @@ extern "C" int mg_wino3x3(const float* x, const float* up, const float* bias, co
   a.nchunk = mg_cdiv(Cin, WCC);
   a.NT = wino_nt_padded(Cout);
   const int Ht = H / 2, Wt = W / 2;
-  a.TBW = mg_pow2_ceil(Wt) < 8 ? mg_pow2_ceil(Wt) : 8;
-  a.TBH = mg_pow2_ceil(Ht) < 64 / a.TBW ? mg_pow2_ceil(Ht) : 64 / a.TBW;
-  a.TBN = 64 / (a.TBW * a.TBH);
+  a.TBW = mg_pow2_ceil(Wt) < 16 ? mg_pow2_ceil(Wt) : 16;  // 16 tiles = 32 pixels = one 128-byte line per row and channel
+  a.TBH = mg_pow2_ceil(Ht) < TPB / a.TBW ? mg_pow2_ceil(Ht) : TPB / a.TBW;
+  a.TBN = TPB / (a.TBW * a.TBH);
   a.lgTBW = mg_ilog2(a.TBW); a.lgTBH = mg_ilog2(a.TBH);
   a.blocks_x = mg_cdiv(Wt, a.TBW); a.blocks_y = mg_cdiv(Ht, a.TBH); a.blocks_n = mg_cdiv(N, a.TBN);
+  MG_CHECK_ARG((long long)a.TBN * Cin * H * W < (1ll << 29), "mg_wino3x3: image block too large for 32-bit offsets");
 
-  // out-channel tiling: 4 tiles (2 per wave x 2 wave groups), 3 (3 per wave) or 2 per workgroup -- least padding wins
+  // out-channel tiles per workgroup (wave groups x tiles per wave): 4 = 2x2, 3 = 3x1, 2 = 2x1 -- least padding wins
   int cfg = 4, best = mg_cdiv(nt, 4) * 4;
   if (mg_cdiv(nt, 3) * 3 < best) { cfg = 3; best = mg_cdiv(nt, 3) * 3; }
   if (mg_cdiv(nt, 2) * 2 < best) { cfg = 2; best = mg_cdiv(nt, 2) * 2; }
@@ -548,24 +556,11 @@ extern "C" int mg_wino3x3(const float* x, const float* up, const float* bias, co
     }
   }
   MG_CHECK_ARG(mg_cdiv(nt, cfg) * cfg <= a.NT, "mg_wino3x3: internal tile error");
-  MG_CHECK_ARG((long long)a.TBN * Cin * H * W < (1ll << 29), "mg_wino3x3: image block too large for 32-bit offsets");
-  // persistent workgroups (one per CU: 128 KB of LDS each), each walking the spatial blocks b, b + grid.x, ... so that the
-  // loads of the next block and the stores of the previous one overlap the matrix work of the current one
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    n_cu = v;
-  }
-  const int nblk = a.blocks_x * a.blocks_y * a.blocks_n, gy = mg_cdiv(nt, cfg);
-  int gx = n_cu / gy > 0 ? n_cu / gy : 1;
-  if (gx > nblk) gx = nblk;
-  gx = mg_cdiv(nblk, mg_cdiv(nblk, gx));  // same number of rounds, evenly spread
-  dim3 grid(gx, gy);
+  dim3 grid(a.blocks_x * a.blocks_y * a.blocks_n, mg_cdiv(nt, cfg));
   hipStream_t s = (hipStream_t)stream;
   switch (cfg) {
     case 4: return launch_wino<2, 2>(a, grid, s);
-    case 3: return launch_wino<3, 1>(a, grid, s);
-    default: return launch_wino<2, 1>(a, grid, s);
+    case 3: return launch_wino<1, 3>(a, grid, s);
+    default: return launch_wino<1, 2>(a, grid, s);
   }
 }

@@ -75,9 +75,7 @@ def wino3x3_supported(n: int, cout: int, h: int, w: int, *, ups=False, pixnorm=F
         return False
     if pixnorm and cout > 64:
         return False
-    if os.environ.get("MG_WINO_ANY_COUT", "0") == "0" and cout % 64:
-        return False  # the kernel tiles 64 output channels per workgroup; other widths currently lose to padding
-    return n * h * w >= int(os.environ.get("MG_WINO_MIN_PIXELS", "65536"))  # fewer 2x2 tiles do not fill the chip
+    return n * h * w >= int(os.environ.get("MG_WINO_MIN_PIXELS", "8192"))  # fewer 2x2 tiles do not fill the chip
 
 
 def conv3x3(x, wp, bias, cout: int, *, ups=False, lrelu=False, mask_aux=None, pixnorm=False, want_y=True, out=None,

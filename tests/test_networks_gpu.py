@@ -62,11 +62,10 @@ def grad_atol(k, ref64, ref32):
 
 @pytest.fixture(params=["auto", "wino_everywhere"])
 def conv_mode(request, monkeypatch):
-    """The engine picks Winograd F(2x2,3x3) only for large maps with 64-multiple widths; "wino_everywhere" forces it onto every
-    3x3 convolution it supports (any even size, any width) so the small golden cases exercise it end to end."""
+    """The engine picks Winograd F(2x2,3x3) only where there are enough 2x2 tiles to fill the chip; "wino_everywhere" forces it
+    onto every 3x3 convolution it supports (any even size) so the small golden cases exercise it end to end."""
     if request.param != "auto":
         monkeypatch.setenv("MG_WINO_MIN_PIXELS", "1")
-        monkeypatch.setenv("MG_WINO_ANY_COUT", "1")
     return request.param
 
 
