@@ -1,0 +1,378 @@
+// Weight gradient of the 3x3 / stride 1 / pad 1 convolution in Winograd F(3x3, 2x2) form on the fp32 matrix cores of gfx950
+// (aten::convolution_backward, weight + bias grads, of nn.Conv2d(3x3) in /root/reference/music_gan/networks/generator.py:9-40 and
+// discriminator.py:8-34).  For every 2x2 tile of the output gradient t and the 4x4 input patch d around it
+//
+//   dW (3x3)  =  G^T [ sum_tiles (A t A^T) .* (B^T d B) ] G        B^T, G: the matrices of wino3x3.hip;  A = (A^T)^T  (4x2)
+//
+// (the transposed F(2x2,3x3) algorithm: same input transform as the forward pass), i.e. 16 multiplies per tile and channel pair
+// instead of 36.  Per Winograd component xi the sum over tiles is a GEMM  M_xi[c, o] = sum_tile V_xi[tile, c] * Y_xi[tile, o]:
+//   M (A rows) = in-channels  (CT tiles of 16),  N (B cols) = out-channels (OT tiles of 16),  K = tiles, 8 per LDS chunk
+//   (two MFMA k-steps: lane k-index rq holds tiles 2rq and 2rq+1 of the chunk)
+// One workgroup of 8 waves owns a (CT*16) x (OT*16) block of ALL 16 components -- wave w accumulates component pair w, 2*CT*OT
+// accumulator tiles -- over a slab of tiles (split-K over workgroups); both operands are transformed on the way from HBM to LDS
+// (x: coalesced 8-byte row loads + DPP halo exchange + packed adds exactly as in wino3x3.hip; gy: two 8-byte loads), the LDS
+// stages are double-buffered with one barrier per chunk, and a second kernel sums the slabs in a fixed order and applies G^T . G
+// (bitwise deterministic, no float atomics).  The bias gradient rides along in the gy staging threads.
+#include <cstdlib>
+
+#include "mg_common.h"
+
+namespace {
+
+constexpr int KT = 8;                  // tiles per chunk
+constexpr int CH = 64;                 // channel slots per operand image (CT, OT <= 4)
+constexpr int IMG = 8 * 4 * CH * 4;    // floats per operand image: [8 comp pairs][4 tile pairs][64 channels][k-step 2][parity 2]
+constexpr int STAGE = 2 * IMG;         // V image + Y image
+
+struct WwArgs {
+  const float* x;
+  const float* gy;
+  float* slab;    // [nsplit][16 slots][CinP][CoutP]
+  float* slab_b;  // [nsplit][CoutP]
+  int N, Cin, Cout, H, W;
+  int TBW, TBH, TBN, lgTBW, lgTBH;  // chunk geometry in TILES: TBW * TBH * TBN == 8
+  int blocks_x, blocks_y, blocks_n, nblk, per;
+  int CinP, CoutP;
+  int nob;  // out-channel blocks (blockIdx.y = cb * nob + ob)
+  int bias_n;
+  unsigned x_bytes, gy_bytes;
+};
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int CT, int OT>
+__global__ void __launch_bounds__(512) wino_wgrad_mfma(const WwArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = component pair
+  const int col = lane & 15, rq = lane >> 4;
+  const int cb = blockIdx.y / a.nob, ob = blockIdx.y % a.nob;
+  const int c0 = cb * CT * 16, o0 = ob * OT * 16;
+  const int split = blockIdx.x;
+  const int HW = a.H * a.W;
+  const int Ht = a.H >> 1, Wt = a.W >> 1;
+
+  // staging item of this thread: tile t of the chunk, channel slot chs: x channel c0 + chs and gy channel o0 + chs
+  const int t = tid & 7, chs = tid >> 3;
+  const int txl = t & (a.TBW - 1);
+  const int tyl = (t >> a.lgTBW) & (a.TBH - 1);
+  const int nl = t >> (a.lgTBW + a.lgTBH);
+  const bool xch = (chs < CT * 16) && (c0 + chs < a.Cin);
+  const bool ych = (chs < OT * 16) && (o0 + chs < a.Cout);
+  const bool ledge = txl == 0, redge = txl == a.TBW - 1;
+  const int xlane = (nl * a.Cin + c0 + chs) * HW + (2 * tyl - 1) * a.W + 2 * txl;   // element offset of patch row 0, own pair
+  const int ylane = (nl * a.Cout + o0 + chs) * HW + (2 * tyl) * a.W + 2 * txl;
+  // LDS float offset of the item's first component pair: [cp][tile pair t>>1][swizzled channel][k-step t&1][parity]
+  const int ldst = ((t >> 1) * CH + (chs ^ ((t >> 1) << 1))) * 4 + (t & 1) * 2;
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gy), 0, (int)a.gy_bytes, 0x00020000);
+
+  f32x4 acc[2][CT][OT];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+      for (int j = 0; j < OT; ++j) acc[p][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  f32x2 rP[4], rG[2];
+  float rL[4], rR[4];
+  float bsum = 0.f;
+  bool bnext = false;  // whether the gy tile in flight counts for the bias gradient
+
+  // chunk `blk` (8 tiles): global loads into registers; tiles / rows / columns outside the image get an out-of-range offset and
+  // read back as 0.0
+  auto load_chunk = [&](int blk) {
+    const int bx = blk % a.blocks_x;
+    const int t2 = blk / a.blocks_x;
+    const int by = t2 % a.blocks_y;
+    const int bn = t2 / a.blocks_y;
+    const int n = bn * a.TBN + nl, TY = by * a.TBH + tyl, TX = bx * a.TBW + txl;
+    const bool ok = (blk < a.nblk) && (n < a.N) && (TY < Ht) && (TX < Wt);
+    const int ux = (bn * a.TBN * a.Cin) * HW + (2 * by * a.TBH) * a.W + 2 * bx * a.TBW;
+    const int uy = (bn * a.TBN * a.Cout) * HW + (2 * by * a.TBH) * a.W + 2 * bx * a.TBW;
+    const unsigned xo = (unsigned)(xlane + ux) * 4u;
+    const bool xok = ok && xch;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool rv = xok && (r == 1 || r == 2 || (r == 0 ? TY > 0 : TY < Ht - 1));
+      const unsigned o = xo + (unsigned)(r * a.W) * 4u;
+      rP[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrs, (int)(rv ? o : 0x80000000u), 0, 0));
+      rL[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)((rv && ledge && TX > 0) ? o - 4u : 0x80000000u), 0, 0));
+      rR[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)((rv && redge && TX < Wt - 1) ? o + 8u : 0x80000000u), 0, 0));
+    }
+    const unsigned yo = (unsigned)(ylane + uy) * 4u;
+    const bool yok = ok && ych;
+    rG[0] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(yrs, (int)(yok ? yo : 0x80000000u), 0, 0));
+    rG[1] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(yrs, (int)(yok ? yo + (unsigned)a.W * 4u : 0x80000000u), 0, 0));
+    bnext = n < a.bias_n;
+  };
+
+  // registers -> transformed operand images of one stage
+  auto store_chunk = [&](float* st) {
+    {  // V = B^T d B, component slots of row i: [v0, v3 | v1, v2]  (see wino3x3.hip)
+      f32x2 E[4], P[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        P[r] = rP[r];
+        const float own_x = rP[r][0], own_y = rP[r][1];
+        const float fl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, own_y), 0x138, 0xf, 0xf, false));  // lane-1
+        const float fr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, own_x), 0x130, 0xf, 0xf, false));  // lane+1
+        E[r] = f32x2{ledge ? rL[r] : fl, redge ? rR[r] : fr};
+      }
+      f32x2 UE[4], UP[4];
+      UE[0] = E[0] - E[2];  UP[0] = P[0] - P[2];
+      UE[1] = E[1] + E[2];  UP[1] = P[1] + P[2];
+      UE[2] = E[2] - E[1];  UP[2] = P[2] - P[1];
+      UE[3] = E[1] - E[3];  UP[3] = P[1] - P[3];
+      float* dst = st + ldst;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x2 ps = __builtin_shufflevector(UP[i], UP[i], 1, 0);
+        const f32x2 v03 = f32x2{UE[i][0], -UE[i][1]} + f32x2{-ps[0], ps[1]};
+        const f32x2 v12 = UP[i] + f32x2{ps[0], -ps[1]};
+        *reinterpret_cast<f32x2*>(dst + (2 * i) * (4 * CH * 4)) = v03;
+        *reinterpret_cast<f32x2*>(dst + (2 * i + 1) * (4 * CH * 4)) = v12;
+      }
+    }
+    {  // Y = A t A^T with A = [[1,0],[1,1],[1,-1],[0,-1]], same slot order: row i -> [y0, y3 | y1, y2]
+      const f32x2 t0 = rG[0], t1 = rG[1];
+      if (bnext) bsum += (t0[0] + t0[1]) + (t1[0] + t1[1]);
+      f32x2 R[4];
+      R[0] = t0;
+      R[1] = t0 + t1;
+      R[2] = t0 - t1;
+      R[3] = -t1;
+      float* dst = st + IMG + ldst;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x2 y03 = f32x2{R[i][0], -R[i][1]};
+        const f32x2 y12 = f32x2{R[i][0] + R[i][1], R[i][0] - R[i][1]};
+        *reinterpret_cast<f32x2*>(dst + (2 * i) * (4 * CH * 4)) = y03;
+        *reinterpret_cast<f32x2*>(dst + (2 * i + 1) * (4 * CH * 4)) = y12;
+      }
+    }
+  };
+
+  auto compute_chunk = [&](const float* st) {
+    const float* vb = st + (wave * 4 + rq) * (CH * 4);
+    const float* yb = vb + IMG;
+    f32x4 av[CT], bv[OT];  // {par0 k0, par1 k0, par0 k1, par1 k1}
+#pragma unroll
+    for (int i = 0; i < CT; ++i) av[i] = *reinterpret_cast<const f32x4*>(vb + ((i * 16 + col) ^ (rq << 1)) * 4);
+#pragma unroll
+    for (int j = 0; j < OT; ++j) bv[j] = *reinterpret_cast<const f32x4*>(yb + ((j * 16 + col) ^ (rq << 1)) * 4);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+          for (int j = 0; j < OT; ++j)
+            acc[p][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][ks * 2 + p], bv[j][ks * 2 + p], acc[p][i][j], 0, 0, 0);
+  };
+
+  // pipeline: iteration q computes chunk q from stage q&1, writes chunk q+1 (registers) into the other stage and issues the
+  // loads of chunk q+2; chunks past the slab (or past the tensor) are all-zero and add nothing
+  const int blk0 = split * a.per;
+  load_chunk(blk0);
+  store_chunk(smem);
+  load_chunk(blk0 + 1 < blk0 + a.per ? blk0 + 1 : a.nblk);
+  __syncthreads();
+  for (int q = 0; q < a.per; ++q) {
+    float* cur = smem + (q & 1) * STAGE;
+    float* nxt = smem + ((q + 1) & 1) * STAGE;
+    store_chunk(nxt);
+    load_chunk(q + 2 < a.per ? blk0 + q + 2 : a.nblk);
+    compute_chunk(cur);
+    __syncthreads();
+  }
+
+  // slab[split][slot = 2*wave + p][c][o]
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    float* sl = a.slab + ((size_t)split * 16 + 2 * wave + p) * a.CinP * a.CoutP;
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+      for (int j = 0; j < OT; ++j) {
+        const int o = o0 + j * 16 + col;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c = c0 + i * 16 + rq * 4 + g;
+          if (c < a.CinP && o < a.CoutP) sl[(size_t)c * a.CoutP + o] = acc[p][i][j][g];
+        }
+      }
+  }
+  // bias gradient: the 8 tile lanes of a channel slot, then one value per (split, out-channel); in-channel block 0 only
+  bsum += __shfl_xor(bsum, 1);
+  bsum += __shfl_xor(bsum, 2);
+  bsum += __shfl_xor(bsum, 4);
+  if (cb == 0 && t == 0 && chs < OT * 16 && o0 + chs < a.CoutP) a.slab_b[(size_t)split * a.CoutP + o0 + chs] = bsum;
+}
+
+// Sum the split-K slabs in a fixed order and apply  dW = G^T M G.  Block = 64 consecutive (c, o) pairs x 4 split-lanes (each lane
+// sums every 4th split), LDS-combined as ((l0 + l1) + (l2 + l3)) => deterministic.  Component slots per row: [nu0, nu3, nu1, nu2].
+__global__ void __launch_bounds__(256) wino_wgrad_reduce(const float* __restrict__ slab, const float* __restrict__ slab_b, int nsplit,
+                                                         float* __restrict__ gw, float* __restrict__ gb, int Cout, int Cin,
+                                                         int CoutP, int CinP, int accumulate) {
+  __shared__ float red[4][16][64];
+  const int el = threadIdx.x & 63, kl = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + el;  // e = c * CoutP + o over the padded block
+  const int total = CinP * CoutP;
+  float m[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) m[s] = 0.f;
+  if (e < total) {
+    for (int k = kl; k < nsplit; k += 4) {
+      const float* src = slab + (size_t)k * 16 * total + e;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) m[s] += src[(size_t)s * total];
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 16; ++s) red[kl][s][el] = m[s];
+  __syncthreads();
+  if (kl != 0 || e >= total) return;
+  const int c = e / CoutP, o = e % CoutP;
+  float M[4][4];  // [xi][nu]
+#pragma unroll
+  for (int xi = 0; xi < 4; ++xi) {
+    constexpr int SL[4] = {0, 2, 3, 1};
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+      const int s = 4 * xi + SL[nu];
+      M[xi][nu] = (red[0][s][el] + red[1][s][el]) + (red[2][s][el] + red[3][s][el]);
+    }
+  }
+  if (c < Cin && o < Cout) {
+    float h[3][4];  // G^T M : 3x4
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+      h[0][nu] = M[0][nu] + 0.5f * (M[1][nu] + M[2][nu]);
+      h[1][nu] = 0.5f * (M[1][nu] - M[2][nu]);
+      h[2][nu] = 0.5f * (M[1][nu] + M[2][nu]) + M[3][nu];
+    }
+    float* dst = gw + ((size_t)o * Cin + c) * 9;
+#pragma unroll
+    for (int aa = 0; aa < 3; ++aa) {
+      const float w0 = h[aa][0] + 0.5f * (h[aa][1] + h[aa][2]);
+      const float w1 = 0.5f * (h[aa][1] - h[aa][2]);
+      const float w2 = 0.5f * (h[aa][1] + h[aa][2]) + h[aa][3];
+      dst[aa * 3 + 0] = accumulate ? dst[aa * 3 + 0] + w0 : w0;
+      dst[aa * 3 + 1] = accumulate ? dst[aa * 3 + 1] + w1 : w1;
+      dst[aa * 3 + 2] = accumulate ? dst[aa * 3 + 2] + w2 : w2;
+    }
+  }
+  if (gb != nullptr && c == 0 && o < Cout) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < nsplit; k += 4) {
+      s0 += slab_b[(size_t)k * CoutP + o];
+      s1 += slab_b[(size_t)(k + 1) * CoutP + o];
+      s2 += slab_b[(size_t)(k + 2) * CoutP + o];
+      s3 += slab_b[(size_t)(k + 3) * CoutP + o];
+    }
+    for (; k < nsplit; ++k) s0 += slab_b[(size_t)k * CoutP + o];
+    const float s = (s0 + s1) + (s2 + s3);
+    gb[o] = accumulate ? gb[o] + s : s;
+  }
+}
+
+struct WwPlan {
+  WwArgs a;
+  int CT, OT, ncb, nsplit;
+  size_t ws_floats;
+};
+
+int blocks_of(int tiles) {  // channel tiles -> blocks of <= 4 tiles, balanced
+  return mg_cdiv(tiles, 4);
+}
+
+void plan_ww(int N, int Cin, int Cout, int H, int W, WwPlan& pl) {
+  WwArgs& a = pl.a;
+  a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+  const int Ht = H / 2, Wt = W / 2;
+  a.TBW = mg_pow2_ceil(Wt) < KT ? mg_pow2_ceil(Wt) : KT;
+  a.TBH = mg_pow2_ceil(Ht) < KT / a.TBW ? mg_pow2_ceil(Ht) : KT / a.TBW;
+  a.TBN = KT / (a.TBW * a.TBH);
+  a.lgTBW = mg_ilog2(a.TBW); a.lgTBH = mg_ilog2(a.TBH);
+  a.blocks_x = mg_cdiv(Wt, a.TBW); a.blocks_y = mg_cdiv(Ht, a.TBH); a.blocks_n = mg_cdiv(N, a.TBN);
+  a.nblk = a.blocks_x * a.blocks_y * a.blocks_n;
+  const int ct = mg_cdiv(Cin, 16), ot = mg_cdiv(Cout, 16);
+  pl.ncb = blocks_of(ct);
+  a.nob = blocks_of(ot);
+  pl.CT = mg_cdiv(ct, pl.ncb) <= 3 ? 3 : 4;
+  pl.OT = mg_cdiv(ot, a.nob) <= 3 ? 3 : 4;
+  a.CinP = ct * 16; a.CoutP = ot * 16;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    n_cu = v;
+  }
+  const int ny = pl.ncb * a.nob;
+  int ns = n_cu / ny > 0 ? n_cu / ny : 1;  // one 8-wave workgroup (128 KB of LDS) per CU
+  if (ns > a.nblk) ns = a.nblk;
+  a.per = mg_cdiv(a.nblk, ns);
+  pl.nsplit = mg_cdiv(a.nblk, a.per);
+  pl.ws_floats = (size_t)pl.nsplit * (16 * (size_t)a.CinP * a.CoutP + a.CoutP);
+}
+
+template <int CT, int OT>
+int launch_ww(const WwArgs& a, dim3 grid, hipStream_t s) {
+  constexpr size_t lds = (size_t)2 * STAGE * sizeof(float);
+  static bool attr_set = false;  // benign race: idempotent
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_wgrad_mfma<CT, OT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((wino_wgrad_mfma<CT, OT>), grid, dim3(512), lds, s, a);
+  MG_CHECK_LAUNCH("mg_wino3x3_wgrad");
+  return MG_OK;
+}
+
+}  // namespace
+
+extern "C" size_t mg_wino3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W) {
+  WwPlan pl;
+  plan_ww(N, Cin, Cout, H, W, pl);
+  return pl.ws_floats * sizeof(float);
+}
+
+extern "C" int mg_wino3x3_wgrad(const float* x, const float* gy, float* gw, float* gb, void* ws, size_t ws_bytes, int N, int Cin,
+                                int Cout, int H, int W, int accumulate, int bias_n, mg_stream_t stream) {
+  MG_CHECK_ARG(x && gy && gw && ws && N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "mg_wino3x3_wgrad: bad arguments");
+  MG_CHECK_ARG((H % 2 == 0) && (W % 2 == 0), "mg_wino3x3_wgrad: H=%d W=%d must be even", H, W);
+  MG_CHECK_ARG((long long)N * Cin * H * W < (1ll << 29) && (long long)N * Cout * H * W < (1ll << 29),
+               "mg_wino3x3_wgrad: tensor too large for 32-bit byte offsets");
+  WwPlan pl;
+  plan_ww(N, Cin, Cout, H, W, pl);
+  if (ws_bytes < pl.ws_floats * sizeof(float)) {
+    mg_set_error("mg_wino3x3_wgrad: workspace %zu < %zu bytes", ws_bytes, pl.ws_floats * sizeof(float));
+    return MG_EWORKSPACE;
+  }
+  WwArgs& a = pl.a;
+  a.x = x; a.gy = gy;
+  a.slab = reinterpret_cast<float*>(ws);
+  a.slab_b = a.slab + (size_t)pl.nsplit * 16 * a.CinP * a.CoutP;
+  a.bias_n = (bias_n <= 0 || bias_n > N) ? N : bias_n;
+  a.x_bytes = (unsigned)((size_t)N * Cin * H * W * 4);
+  a.gy_bytes = (unsigned)((size_t)N * Cout * H * W * 4);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(pl.nsplit, pl.ncb * a.nob);
+  int rc;
+  if (pl.CT == 3 && pl.OT == 3) rc = launch_ww<3, 3>(a, grid, s);
+  else if (pl.CT == 3) rc = launch_ww<3, 4>(a, grid, s);
+  else if (pl.OT == 3) rc = launch_ww<4, 3>(a, grid, s);
+  else rc = launch_ww<4, 4>(a, grid, s);
+  if (rc != MG_OK) return rc;
+  const int total = a.CinP * a.CoutP;
+  hipLaunchKernelGGL(wino_wgrad_reduce, dim3(mg_cdiv(total, 64)), dim3(256), 0, s, a.slab, a.slab_b, pl.nsplit, gw, gb, Cout, Cin,
+                     a.CoutP, a.CinP, accumulate);
+  MG_CHECK_LAUNCH("mg_wino3x3_wgrad(reduce)");
+  return MG_OK;
+}

@@ -175,12 +175,27 @@ def upconv3x3_dgrad(gy, wp, cin: int):
     return gx
 
 
+def wino_wgrad_supported(n: int, cin: int, cout: int, h: int, w: int, *, ups=False) -> bool:
+    """Whether conv3x3_wgrad takes the Winograd F(3x3,2x2) kernel: even sizes, no fused up-sampling, enough 2x2 tiles for its
+    split-K pipeline, byte offsets within 31 bits."""
+    if os.environ.get("MG_WINO_WGRAD", "1") == "0" or ups or (h % 2) or (w % 2):
+        return False
+    if n * max(cin, cout) * h * w >= (1 << 29):
+        return False
+    return n * h * w >= int(os.environ.get("MG_WINO_WGRAD_MIN_PIXELS", "8192"))
+
+
 def conv3x3_wgrad(x, gy, gw, gb, *, ups=False, accumulate=False, bias_n: int = 0):
     """gw[Cout,Cin,3,3] (+)= wgrad(x, gy); gb[Cout] (+)= sum gy over samples n < bias_n (0: all; gb may be None)."""
     _chk(x, gy, gw, gb)
     n, cout, h, w = gy.shape
     cin = x.shape[1]
     lib = _lib.load()
+    if wino_wgrad_supported(n, cin, cout, h, w, ups=ups):
+        ws = workspace(lib.mg_wino3x3_wgrad_ws_bytes(n, cin, cout, h, w), x.device)
+        check(lib.mg_wino3x3_wgrad(_p(x), _p(gy), _p(gw), _p(gb), _p(ws), ws.numel(), n, cin, cout, h, w, int(accumulate),
+                                   int(bias_n), _s()), "mg_wino3x3_wgrad")
+        return
     nbytes = lib.mg_conv3x3_wgrad_ws_bytes(n, cin, cout, h, w)
     ws = workspace(nbytes, x.device)
     check(lib.mg_conv3x3_wgrad(_p(x), _p(gy), _p(gw), _p(gb), _p(ws), ws.numel(), n, cin, cout, h, w,

@@ -63,9 +63,10 @@ def grad_atol(k, ref64, ref32):
 @pytest.fixture(params=["auto", "wino_everywhere"])
 def conv_mode(request, monkeypatch):
     """The engine picks Winograd F(2x2,3x3) only where there are enough 2x2 tiles to fill the chip; "wino_everywhere" forces it
-    onto every 3x3 convolution it supports (any even size) so the small golden cases exercise it end to end."""
+    onto every 3x3 convolution and weight gradient it supports (any even size) so the small golden cases exercise it end to end."""
     if request.param != "auto":
         monkeypatch.setenv("MG_WINO_MIN_PIXELS", "1")
+        monkeypatch.setenv("MG_WINO_WGRAD_MIN_PIXELS", "1")
     return request.param
 
 

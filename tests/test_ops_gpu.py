@@ -406,3 +406,46 @@ def test_wino3x3_refuses_what_it_cannot_do():
         ops.conv3x3(torch.randn(1, 8, 3, 4, device=DEV), None, None, 80, wino=up)
     with pytest.raises(Exception, match="UPS_IN unsupported"):
         ops.conv3x3(x, None, None, 80, ups=True, wino=up)
+
+
+WW_SHAPES = [(2, 8, 8, 2, 2), (3, 32, 128, 4, 4), (4, 128, 112, 8, 8), (2, 96, 80, 32, 32), (2, 64, 48, 64, 64),
+             (1, 48, 64, 128, 128), (5, 144, 160, 2, 2), (3, 16, 32, 16, 16), (2, 24, 40, 12, 20), (7, 20, 17, 2, 12),
+             (2, 80, 80, 16, 8), (9, 64, 64, 8, 8)]
+
+
+@pytest.mark.parametrize("shape", WW_SHAPES)
+def test_wino_wgrad_matches_autograd(shape, monkeypatch):
+    """mg_wino3x3_wgrad (Winograd F(3x3,2x2), split-K + fixed-order reduce) against fp64 autograd: weight and bias gradient,
+    accumulate mode, bias restricted to the first samples (the fused critic step's use), and run-to-run determinism."""
+    ops = _ops()
+    monkeypatch.setenv("MG_WINO_WGRAD_MIN_PIXELS", "1")
+    n, ci, co, h, w = shape
+    assert ops.wino_wgrad_supported(n, ci, co, h, w)
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(n, ci, h, w, generator=g).double()
+    gy = torch.randn(n, co, h, w, generator=g).double()
+    wt = torch.zeros(co, ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    bt = torch.zeros(co, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(x, wt, bt, padding=1) * gy).sum().backward()
+    gw = torch.full((co, ci, 3, 3), 7.0, device=DEV)
+    gb = torch.full((co,), 7.0, device=DEV)
+    xd, gyd = x.float().to(DEV), gy.float().to(DEV)
+    ops.conv3x3_wgrad(xd, gyd, gw, gb)
+    report("wino wgrad gw", gw, wt.grad, 3e-6)
+    report("wino wgrad gb", gb, bt.grad, 3e-6)
+    gw2 = torch.empty_like(gw)
+    ops.conv3x3_wgrad(xd, gyd, gw2, None)
+    assert torch.equal(gw, gw2)  # deterministic, and gb is optional
+    ops.conv3x3_wgrad(xd, gyd, gw, gb, accumulate=True)
+    report("wino wgrad gw acc", gw, 2 * wt.grad, 3e-6)
+    report("wino wgrad gb acc", gb, 2 * bt.grad, 3e-6)
+    if n > 1:
+        nb = n // 2
+        gb3 = torch.empty(co, device=DEV)
+        ops.conv3x3_wgrad(xd, gyd, gw2, gb3, bias_n=nb)
+        report("wino wgrad gb first samples", gb3, gy[:nb].sum(dim=(0, 2, 3)), 3e-6)
+    # agrees with the direct kernel
+    monkeypatch.setenv("MG_WINO_WGRAD", "0")
+    gwd = torch.empty_like(gw2)
+    ops.conv3x3_wgrad(xd, gyd, gwd, None)
+    report("wino vs direct wgrad", gw2, gwd.double(), 3e-6)
