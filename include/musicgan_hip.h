@@ -71,12 +71,12 @@ int mg_wino3x3_pack(const float* w, float* up, int Co, int Ci, int dgrad, mg_str
 int mg_wino3x3(const float* x, const float* up, const float* bias, const float* aux, float* y, float* p, float* rn, int N,
                int Cin, int Cout, int H, int W, int flags, float slope, mg_stream_t stream);
 
-/* Weight (+ bias) gradient of the same convolution in Winograd F(3x3,2x2) form (even H, W; no UPS_IN): same result as
+/* Weight (+ bias) gradient of the same convolution in Winograd F(3x3,2x2) form (even H, W; flags: MG_CONV_UPS_IN): same result as
  * mg_conv3x3_wgrad within fp32 rounding, 2.25x fewer multiplies, split-K slabs reduced in a fixed order (deterministic).
  * gw[Cout][Cin][3][3] (+)= ..., gb[Cout] (+)= sum of gy over samples n < bias_n (0: all; gb may be NULL). */
 size_t mg_wino3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W);
 int mg_wino3x3_wgrad(const float* x, const float* gy, float* gw, float* gb, void* ws, size_t ws_bytes, int N, int Cin, int Cout,
-                     int H, int W, int accumulate, int bias_n, mg_stream_t stream);
+                     int H, int W, int flags, int accumulate, int bias_n, mg_stream_t stream);
 
 /* Data gradient of Upsample(x2) -> Conv3x3 w.r.t. the LOW-resolution input: one stride-2 convolution with the 4x4 effective
  * kernel over gy (N,Cout,2Hin,2Win) -> gx (N,Cin,Hin,Win); replaces conv-dgrad at 2Hx2W + the 2x2 block sums of Upsample's

@@ -42,7 +42,7 @@ SIGNATURES = {
     "mg_wino3x3_pack": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "mg_wino3x3": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "mg_wino3x3_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "mg_wino3x3_wgrad": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "mg_wino3x3_wgrad": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "mg_upconv3x3_dgrad_packed_floats": (c_size_t, [c_int, c_int]),
     "mg_upconv3x3_dgrad_pack": (c_int, [_P, _P, c_int, c_int, _P]),
     "mg_upconv3x3_dgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),

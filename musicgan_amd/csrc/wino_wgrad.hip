@@ -40,7 +40,9 @@ struct WwArgs {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int CT, int OT>
+// UPS: x is (N, Cin, H/2, W/2) and the convolution input is its nearest x2 up-sampling (generator.py:24-25): the 4x4 patch of tile
+// (TY, TX) is then the 3x3 low-res neighbourhood with the centre row / column doubled -- one dword per row and lane.
+template <int CT, int OT, bool UPS>
 __global__ void __launch_bounds__(512) wino_wgrad_mfma(const WwArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -60,7 +62,9 @@ __global__ void __launch_bounds__(512) wino_wgrad_mfma(const WwArgs a) {
   const bool xch = (chs < CT * 16) && (c0 + chs < a.Cin);
   const bool ych = (chs < OT * 16) && (o0 + chs < a.Cout);
   const bool ledge = txl == 0, redge = txl == a.TBW - 1;
-  const int xlane = (nl * a.Cin + c0 + chs) * HW + (2 * tyl - 1) * a.W + 2 * txl;   // element offset of patch row 0, own pair
+  const int HWx = UPS ? Ht * Wt : HW;
+  const int xlane = UPS ? (nl * a.Cin + c0 + chs) * HWx + tyl * Wt + txl             // low-res pixel (TY, TX)
+                        : (nl * a.Cin + c0 + chs) * HWx + (2 * tyl - 1) * a.W + 2 * txl;  // patch row 0, own pair
   const int ylane = (nl * a.Cout + o0 + chs) * HW + (2 * tyl) * a.W + 2 * txl;
   // LDS float offset of the item's first component pair: [cp][tile pair t>>1][swizzled channel][k-step t&1][parity]
   const int ldst = ((t >> 1) * CH + (chs ^ ((t >> 1) << 1))) * 4 + (t & 1) * 2;
@@ -90,17 +94,34 @@ __global__ void __launch_bounds__(512) wino_wgrad_mfma(const WwArgs a) {
     const int bn = t2 / a.blocks_y;
     const int n = bn * a.TBN + nl, TY = by * a.TBH + tyl, TX = bx * a.TBW + txl;
     const bool ok = (blk < a.nblk) && (n < a.N) && (TY < Ht) && (TX < Wt);
-    const int ux = (bn * a.TBN * a.Cin) * HW + (2 * by * a.TBH) * a.W + 2 * bx * a.TBW;
+    const int ux = UPS ? (bn * a.TBN * a.Cin) * HWx + (by * a.TBH) * Wt + bx * a.TBW
+                       : (bn * a.TBN * a.Cin) * HWx + (2 * by * a.TBH) * a.W + 2 * bx * a.TBW;
     const int uy = (bn * a.TBN * a.Cout) * HW + (2 * by * a.TBH) * a.W + 2 * bx * a.TBW;
     const unsigned xo = (unsigned)(xlane + ux) * 4u;
     const bool xok = ok && xch;
+    if constexpr (UPS) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bool rv = xok && (r == 1 || r == 2 || (r == 0 ? TY > 0 : TY < Ht - 1));
-      const unsigned o = xo + (unsigned)(r * a.W) * 4u;
-      rP[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrs, (int)(rv ? o : 0x80000000u), 0, 0));
-      rL[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)((rv && ledge && TX > 0) ? o - 4u : 0x80000000u), 0, 0));
-      rR[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)((rv && redge && TX < Wt - 1) ? o + 8u : 0x80000000u), 0, 0));
+      for (int r3 = 0; r3 < 3; ++r3) {  // low-res rows TY-1, TY, TY+1 -> patch rows 0, (1, 2), 3
+        const bool rv = xok && (r3 == 1 || (r3 == 0 ? TY > 0 : TY < Ht - 1));
+        const unsigned o = xo + (unsigned)((r3 - 1) * Wt) * 4u;
+        const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)(rv ? o : 0x80000000u), 0, 0));
+        const float vl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)((rv && ledge && TX > 0) ? o - 4u : 0x80000000u), 0, 0));
+        const float vr = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)((rv && redge && TX < Wt - 1) ? o + 4u : 0x80000000u), 0, 0));
+        const int r = r3 == 0 ? 0 : (r3 == 1 ? 1 : 3);
+        rP[r] = f32x2{v, v};
+        rL[r] = vl;
+        rR[r] = vr;
+        if (r3 == 1) { rP[2] = f32x2{v, v}; rL[2] = vl; rR[2] = vr; }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool rv = xok && (r == 1 || r == 2 || (r == 0 ? TY > 0 : TY < Ht - 1));
+        const unsigned o = xo + (unsigned)(r * a.W) * 4u;
+        rP[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrs, (int)(rv ? o : 0x80000000u), 0, 0));
+        rL[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)((rv && ledge && TX > 0) ? o - 4u : 0x80000000u), 0, 0));
+        rR[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)((rv && redge && TX < Wt - 1) ? o + 8u : 0x80000000u), 0, 0));
+      }
     }
     const unsigned yo = (unsigned)(ylane + uy) * 4u;
     const bool yok = ok && ych;
@@ -321,16 +342,16 @@ void plan_ww(int N, int Cin, int Cout, int H, int W, WwPlan& pl) {
   pl.ws_floats = (size_t)pl.nsplit * (16 * (size_t)a.CinP * a.CoutP + a.CoutP);
 }
 
-template <int CT, int OT>
+template <int CT, int OT, bool UPS>
 int launch_ww(const WwArgs& a, dim3 grid, hipStream_t s) {
   constexpr size_t lds = (size_t)2 * STAGE * sizeof(float);
   static bool attr_set = false;  // benign race: idempotent
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_wgrad_mfma<CT, OT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_wgrad_mfma<CT, OT, UPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((wino_wgrad_mfma<CT, OT>), grid, dim3(512), lds, s, a);
+  hipLaunchKernelGGL((wino_wgrad_mfma<CT, OT, UPS>), grid, dim3(512), lds, s, a);
   MG_CHECK_LAUNCH("mg_wino3x3_wgrad");
   return MG_OK;
 }
@@ -344,9 +365,11 @@ extern "C" size_t mg_wino3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int
 }
 
 extern "C" int mg_wino3x3_wgrad(const float* x, const float* gy, float* gw, float* gb, void* ws, size_t ws_bytes, int N, int Cin,
-                                int Cout, int H, int W, int accumulate, int bias_n, mg_stream_t stream) {
+                                int Cout, int H, int W, int flags, int accumulate, int bias_n, mg_stream_t stream) {
   MG_CHECK_ARG(x && gy && gw && ws && N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "mg_wino3x3_wgrad: bad arguments");
   MG_CHECK_ARG((H % 2 == 0) && (W % 2 == 0), "mg_wino3x3_wgrad: H=%d W=%d must be even", H, W);
+  MG_CHECK_ARG(!(flags & ~MG_CONV_UPS_IN), "mg_wino3x3_wgrad: unknown flag");
+  const bool ups = (flags & MG_CONV_UPS_IN) != 0;
   MG_CHECK_ARG((long long)N * Cin * H * W < (1ll << 29) && (long long)N * Cout * H * W < (1ll << 29),
                "mg_wino3x3_wgrad: tensor too large for 32-bit byte offsets");
   WwPlan pl;
@@ -360,15 +383,22 @@ extern "C" int mg_wino3x3_wgrad(const float* x, const float* gy, float* gw, floa
   a.slab = reinterpret_cast<float*>(ws);
   a.slab_b = a.slab + (size_t)pl.nsplit * 16 * a.CinP * a.CoutP;
   a.bias_n = (bias_n <= 0 || bias_n > N) ? N : bias_n;
-  a.x_bytes = (unsigned)((size_t)N * Cin * H * W * 4);
+  a.x_bytes = (unsigned)((size_t)N * Cin * (ups ? (H / 2) * (W / 2) : H * W) * 4);
   a.gy_bytes = (unsigned)((size_t)N * Cout * H * W * 4);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(pl.nsplit, pl.ncb * a.nob);
   int rc;
-  if (pl.CT == 3 && pl.OT == 3) rc = launch_ww<3, 3>(a, grid, s);
-  else if (pl.CT == 3) rc = launch_ww<3, 4>(a, grid, s);
-  else if (pl.OT == 3) rc = launch_ww<4, 3>(a, grid, s);
-  else rc = launch_ww<4, 4>(a, grid, s);
+  if (ups) {
+    if (pl.CT == 3 && pl.OT == 3) rc = launch_ww<3, 3, true>(a, grid, s);
+    else if (pl.CT == 3) rc = launch_ww<3, 4, true>(a, grid, s);
+    else if (pl.OT == 3) rc = launch_ww<4, 3, true>(a, grid, s);
+    else rc = launch_ww<4, 4, true>(a, grid, s);
+  } else {
+    if (pl.CT == 3 && pl.OT == 3) rc = launch_ww<3, 3, false>(a, grid, s);
+    else if (pl.CT == 3) rc = launch_ww<3, 4, false>(a, grid, s);
+    else if (pl.OT == 3) rc = launch_ww<4, 3, false>(a, grid, s);
+    else rc = launch_ww<4, 4, false>(a, grid, s);
+  }
   if (rc != MG_OK) return rc;
   const int total = a.CinP * a.CoutP;
   hipLaunchKernelGGL(wino_wgrad_reduce, dim3(mg_cdiv(total, 64)), dim3(256), 0, s, a.slab, a.slab_b, pl.nsplit, gw, gb, Cout, Cin,

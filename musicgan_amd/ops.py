@@ -176,9 +176,9 @@ def upconv3x3_dgrad(gy, wp, cin: int):
 
 
 def wino_wgrad_supported(n: int, cin: int, cout: int, h: int, w: int, *, ups=False) -> bool:
-    """Whether conv3x3_wgrad takes the Winograd F(3x3,2x2) kernel: even sizes, no fused up-sampling, enough 2x2 tiles for its
-    split-K pipeline, byte offsets within 31 bits."""
-    if os.environ.get("MG_WINO_WGRAD", "1") == "0" or ups or (h % 2) or (w % 2):
+    """Whether conv3x3_wgrad takes the Winograd F(3x3,2x2) kernel: even sizes, enough 2x2 tiles for its split-K pipeline, byte
+    offsets within 31 bits."""
+    if os.environ.get("MG_WINO_WGRAD", "1") == "0" or (h % 2) or (w % 2):
         return False
     if n * max(cin, cout) * h * w >= (1 << 29):
         return False
@@ -193,8 +193,8 @@ def conv3x3_wgrad(x, gy, gw, gb, *, ups=False, accumulate=False, bias_n: int = 0
     lib = _lib.load()
     if wino_wgrad_supported(n, cin, cout, h, w, ups=ups):
         ws = workspace(lib.mg_wino3x3_wgrad_ws_bytes(n, cin, cout, h, w), x.device)
-        check(lib.mg_wino3x3_wgrad(_p(x), _p(gy), _p(gw), _p(gb), _p(ws), ws.numel(), n, cin, cout, h, w, int(accumulate),
-                                   int(bias_n), _s()), "mg_wino3x3_wgrad")
+        check(lib.mg_wino3x3_wgrad(_p(x), _p(gy), _p(gw), _p(gb), _p(ws), ws.numel(), n, cin, cout, h, w,
+                                   MG_CONV_UPS_IN if ups else 0, int(accumulate), int(bias_n), _s()), "mg_wino3x3_wgrad")
         return
     nbytes = lib.mg_conv3x3_wgrad_ws_bytes(n, cin, cout, h, w)
     ws = workspace(nbytes, x.device)

@@ -120,9 +120,12 @@ def test_conv3x3_wgrad(shape):
     report("wgrad gb acc", gb, 2 * bt.grad, 3e-6)
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 16, 2, 2), (2, 96, 80, 8, 8), (1, 64, 48, 32, 32)])
-def test_conv3x3_wgrad_upsampled_input(shape):
+@pytest.mark.parametrize("shape", [(2, 8, 16, 2, 2), (2, 96, 80, 8, 8), (1, 64, 48, 32, 32), (3, 24, 40, 6, 10), (5, 20, 17, 1, 6)])
+@pytest.mark.parametrize("wino", [False, True])
+def test_conv3x3_wgrad_upsampled_input(shape, wino, monkeypatch):
     ops = _ops()
+    monkeypatch.setenv("MG_WINO_WGRAD", "1" if wino else "0")
+    monkeypatch.setenv("MG_WINO_WGRAD_MIN_PIXELS", "1")
     n, ci, co, h, w = shape
     g = torch.Generator().manual_seed(5)
     x = torch.randn(n, ci, h, w, generator=g).double()
