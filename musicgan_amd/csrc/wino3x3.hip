@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(64 * WT * WC, 2) wino3x3_mfma(const WinoArgs a
   // the neighbour lane (DPP wave shift); the lanes on the left / right edge of the tile block load theirs from memory.
   // Offsets are bytes from the block's first image; 0x80000000 (beyond any num_records) marks the zero padding, tiles that
   // do not exist, item indices past the chunk and -- for the halo loads -- every lane that has a neighbour.
-  unsigned voffP[NITEM][4], voffL[NITEM][4], voffR[NITEM][4];
+  unsigned voffP[NITEM][4], voffE[NITEM][4];  // own pair; halo column of an edge lane (left OR right: a lane is at most one)
   bool ledge[NITEM], redge[NITEM];
   int vdst[NITEM];  // LDS float offset of the item's first component pair
   const int n0 = bn * a.TBN;
@@ -108,8 +108,8 @@ __global__ void __launch_bounds__(64 * WT * WC, 2) wino3x3_mfma(const WinoArgs a
       const bool rv = ok && (Y >= 0) && (Y < a.H);
       const unsigned o = (unsigned)(base + Y * a.W) * 4u;
       voffP[k][r] = rv ? o : 0x80000000u;
-      voffL[k][r] = (rv && ledge[k] && TX > 0) ? o - 4u : 0x80000000u;
-      voffR[k][r] = (rv && redge[k] && 2 * TX + 2 < a.W) ? o + 8u : 0x80000000u;
+      // a block one tile wide has both halos outside the image (W == 2), so one offset per lane is enough
+      voffE[k][r] = (rv && ledge[k] && TX > 0) ? o - 4u : ((rv && redge[k] && 2 * TX + 2 < a.W) ? o + 8u : 0x80000000u);
     }
     // [tile group][component pair][lane' = (cl>>1)*16 + tile%16][k-step = cl&1][parity]
     vdst[k] = (it < NITEMS) ? (((tl >> 4) * 8 * 64 + (cl >> 1) * 16 + (tl & 15)) * 4 + (cl & 1) * 2) : -1;
@@ -123,11 +123,10 @@ __global__ void __launch_bounds__(64 * WT * WC, 2) wino3x3_mfma(const WinoArgs a
 
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   f32x2 rP[NITEM][4];
-  float rL[NITEM][4], rR[NITEM][4];
+  float rE[NITEM][4];
   f32x4 rw[NU4];
 
   auto load_chunk = [&](int ch) {
-#ifndef WINO_EXP_NOV
     const int soff = ch * WCC * HW * 4;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img_base), 0, (int)img_bytes, 0x00020000);
@@ -136,25 +135,16 @@ __global__ void __launch_bounds__(64 * WT * WC, 2) wino3x3_mfma(const WinoArgs a
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         rP[k][r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voffP[k][r], soff, 0));
-#ifndef WINO_EXP_NOEDGE
-        rL[k][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voffL[k][r], soff, 0));
-        rR[k][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voffR[k][r], soff, 0));
-#else
-        rL[k][r] = 0.f; rR[k][r] = 0.f;
-#endif
+        rE[k][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voffE[k][r], soff, 0));
       }
     }
-#endif
-#ifndef WINO_EXP_NOU
     const f32x4* src = reinterpret_cast<const f32x4*>(a.up + ((size_t)ch * a.NT + ct0) * 2048);
 #pragma unroll
     for (int j = 0; j < NU4; ++j)
       if (NU4 * NTHR == U4 || tid + NTHR * j < U4) rw[j] = src[tid + NTHR * j];
-#endif
   };
 
   auto store_chunk = [&](int ch) {
-#ifndef WINO_EXP_NOV
     if (a.Cin - ch * WCC < WCC) {  // ragged last chunk: channels that do not exist must read as zero (the loads see real data)
       const int lim = a.Cin - ch * WCC;
 #pragma unroll
@@ -163,8 +153,7 @@ __global__ void __launch_bounds__(64 * WT * WC, 2) wino3x3_mfma(const WinoArgs a
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             rP[k][r] = f32x2{0.f, 0.f};
-            rL[k][r] = 0.f;
-            rR[k][r] = 0.f;
+            rE[k][r] = 0.f;
           }
         }
     }
@@ -180,7 +169,7 @@ __global__ void __launch_bounds__(64 * WT * WC, 2) wino3x3_mfma(const WinoArgs a
         const float own_x = rP[k][r][0], own_y = rP[k][r][1];
         const float fl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, own_y), 0x138, 0xf, 0xf, false));  // lane-1
         const float fr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, own_x), 0x130, 0xf, 0xf, false));  // lane+1
-        E[r] = f32x2{ledge[k] ? rL[k][r] : fl, redge[k] ? rR[k][r] : fr};
+        E[r] = f32x2{ledge[k] ? (a.TBW > 1 ? rE[k][r] : 0.f) : fl, redge[k] ? (a.TBW > 1 ? rE[k][r] : 0.f) : fr};
       }
       f32x2 UE[4], UP[4];  // B^T d (rows)
       UE[0] = E[0] - E[2];  UP[0] = P[0] - P[2];
@@ -194,22 +183,15 @@ __global__ void __launch_bounds__(64 * WT * WC, 2) wino3x3_mfma(const WinoArgs a
           const f32x2 ps = __builtin_shufflevector(UP[i], UP[i], 1, 0);  // (p1, p0)
           const f32x2 v03 = f32x2{UE[i][0], -UE[i][1]} + f32x2{-ps[0], ps[1]};
           const f32x2 v12 = UP[i] + f32x2{ps[0], -ps[1]};
-#ifndef WINO_EXP_NOLDSW
           *reinterpret_cast<f32x2*>(dst + (2 * i) * 256) = v03;
           *reinterpret_cast<f32x2*>(dst + (2 * i + 1) * 256) = v12;
-#else
-          if (a.N < 0) { *reinterpret_cast<f32x2*>(dst + (2 * i) * 256) = v03; *reinterpret_cast<f32x2*>(dst + (2 * i + 1) * 256) = v12; }
-#endif
         }
       }
     }
-#endif
-#ifndef WINO_EXP_NOU
     f32x4* dstw = reinterpret_cast<f32x4*>(Us);
 #pragma unroll
     for (int j = 0; j < NU4; ++j)
       if (NU4 * NTHR == U4 || tid + NTHR * j < U4) dstw[tid + NTHR * j] = rw[j];
-#endif
   };
 
   auto compute_chunk = [&]() {
@@ -237,9 +219,7 @@ __global__ void __launch_bounds__(64 * WT * WC, 2) wino3x3_mfma(const WinoArgs a
     store_chunk(ch);
     __syncthreads();
     load_chunk(ch + 1 < a.nchunk ? ch + 1 : ch);  // in flight during the MFMA phase below (the last one is a harmless repeat)
-#ifndef WINO_EXP_NOMFMA
     compute_chunk();
-#endif
   }
 
   // ---------------------------------------------------------------- epilogue: A^T M A, then the fused point-wise tail
@@ -307,11 +287,7 @@ __global__ void __launch_bounds__(64 * WT * WC, 2) wino3x3_mfma(const WinoArgs a
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int oc = oc0 + ni * 16 + g;
-#ifdef WINO_EXP_NOSTORE
-        const bool act = tok && oc < a.Cout && a.N < 0;
-#else
         const bool act = tok && oc < a.Cout;
-#endif
         const float r0 = swap1(odd ? on[g][0] : on[g][2]), r1 = swap1(odd ? on[g][1] : on[g][3]);
         f32x4 v = odd ? f32x4{r0, r1, on[g][2], on[g][3]} : f32x4{on[g][0], on[g][1], r0, r1};
         const size_t idx = pixw + (size_t)oc * HW;
@@ -410,17 +386,6 @@ __global__ void __launch_bounds__(64 * WT * WC, 2) wino3x3_mfma(const WinoArgs a
   };
   using T_ = std::true_type;
   using F_ = std::false_type;
-#ifdef WINO_EXP_NOEPI
-  if (a.N < 0) {  // keeps the accumulators alive
-    f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < 16; ++c)
-#pragma unroll
-      for (int ni = 0; ni < NIW; ++ni) t += acc[c][ni];
-    a.y[tid] = (t[0] + t[1]) + (t[2] + t[3]);
-  }
-  return;
-#endif
   if (a.flags & MG_CONV_PIXNORM) {
     if (a.y != nullptr) tail_pn(T_{});
     else tail_pn(F_{});

@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(512) wino_wgrad_mfma(const WwArgs a) {
       for (int j = 0; j < OT; ++j) acc[p][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   f32x2 rP[4], rG[2];
-  float rL[4], rR[4];
+  float rE[4];  // halo column of an edge lane (left OR right: a lane is at most one; a 1-tile-wide chunk has both outside)
   float bsum = 0.f;
   bool bnext = false;  // whether the gy tile in flight counts for the bias gradient
 
@@ -105,13 +105,12 @@ __global__ void __launch_bounds__(512) wino_wgrad_mfma(const WwArgs a) {
         const bool rv = xok && (r3 == 1 || (r3 == 0 ? TY > 0 : TY < Ht - 1));
         const unsigned o = xo + (unsigned)((r3 - 1) * Wt) * 4u;
         const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)(rv ? o : 0x80000000u), 0, 0));
-        const float vl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)((rv && ledge && TX > 0) ? o - 4u : 0x80000000u), 0, 0));
-        const float vr = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)((rv && redge && TX < Wt - 1) ? o + 4u : 0x80000000u), 0, 0));
+        const unsigned oe = (rv && ledge && TX > 0) ? o - 4u : ((rv && redge && TX < Wt - 1) ? o + 4u : 0x80000000u);
+        const float ve = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)oe, 0, 0));
         const int r = r3 == 0 ? 0 : (r3 == 1 ? 1 : 3);
         rP[r] = f32x2{v, v};
-        rL[r] = vl;
-        rR[r] = vr;
-        if (r3 == 1) { rP[2] = f32x2{v, v}; rL[2] = vl; rR[2] = vr; }
+        rE[r] = ve;
+        if (r3 == 1) { rP[2] = f32x2{v, v}; rE[2] = ve; }
       }
     } else {
 #pragma unroll
@@ -119,8 +118,8 @@ __global__ void __launch_bounds__(512) wino_wgrad_mfma(const WwArgs a) {
         const bool rv = xok && (r == 1 || r == 2 || (r == 0 ? TY > 0 : TY < Ht - 1));
         const unsigned o = xo + (unsigned)(r * a.W) * 4u;
         rP[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrs, (int)(rv ? o : 0x80000000u), 0, 0));
-        rL[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)((rv && ledge && TX > 0) ? o - 4u : 0x80000000u), 0, 0));
-        rR[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)((rv && redge && TX < Wt - 1) ? o + 8u : 0x80000000u), 0, 0));
+        const unsigned oe = (rv && ledge && TX > 0) ? o - 4u : ((rv && redge && TX < Wt - 1) ? o + 8u : 0x80000000u);
+        rE[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)oe, 0, 0));
       }
     }
     const unsigned yo = (unsigned)(ylane + uy) * 4u;
@@ -140,7 +139,7 @@ __global__ void __launch_bounds__(512) wino_wgrad_mfma(const WwArgs a) {
         const float own_x = rP[r][0], own_y = rP[r][1];
         const float fl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, own_y), 0x138, 0xf, 0xf, false));  // lane-1
         const float fr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, own_x), 0x130, 0xf, 0xf, false));  // lane+1
-        E[r] = f32x2{ledge ? rL[r] : fl, redge ? rR[r] : fr};
+        E[r] = f32x2{ledge ? (a.TBW > 1 ? rE[r] : 0.f) : fl, redge ? (a.TBW > 1 ? rE[r] : 0.f) : fr};
       }
       f32x2 UE[4], UP[4];
       UE[0] = E[0] - E[2];  UP[0] = P[0] - P[2];
