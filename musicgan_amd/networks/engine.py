@@ -54,8 +54,8 @@ class PackCache:
     def conv(self, x: torch.Tensor, w: torch.Tensor, dgrad: bool, bias, cout: int, **kw):
         """ops.conv3x3 with the kernel chosen per shape: Winograd F(2x2,3x3) where it is supported and pays (large maps, no
         fused up-sampling), the direct implicit GEMM otherwise.  Only the form that is used gets packed."""
-        n, _, h, wd = x.shape
-        if ops.wino3x3_supported(n, cout, h, wd, ups=kw.get("ups", False), pixnorm=kw.get("pixnorm", False)):
+        n, cin, h, wd = x.shape
+        if ops.wino3x3_supported(n, cout, h, wd, ups=kw.get("ups", False), pixnorm=kw.get("pixnorm", False), cin=cin):
             return ops.conv3x3(x, None, bias, cout, wino=self.get_wino(w, dgrad), **kw)
         return ops.conv3x3(x, self.get(w, dgrad), bias, cout, **kw)
 
@@ -129,7 +129,7 @@ def gen_forward(W: GenWeights, z: torch.Tensor, alpha: float, cache: PackCache, 
         ci, co = w1.shape[0], w2.shape[0]
         # only the normalised outputs p and the per-pixel 1/norm are kept: the backward derives mask and x_hat from p
         _, p1, rn1 = cache.conv(x, w1, False, b1, ci, lrelu=True, pixnorm=True, want_y=False)
-        if ops.upconv3x3_supported(co, p1.shape[3]):  # sub-pixel form: 2.25x fewer MFMAs than conv over the upsampled map
+        if ops.upconv3x3_supported(co, p1.shape[3], p1.numel()):  # sub-pixel form: 2.25x fewer MFMAs than conv over the upsampled map
             _, p2, rn2 = ops.upconv3x3(p1, cache.get_up(w2), b2, co, lrelu=True, pixnorm=True, want_y=False)
         else:
             _, p2, rn2 = cache.conv(p1, w2, False, b2, co, ups=True, lrelu=True, pixnorm=True, want_y=False)

@@ -68,12 +68,16 @@ def pack_wino3x3(w: torch.Tensor, dgrad: bool) -> torch.Tensor:
     return up
 
 
-def wino3x3_supported(n: int, cout: int, h: int, w: int, *, ups=False, pixnorm=False) -> bool:
-    """Whether conv3x3(..., wino=) may be used: even sizes, enough 2x2 tiles to fill the chip, and for the fused PixelNorm
-    all channels of a pixel inside one workgroup."""
+def wino3x3_supported(n: int, cout: int, h: int, w: int, *, ups=False, pixnorm=False, cin: int = 0) -> bool:
+    """Whether conv3x3(..., wino=) may be used: even sizes, enough 2x2 tiles to fill the chip, for the fused PixelNorm all
+    channels of a pixel inside one workgroup, and one image's input planes within the kernel's 32-bit byte offsets (the long
+    non-square maps of `generate` can exceed that; they then take the direct kernel)."""
     if os.environ.get("MG_WINO", "1") == "0" or ups or (h % 2) or (w % 2):
         return False
     if pixnorm and cout > 64:
+        return False
+    tiles = (h // 2) * (w // 2)
+    if max(cin, 1) * h * w * max(1, 32 // max(tiles, 1)) >= (1 << 29):  # images per 32-tile block x one image's planes
         return False
     return n * h * w >= int(os.environ.get("MG_WINO_MIN_PIXELS", "8192"))  # fewer 2x2 tiles do not fill the chip
 
@@ -122,10 +126,11 @@ def pack_upconv3x3(w: torch.Tensor) -> torch.Tensor:
     return wp
 
 
-def upconv3x3_supported(cout: int, win: int) -> bool:
+def upconv3x3_supported(cout: int, win: int, numel: int = 0) -> bool:
     """The sub-pixel kernel keeps 4 phases x all output channels of 16 pixels in one wave: beyond 80 channels its registers
-    cost more occupancy than the 2.25x MFMA saving returns (measured: 112->96 @8x8 is slower than the direct form)."""
-    return cout <= 80 and win >= 2
+    cost more occupancy than the 2.25x MFMA saving returns (measured: 112->96 @8x8 is slower than the direct form).
+    `numel` (input elements): the kernel indexes with 31 bits."""
+    return cout <= 80 and win >= 2 and numel < (1 << 31)
 
 
 def upconv3x3(x, wp, bias, cout: int, *, lrelu=False, pixnorm=False, want_y=True):

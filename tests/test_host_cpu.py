@@ -87,3 +87,19 @@ def test_package_reexports_drivers_lazily():
     assert callable(musicgan_amd.train)  # still the function after the sub-module import
     from musicgan_amd.audio import N_FFT, N_VEC, SAMPLE_RATE, STFT_STRIDE
     assert (N_FFT, N_VEC, STFT_STRIDE, SAMPLE_RATE) == (1024, 512, 256, 44100)
+
+
+def test_kernel_selection_predicates_respect_index_limits():
+    """The engine only routes a layer to the Winograd / sub-pixel kernels when their 31/32-bit offset arithmetic can address it;
+    the long non-square maps of `generate` (e.g. 512 x 5120*k) fall back to the direct kernels instead of failing."""
+    from musicgan_amd import ops
+    assert ops.wino3x3_supported(64, 64, 128, 128, cin=48)
+    assert ops.wino3x3_supported(1, 48, 512, 5120, cin=48)
+    assert not ops.wino3x3_supported(1, 48, 512, 5120 * 8, cin=64)       # 64 * 512 * 40960 * 4 B > 2^31
+    assert not ops.wino3x3_supported(64, 80, 32, 32, pixnorm=True, cin=80)  # PixelNorm epilogue needs <= 64 channels
+    assert not ops.wino3x3_supported(64, 64, 7, 8, cin=64) and not ops.wino3x3_supported(64, 64, 8, 8, ups=True, cin=64)
+    assert not ops.wino3x3_supported(2, 64, 8, 8, cin=64)               # too few tiles
+    assert ops.upconv3x3_supported(48, 64, 64 * 64 * 64 * 64) and not ops.upconv3x3_supported(48, 64, 1 << 31)
+    assert not ops.upconv3x3_supported(96, 64, 1024)
+    assert ops.wino_wgrad_supported(192, 48, 64, 128, 128) and not ops.wino_wgrad_supported(192, 48, 64, 127, 128)
+    assert not ops.wino_wgrad_supported(1024, 64, 64, 128, 128)         # > 2^29 elements

@@ -191,7 +191,7 @@ def test_shapes_walk_and_growth_flags():
     assert next(gen.end_block_params()).is_cuda and next(disc.start_block_parameters()).is_cuda
 
 
-def test_nonsquare_generator_forward():
+def test_nonsquare_generator_forward(conv_mode):
     """generate.py:47-54 feeds a non-square latent through a directly constructed Generator(end_layer=k)."""
     from musicgan_amd.networks import Generator
     g = load("progan_shapes.npz")
