@@ -38,6 +38,7 @@ struct ConvArgs {
   int plane, ch_stride, tab_floats;
   int OPF;  // row stride of the packed weights (floats) = 16*ceil(Cout/16)
   int nchunk;
+  int sub;  // 8-channel chunks per barrier interval (1 or 4)
 };
 
 // PF: software-pipelined variant -- the next chunk's global loads are issued into registers right after the barrier that
@@ -45,13 +46,16 @@ struct ConvArgs {
 // under the matrix work of the same workgroup instead of relying on other workgroups being in a different phase.
 constexpr int PF_NIN = 12;  // halo positions per thread held in flight (covers plane <= 384: every tile of a >= 16-wide image)
 
-template <int NI, int MI, bool PF>
+// SUB: 8-channel chunks staged and consumed per barrier interval.  The small maps at the ends of both networks (<= 8x8, 112-160
+// channels) are latency-bound -- 14-20 chunks of 18 MFMAs, each behind two barriers and a global-load round trip -- so their
+// variants take 4 chunks at a time.
+template <int NI, int MI, bool PF, int SUB = 1>
 __global__ void __launch_bounds__(256) conv3x3_mfma(const ConvArgs a) {
   constexpr int OPL = (NI & 1) ? NI * 16 : NI * 16 + 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int* tab = reinterpret_cast<int*>(smem);
   float* in_t = smem + a.tab_floats;
-  float* w_t = in_t + CC * a.ch_stride;
+  float* w_t = in_t + SUB * CC * a.ch_stride;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 15, rq = lane >> 4;
@@ -98,80 +102,98 @@ __global__ void __launch_bounds__(256) conv3x3_mfma(const ConvArgs a) {
 
   constexpr int NW4 = (9 * CC * NI * 4 + 255) / 256;
   const int cl_ = tid >> 5, l32_ = tid & 31;
-  float rin[PF ? PF_NIN : 1];
-  f32x4 rw[PF ? NW4 : 1];
+  constexpr int RIN = SUB > 1 ? 8 : PF_NIN;  // SUB variants serve small maps only: halo tile <= 256 positions
+  float rin[PF ? RIN * SUB : 1];
+  f32x4 rw[PF ? NW4 * SUB : 1];
 
-  auto compute_chunk = [&]() {
+  auto compute_chunk = [&](int ch) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int tap = (t / 3) * a.TWp + (t % 3);
+    for (int sub = 0; sub < SUB; ++sub) {
+      if (SUB > 1 && ch * SUB + sub >= a.nchunk) break;
+      const float* in_s = in_t + sub * CC * a.ch_stride;
+      const float* w_s = w_t + sub * 9 * CC * OPL;
 #pragma unroll
-      for (int ks = 0; ks < CC / 4; ++ks) {
-        float av[MI], bv[NI];
+      for (int t = 0; t < 9; ++t) {
+        const int tap = (t / 3) * a.TWp + (t % 3);
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) av[mi] = in_t[pix_off[mi] + ks * 4 * a.ch_stride + tap];
+        for (int ks = 0; ks < CC / 4; ++ks) {
+          float av[MI], bv[NI];
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) bv[ni] = w_t[(t * CC + ks * 4 + rq) * OPL + ni * 16 + col];
+          for (int mi = 0; mi < MI; ++mi) av[mi] = in_s[pix_off[mi] + ks * 4 * a.ch_stride + tap];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+          for (int ni = 0; ni < NI; ++ni) bv[ni] = w_s[(t * CC + ks * 4 + rq) * OPL + ni * 16 + col];
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+        }
       }
     }
   };
 
   if constexpr (PF) {
+    const int nouter = (a.nchunk + SUB - 1) / SUB;
     auto load_chunk = [&](int ch) {
-      const int c = ch * CC + cl_;
-      const bool cok = c < a.Cin;
-      const float* xc = xn + (size_t)c * HWin;
 #pragma unroll
-      for (int j = 0; j < PF_NIN; ++j) {
-        const int pos = l32_ + 32 * j;
-        float v = 0.f;
-        if (pos < a.plane) {
-          const int off = tab[pos];
-          if (cok && off >= 0) v = xc[off];
+      for (int sub = 0; sub < SUB; ++sub) {
+        const int chs = ch * SUB + sub;
+        if (SUB > 1 && chs >= a.nchunk) break;
+        const int c = chs * CC + cl_;
+        const bool cok = c < a.Cin;
+        const float* xc = xn + (size_t)c * HWin;
+#pragma unroll
+        for (int j = 0; j < RIN; ++j) {
+          const int pos = l32_ + 32 * j;
+          float v = 0.f;
+          if (pos < a.plane) {
+            const int off = tab[pos];
+            if (cok && off >= 0) v = xc[off];
+          }
+          rin[sub * RIN + j] = v;
         }
-        rin[j] = v;
-      }
-      const float* src = a.wp + (size_t)ch * (9 * CC) * a.OPF + o0;
+        const float* src = a.wp + (size_t)chs * (9 * CC) * a.OPF + o0;
 #pragma unroll
-      for (int j = 0; j < NW4; ++j) {
-        const int e = tid + 256 * j;
-        if (e < 9 * CC * NI * 4) {
-          const int row = e / (NI * 4);
-          const int jj = e - row * (NI * 4);
-          rw[j] = *reinterpret_cast<const f32x4*>(src + (size_t)row * a.OPF + 4 * jj);
+        for (int j = 0; j < NW4; ++j) {
+          const int e = tid + 256 * j;
+          if (e < 9 * CC * NI * 4) {
+            const int row = e / (NI * 4);
+            const int jj = e - row * (NI * 4);
+            rw[sub * NW4 + j] = *reinterpret_cast<const f32x4*>(src + (size_t)row * a.OPF + 4 * jj);
+          }
         }
       }
     };
-    auto store_chunk = [&]() {
-      float* dst = in_t + cl_ * a.ch_stride;
+    auto store_chunk = [&](int ch) {
 #pragma unroll
-      for (int j = 0; j < PF_NIN; ++j) {
-        const int pos = l32_ + 32 * j;
-        if (pos < a.plane) dst[pos] = rin[j];
-      }
+      for (int sub = 0; sub < SUB; ++sub) {
+        if (SUB > 1 && ch * SUB + sub >= a.nchunk) break;
+        float* dst = in_t + (sub * CC + cl_) * a.ch_stride;
 #pragma unroll
-      for (int j = 0; j < NW4; ++j) {
-        const int e = tid + 256 * j;
-        if (e < 9 * CC * NI * 4) {
-          const int row = e / (NI * 4);
-          const int jj = e - row * (NI * 4);
-          *reinterpret_cast<f32x4*>(w_t + row * OPL + 4 * jj) = rw[j];
+        for (int j = 0; j < RIN; ++j) {
+          const int pos = l32_ + 32 * j;
+          if (pos < a.plane) dst[pos] = rin[sub * RIN + j];
+        }
+        float* wd = w_t + sub * 9 * CC * OPL;
+#pragma unroll
+        for (int j = 0; j < NW4; ++j) {
+          const int e = tid + 256 * j;
+          if (e < 9 * CC * NI * 4) {
+            const int row = e / (NI * 4);
+            const int jj = e - row * (NI * 4);
+            *reinterpret_cast<f32x4*>(wd + row * OPL + 4 * jj) = rw[sub * NW4 + j];
+          }
         }
       }
     };
     __syncthreads();  // tab visible
     load_chunk(0);
-    for (int ch = 0; ch < a.nchunk; ++ch) {
+    for (int ch = 0; ch < nouter; ++ch) {
       __syncthreads();  // previous chunk's LDS reads done
-      store_chunk();
+      store_chunk(ch);
       __syncthreads();
-      if (ch + 1 < a.nchunk) load_chunk(ch + 1);  // in flight during the MFMA phase below
-      compute_chunk();
+      if (ch + 1 < nouter) load_chunk(ch + 1);  // in flight during the MFMA phase below
+      compute_chunk(ch);
     }
   } else {
     for (int ch = 0; ch < a.nchunk; ++ch) {
@@ -199,7 +221,7 @@ __global__ void __launch_bounds__(256) conv3x3_mfma(const ConvArgs a) {
         }
       }
       __syncthreads();
-      compute_chunk();
+      compute_chunk(ch);
     }
   }
 
@@ -381,15 +403,15 @@ __global__ void conv3x3_pack_kernel(const float* __restrict__ w, float* __restri
   wp[e] = v;
 }
 
-template <int NI, int MI, bool PF>
+template <int NI, int MI, bool PF, int SUB = 1>
 int launch_conv_pf(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;  // benign race: idempotent
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma<NI, MI, PF>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma<NI, MI, PF, SUB>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_mfma<NI, MI, PF>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv3x3_mfma<NI, MI, PF, SUB>), grid, dim3(256), lds, s, a);
   MG_CHECK_LAUNCH("mg_conv3x3");
   return MG_OK;
 }
@@ -405,6 +427,9 @@ bool pf_enabled() {
 
 template <int NI, int MI>
 int launch_conv(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  // small maps with many channels: 4 chunks per barrier interval (the host sized `lds` for it)
+  if constexpr (MI == 1 && NI <= 2)
+    if (a.sub == 4) return launch_conv_pf<NI, MI, true, 4>(a, grid, lds, s);
   // the pipelined variant needs the halo tile to fit its in-flight registers and more than one chunk to overlap
   if (pf_enabled() && a.plane <= 32 * PF_NIN && a.nchunk > 1) return launch_conv_pf<NI, MI, true>(a, grid, lds, s);
   return launch_conv_pf<NI, MI, false>(a, grid, lds, s);
@@ -508,7 +533,9 @@ extern "C" int mg_conv3x3(const float* x, const float* wp, const float* bias, co
   if (a.ch_stride < a.plane) a.ch_stride += 32;
   a.tab_floats = (a.plane + 3) & ~3;
   const int OPL = (NI & 1) ? NI * 16 : NI * 16 + 16;
-  const size_t lds = (size_t)(a.tab_floats + CC * a.ch_stride + 9 * CC * OPL) * sizeof(float);
+  a.sub = 1;
+  if (MI == 1 && NI <= 2 && pf_enabled() && a.plane <= 256 && a.nchunk >= 8 && getenv("MG_CONV_NOSUB") == nullptr) a.sub = 4;
+  const size_t lds = (size_t)(a.tab_floats + a.sub * (CC * a.ch_stride + 9 * CC * OPL)) * sizeof(float);
   MG_CHECK_ARG(lds <= 160 * 1024, "mg_conv3x3: LDS tile %zu B too large", lds);
   dim3 grid(a.tiles_x * a.tiles_y * a.tiles_n, NIfull / NI);
   MG_CHECK_ARG(NIfull % NI == 0, "mg_conv3x3: internal tile error");
