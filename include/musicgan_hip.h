@@ -129,6 +129,10 @@ int mg_avgpool2_bwd(const float* gy, const float* act, float* gx, int NC, int H,
                     mg_stream_t stream);
 /* out = g * (act > 0 ? 1 : slope) */
 int mg_lrelu_bwd(const float* g, const float* act, float* out, size_t n, float slope, mg_stream_t stream);
+/* backward of the critic's fade-in blend [discriminator.py:111-113] and of the two LeakyReLUs feeding it, in one pass:
+ * out_a = ca*g*(act_a > 0 ? 1 : slope), out_o = co*g*(act_o > 0 ? 1 : slope)  (rounded as (c*g)*mask, like axpby + lrelu_bwd) */
+int mg_blend_lrelu_bwd(const float* g, const float* act_a, const float* act_o, float ca, float co, float* out_a, float* out_o,
+                       size_t n, float slope, mg_stream_t stream);
 /* out = a*x + b*y (fade-in blend [generator.py:124, discriminator.py:113]); y may be NULL (out = a*x) */
 int mg_axpby(float a, const float* x, float b, const float* y, float* out, size_t n, mg_stream_t stream);
 /* out[n,c,h,w] = a*x[n,c,h,w] + b*up2(y)[n,c,h,w], y is (NC, H/2, W/2) */

@@ -208,6 +208,27 @@ __global__ void __launch_bounds__(256) lrelu_bwd_k(const float* __restrict__ g, 
   }
 }
 
+// backward of the fade-in blend alpha*a + (1-alpha)*o followed by the two LeakyReLUs that produced a and o: one pass over g
+template <int V>
+__global__ void __launch_bounds__(256) blend_lrelu_bwd_k(const float* __restrict__ g, const float* __restrict__ act_a,
+                                                         const float* __restrict__ act_o, float ca, float co,
+                                                         float* __restrict__ out_a, float* __restrict__ out_o, size_t nq,
+                                                         float slope) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (size_t)gridDim.x * blockDim.x) {
+    float gv[V], a[V], o[V];
+    ld<V>(g + i * V, gv);
+    ld<V>(act_a + i * V, a);
+    ld<V>(act_o + i * V, o);
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      a[v] = (ca * gv[v]) * mg_lrelu_mask(a[v], slope);
+      o[v] = (co * gv[v]) * mg_lrelu_mask(o[v], slope);
+    }
+    st<V>(out_a + i * V, a);
+    st<V>(out_o + i * V, o);
+  }
+}
+
 template <int V>
 __global__ void __launch_bounds__(256) axpby_k(float a, const float* __restrict__ x, float b,
                                                const float* __restrict__ y, float* __restrict__ out, size_t nq) {
@@ -430,6 +451,15 @@ extern "C" int mg_lrelu_bwd(const float* g, const float* act, float* out, size_t
   if ((n & 3) == 0) EW_LAUNCH(lrelu_bwd_k<4>, ew_grid(n / 4), 256, g, act, out, n / 4, slope);
   else EW_LAUNCH(lrelu_bwd_k<1>, ew_grid(n), 256, g, act, out, n, slope);
   MG_CHECK_LAUNCH("mg_lrelu_bwd");
+  return MG_OK;
+}
+
+extern "C" int mg_blend_lrelu_bwd(const float* g, const float* act_a, const float* act_o, float ca, float co, float* out_a,
+                                  float* out_o, size_t n, float slope, mg_stream_t stream) {
+  MG_CHECK_ARG(g && act_a && act_o && out_a && out_o && n > 0, "mg_blend_lrelu_bwd: bad arguments");
+  if ((n & 3) == 0) EW_LAUNCH(blend_lrelu_bwd_k<4>, ew_grid(n / 4), 256, g, act_a, act_o, ca, co, out_a, out_o, n / 4, slope);
+  else EW_LAUNCH(blend_lrelu_bwd_k<1>, ew_grid(n), 256, g, act_a, act_o, ca, co, out_a, out_o, n, slope);
+  MG_CHECK_LAUNCH("mg_blend_lrelu_bwd");
   return MG_OK;
 }
 

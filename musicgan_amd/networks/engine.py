@@ -239,7 +239,7 @@ def disc_forward(W: DiscWeights, x: torch.Tensor, alpha: float, cache: PackCache
 
 
 def disc_backward(W: DiscWeights, ctx, g_out: torch.Tensor, cache: PackCache, sink: Optional[GradSink],
-                  need_gx: bool, keep_h: bool = False):
+                  need_gx: bool, keep_h: bool = False, gx_from: int = 0):
     """Back-propagate g_out (N,1).  sink=None skips all parameter gradients (first-order pass of the penalty).
     keep_h returns the masked per-layer gradients h_l needed by disc_gp_param_grads()."""
     x, h0, saved, xp, o, flat, alpha = ctx
@@ -256,8 +256,7 @@ def disc_backward(W: DiscWeights, ctx, g_out: torch.Tensor, cache: PackCache, si
     a2_last = saved[nb - 1][3]
     g = g.reshape(a2_last.shape)
     if nb == 1 and W.old_stem is not None:  # the blend is the classifier input
-        gpre2 = ops.lrelu_bwd(ops.axpby(alpha, g), a2_last)
-        gpre_o = ops.lrelu_bwd(ops.axpby(1.0 - alpha, g), o)
+        gpre2, gpre_o = ops.blend_lrelu_bwd(g, a2_last, o, alpha, 1.0 - alpha)
     else:
         gpre2 = ops.lrelu_bwd(g, a2_last)
         gpre_o = None
@@ -282,8 +281,7 @@ def disc_backward(W: DiscWeights, ctx, g_out: torch.Tensor, cache: PackCache, si
             a2_prev = saved[i - 1][3]
             if i == 1 and W.old_stem is not None:  # inp is the fade-in blend of a2_prev and the old stem path
                 gblend = cache.conv(gpre1, w1, True, None, cin)
-                gpre2 = ops.lrelu_bwd(ops.axpby(alpha, gblend), a2_prev)
-                gpre_o = ops.lrelu_bwd(ops.axpby(1.0 - alpha, gblend), o)
+                gpre2, gpre_o = ops.blend_lrelu_bwd(gblend, a2_prev, o, alpha, 1.0 - alpha)
             else:
                 gpre2 = cache.conv(gpre1, w1, True, None, cin, mask_aux=a2_prev)
         else:
@@ -299,10 +297,10 @@ def disc_backward(W: DiscWeights, ctx, g_out: torch.Tensor, cache: PackCache, si
     if keep_h:
         hs["stem"], hs["old"] = gpre_s, gpre_o
     gx = None
-    if need_gx:
-        gx = ops.conv1x1(gpre_s, W.stem[0], None, 2, transposed=True)
+    if need_gx:  # gx_from > 0: only samples gx_from.. are wanted (the fused critic step needs the interpolated third only)
+        gx = ops.conv1x1(gpre_s[gx_from:], W.stem[0], None, 2, transposed=True)
         if W.old_stem is not None:
-            gxp = ops.conv1x1(gpre_o, W.old_stem[0], None, 2, transposed=True)
+            gxp = ops.conv1x1(gpre_o[gx_from:], W.old_stem[0], None, 2, transposed=True)
             gx = ops.axpby(1.0, gx, 1.0, ops.avgpool2_bwd(gxp), out=gx)
     return gx, (hs if keep_h else None)
 
@@ -367,13 +365,13 @@ def disc_step_fused(W: DiscWeights, x_real: torch.Tensor, x_fake: torch.Tensor, 
     g_out[:n] = -1.0 / n
     g_out[n:2 * n] = 1.0 / n
     g_out[2 * n:] = 1.0
-    gx, hs = disc_backward(W, ctx, g_out, cache, None, need_gx=True, keep_h=True)
+    gx, hs = disc_backward(W, ctx, g_out, cache, None, need_gx=True, keep_h=True, gx_from=2 * n)  # input gradient: x~ only
     # penalty value and u_0 = dP/dg_0, written over the interpolated inputs (they are not needed any more)
-    ss = ops.sumsq_per_sample(gx[2 * n:])
+    ss = ops.sumsq_per_sample(gx)
     grad_pen, coef = ops.gp_finish(ss, gp_factor, 1.0)
     x, h0, saved, xp, o, flat, _ = ctx
     sl = slice(2 * n, 3 * n)
-    ops.scale_per_sample(gx[sl], coef, out=x[sl])
+    ops.scale_per_sample(gx, coef, out=x[sl])
     # ---- tangent pass, in place over the interpolated slices
     c0 = W.stem[0].shape[0]
     ops.conv1x1(x[sl], W.stem[0], None, c0, mask_aux=h0[sl], out=h0[sl])

@@ -297,6 +297,15 @@ def avgpool2_bwd(gy, act=None):
     return gx
 
 
+def blend_lrelu_bwd(g, act_a, act_o, ca: float, co: float):
+    """(ca*g*lrelu'(act_a), co*g*lrelu'(act_o)): backward of the fade-in blend and the two LeakyReLUs in one pass."""
+    _chk(g, act_a, act_o)
+    out_a, out_o = torch.empty_like(g), torch.empty_like(g)
+    check(_lib.load().mg_blend_lrelu_bwd(_p(g), _p(act_a), _p(act_o), ca, co, _p(out_a), _p(out_o), g.numel(), SLOPE, _s()),
+          "mg_blend_lrelu_bwd")
+    return out_a, out_o
+
+
 def lrelu_bwd(g, act, out=None):
     _chk(g, act, out)
     out = torch.empty_like(g) if out is None else out

@@ -452,3 +452,16 @@ def test_wino_wgrad_matches_autograd(shape, monkeypatch):
     gwd = torch.empty_like(gw2)
     ops.conv3x3_wgrad(xd, gyd, gwd, None)
     report("wino vs direct wgrad", gw2, gwd.double(), 3e-6)
+
+
+def test_blend_lrelu_bwd_equals_the_four_kernels_it_replaces():
+    ops = _ops()
+    g = torch.Generator().manual_seed(41)
+    gr = torch.randn(3, 7, 5, 6, generator=g).to(DEV)
+    a = torch.randn(3, 7, 5, 6, generator=g).to(DEV)
+    o = torch.randn(3, 7, 5, 6, generator=g).to(DEV)
+    oa, oo = ops.blend_lrelu_bwd(gr, a, o, 0.37, 0.63)
+    assert torch.equal(oa, ops.lrelu_bwd(ops.axpby(0.37, gr), a)) and torch.equal(oo, ops.lrelu_bwd(ops.axpby(0.63, gr), o))
+    gr4, a4, o4 = gr.reshape(-1)[:628], a.reshape(-1)[:628].clone(), o.reshape(-1)[:628].clone()  # vector path (n % 4 == 0)
+    oa, oo = ops.blend_lrelu_bwd(gr4.clone(), a4, o4, 0.5, 0.5)
+    assert torch.equal(oa, ops.lrelu_bwd(ops.axpby(0.5, gr4.clone()), a4))
