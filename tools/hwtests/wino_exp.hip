@@ -1,6 +1,8 @@
-// Timing harness for variants of the Winograd conv kernel: compiles musicgan_amd/csrc/wino3x3.hip in place (with -DWINO_EXP_*
-// switches that drop parts of the pipeline) and times mg_wino3x3 on random data.  Results of the reduced variants are wrong by
-// construction; only the timings mean something.   ./wino_exp N Cin Cout H W flags
+// Stand-alone timing harness for the Winograd conv kernel: compiles musicgan_amd/csrc/wino3x3.hip in place (so a locally
+// modified copy, or one built with extra -D switches, can be A/B-timed in a single gpurun call without touching the library)
+// and times mg_wino3x3 on random data with HIP events.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -DWINO_EXP_NAME='"BASE"' wino_exp.hip -o wino_exp_BASE
+//   ./wino_exp_BASE N Cin Cout H W flags
 #include "../../musicgan_amd/csrc/core.hip"
 #include "../../musicgan_amd/csrc/wino3x3.hip"
 #include <vector>
