@@ -5,7 +5,8 @@
 //            zero Nyquist row, inverse_spectrogram == window * irfft, overlap-add / window envelope, centre trim)
 // The unwrap / cumulative sums are evaluated SEQUENTIALLY per frequency row in fp32, exactly as torch.cumsum does on the CPU:
 // the running sum reaches hundreds of radians, so any re-association would change the low bits the reference produces.
-// One thread per row walks time; everything else is embarrassingly parallel and HBM-bound (8 B in + 8 B out per bin).
+// One lane per row walks time (the forward unwrap tiles it through LDS so that only the running sum itself is serial);
+// everything else is embarrassingly parallel and HBM-bound (8 B in + 8 B out per bin).
 #include "mg_common.h"
 
 namespace {
@@ -67,61 +68,153 @@ __global__ void __launch_bounds__(256) codec_abs_angle(const float2* __restrict_
 }
 
 // ---- forward pass 2: per row, sequential unwrap (np.unwrap semantics incl. the -pi -> +pi fix), first difference of the
-// unwrapped phase -> delta[k][t-1], t = 1..T-1; per-row min/max
-__global__ void __launch_bounds__(64) codec_unwrap_delta(const float* __restrict__ phi, float* __restrict__ delta,
-                                                         float* __restrict__ part, int T) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= NB) return;
-  const float* p = phi + (size_t)k * T;
-  float* d = delta + (size_t)k * (T - 1);
-  float prev = p[0];
-  float c = 0.f;       // running cumsum of the adjustments (fp32, sequential)
-  float prev_u = prev;  // unwrapped[0] = phi[0] + 0
+// unwrapped phase -> delta[k][t-1], t = 1..T-1; partial min/max.
+// Only the running sum of the adjustments is sequential (c_t = c_{t-1} + adj_t, one fp32 add per frame, in frame order, exactly
+// as torch.cumsum does it); everything else is parallel.  A workgroup owns 64 frequency rows and walks time in tiles of 64
+// frames through LDS: 8 loader waves fetch a tile coalesced along t, compute the adjustments (wrap test, remainder, the
+// -pi -> +pi fix) and write phi / adj tiles; ONE scanner wave (lane = row) runs the sequential part of the tile before --
+// 3 adds per frame, operands by 16-byte LDS reads; 4 storer waves write the finished delta tile coalesced.  Loads and stores
+// sit in different waves on purpose: gfx950 retires a wave's vector-memory operations in order, so a wave that interleaves
+// them waits for a store round trip before every tile (measured: 5.8 us per tile instead of < 1).  One barrier per tile; all
+// tiles double-buffered.
+constexpr int UT = 64;     // frames per tile
+constexpr int USTR = 68;   // LDS row stride (floats): rows 16-byte aligned, 16-byte reads of 16 lanes hit 16 distinct slots
+constexpr int UTILE = 64 * USTR;
+constexpr size_t UNWRAP_LDS = (size_t)6 * UTILE * sizeof(float);
+constexpr int NLW = 8;             // loader waves
+constexpr int RPL = 64 / NLW;      // rows per loader lane
+constexpr int UNWRAP_THREADS = 64 * (1 + NLW + 4);
+
+// torch.remainder(a, 2 pi) for a = dphi + pi.  Both phases come from atan2f, so a lies in [-pi, 3 pi] and fmodf reduces to at most
+// one exact subtraction (Sterbenz: a - b is exact for b <= a <= 2b) or, for negative a, the single rounded add of py_mod: the
+// three-way select below returns the same bits as the library call at a few instructions instead of a few hundred.
+// (phi is this file's own atan2f output, codec_abs_angle above; outside [-2 pi, 4 pi) the select would not be a remainder.)
+__device__ __forceinline__ float py_mod_2pi_near(float a) {
+  return a >= TWO_PI_F ? a - TWO_PI_F : (a < 0.f ? a + TWO_PI_F : a);
+}
+
+__device__ __forceinline__ float unwrap_adj(float cur, float prev) {
+  const float dphi = cur - prev;
+  float dm = py_mod_2pi_near(dphi + PI_F) - PI_F;
+  if (dm == -PI_F && dphi > 0.f) dm = PI_F;
+  float adj = dm - dphi;
+  if (fabsf(dphi) < PI_F) adj = 0.f;
+  return adj;
+}
+
+__global__ void __launch_bounds__(UNWRAP_THREADS) codec_unwrap_delta(const float* __restrict__ phi, float* __restrict__ delta,
+                                                          float* __restrict__ part, int T) {
+  extern __shared__ __attribute__((aligned(16))) float usm[];
+  float* phi_s = usm;               // [2][64][USTR]
+  float* adj_s = usm + 2 * UTILE;   // [2][64][USTR]
+  float* out_s = usm + 4 * UTILE;   // [2][64][USTR]
+  __shared__ float red[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k0 = blockIdx.x * 64;
+  const int ntile = (T - 1 + UT - 1) / UT;  // tile q covers frames t = 1 + 64 q + col
+  const bool scanner = wave == 0, loader = wave >= 1 && wave <= NLW, storer = wave > NLW;
+  // producer geometry: column = lane (coalesced along t), 16 rows each.  Three register sets keep tiles q+1 .. q+3 in flight
+  // (two full iterations of latency cover); phi[t-1] comes from the neighbour lane, for lane 0 from the previous tile's
+  // last column (kept in scalars)
+  const int pcol = lane, prow0 = loader ? (wave - 1) * RPL : (storer ? (wave - 1 - NLW) * 16 : 0);
+  float r0[RPL], r1[RPL], r2[RPL];
+  float lastcol[RPL];  // wave-uniform: column 63 of the tile staged last
   float mn = INFINITY, mx = -INFINITY;
-  // the recurrence is sequential, the loads are not: fetch 16 frames ahead so their latency overlaps the scan
-  constexpr int BLK = 16;
-  int t = 1;
-  for (; t + BLK <= T; t += BLK) {
-    float cur[BLK], out[BLK];
+
+  auto load_tile = [&](int q, float (&r)[RPL]) {
+    // unconditional (frames past the end re-read frame T-1; their adjustment is forced to 0 and their delta never stored):
+    // with divergent loads hipcc waits vmcnt(0) at every use and the three-tile prefetch collapses
+    const long long tq = 1ll + (long long)q * UT + pcol;
+    const int t = tq < T ? (int)tq : T - 1;
 #pragma unroll
-    for (int j = 0; j < BLK; ++j) cur[j] = p[t + j];
+    for (int i = 0; i < RPL; ++i) r[i] = phi[(size_t)(k0 + prow0 + i) * T + t];
+  };
+  auto stage_tile = [&](int q, const float (&r)[RPL]) {  // registers -> phi / adj tiles of buffer q & 1 (past the end: adj 0)
+    float* ph = phi_s + (q & 1) * UTILE;
+    float* ad = adj_s + (q & 1) * UTILE;
+    const bool ok = (1 + q * UT + pcol) < T;
 #pragma unroll
-    for (int j = 0; j < BLK; ++j) {
-      const float dphi = cur[j] - prev;
-      float dm = py_mod(dphi + PI_F, TWO_PI_F) - PI_F;
-      if (dm == -PI_F && dphi > 0.f) dm = PI_F;
-      float adj = dm - dphi;
-      if (fabsf(dphi) < PI_F) adj = 0.f;
-      c += adj;
-      const float u = cur[j] + c;
-      const float dl = u - prev_u;
-      out[j] = dl;
-      mn = fminf(mn, dl);
-      mx = fmaxf(mx, dl);
-      prev = cur[j];
-      prev_u = u;
+    for (int i = 0; i < RPL; ++i) {
+      const float left = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r[i]), 0x138, 0xf, 0xf, false));
+      const float prev = pcol == 0 ? lastcol[i] : left;
+      ph[(prow0 + i) * USTR + pcol] = r[i];
+      ad[(prow0 + i) * USTR + pcol] = ok ? unwrap_adj(r[i], prev) : 0.f;
+      lastcol[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r[i]), 63));
     }
+  };
+  auto store_tile = [&](int q) {  // finished delta tile -> global, coalesced along t; min/max on the way
+    const float* o = out_s + (q & 1) * UTILE;
+    const int t = 1 + q * UT + pcol;
+    if (t < T) {
 #pragma unroll
-    for (int j = 0; j < BLK; ++j) d[t - 1 + j] = out[j];
+      for (int i = 0; i < 16; ++i) {
+        const float v = o[(prow0 + i) * USTR + pcol];
+        delta[(size_t)(k0 + prow0 + i) * (T - 1) + (t - 1)] = v;
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+      }
+    }
+  };
+
+  float c = 0.f, prev_u = 0.f;  // scanner state of row k0 + lane: running sum of adjustments, previous unwrapped value
+  if (scanner) {
+    prev_u = phi[(size_t)(k0 + lane) * T];  // unwrapped[0] = phi[0]
+  } else if (loader) {
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) lastcol[i] = phi[(size_t)(k0 + prow0 + i) * T];  // phi[0]: left neighbour of frame 1
+    load_tile(0, r0);
+    load_tile(1, r1);
+    load_tile(2, r2);
+    stage_tile(0, r0);
+    load_tile(3, r0);
   }
-  for (; t < T; ++t) {
-    const float cur = p[t];
-    const float dphi = cur - prev;
-    float dm = py_mod(dphi + PI_F, TWO_PI_F) - PI_F;
-    if (dm == -PI_F && dphi > 0.f) dm = PI_F;
-    float adj = dm - dphi;
-    if (fabsf(dphi) < PI_F) adj = 0.f;
-    c += adj;
-    const float u = cur + c;
-    const float dl = u - prev_u;
-    d[t - 1] = dl;
-    mn = fminf(mn, dl);
-    mx = fmaxf(mx, dl);
-    prev = cur;
-    prev_u = u;
+  __syncthreads();
+  auto scan_tile = [&](int q) {
+    const float* ph = phi_s + (q & 1) * UTILE + lane * USTR;
+    const float* ad = adj_s + (q & 1) * UTILE + lane * USTR;
+    float* o = out_s + (q & 1) * UTILE + lane * USTR;
+#pragma unroll 4
+    for (int j = 0; j < UT; j += 4) {
+      const f32x4 pv = *reinterpret_cast<const f32x4*>(ph + j);
+      const f32x4 av = *reinterpret_cast<const f32x4*>(ad + j);
+      f32x4 ov;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        c += av[e];
+        const float u = pv[e] + c;
+        ov[e] = u - prev_u;
+        prev_u = u;
+      }
+      *reinterpret_cast<f32x4*>(o + j) = ov;
+    }
+  };
+  // iteration q: the scanner runs tile q; the storers write tile q-1; the loaders stage tile q+1 (registers loaded two
+  // iterations ago) and re-load that register set with tile q+4
+  auto iteration = [&](int q, float (&r)[RPL]) {
+    if (scanner) {
+      if (q < ntile) scan_tile(q);
+    } else if (loader) {
+      stage_tile(q + 1, r);
+      load_tile(q + 4, r);
+    } else {
+      if (q > 0 && q - 1 < ntile) store_tile(q - 1);
+    }
+    __syncthreads();
+  };
+  for (int q = 0; q < ntile; q += 3) {
+    iteration(q, r1);
+    iteration(q + 1, r2);
+    iteration(q + 2, r0);
   }
-  part[2 * k] = mn;
-  part[2 * k + 1] = mx;
+  if (storer) {
+    const int qe = ((ntile + 2) / 3) * 3;  // iterations run: tiles up to qe-2 are stored inside the loop
+    if (qe - 1 < ntile) store_tile(qe - 1);
+  }
+  block_minmax(mn, mx, red);
+  if (tid == 0) {
+    part[2 * blockIdx.x] = mn;
+    part[2 * blockIdx.x + 1] = mx;
+  }
 }
 
 // ---- tiny: reduce (min,max) pairs
@@ -289,9 +382,21 @@ extern "C" int mg_codec_fwd(const float* stft_c64, const float* bark_scale, floa
   if (gx > 64) gx = 64;
   hipLaunchKernelGGL(codec_abs_angle, dim3(gx, NB), dim3(256), 0, s, reinterpret_cast<const float2*>(stft_c64),
                      bark_scale, magn, phi, part_m, T);
-  hipLaunchKernelGGL(codec_unwrap_delta, dim3(NB / 64), dim3(64), 0, s, phi, delta, part_p, T);
+  static bool attr_set = false;  // benign race: idempotent
+  if (!attr_set) {
+    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&codec_unwrap_delta),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    if (ea != hipSuccess) {
+      mg_set_error("mg_codec_fwd: hipFuncSetAttribute: %s", hipGetErrorString(ea));
+      return MG_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  MG_CHECK_LAUNCH("mg_codec_fwd(abs_angle)");
+  hipLaunchKernelGGL(codec_unwrap_delta, dim3(NB / 64), dim3(UNWRAP_THREADS), UNWRAP_LDS, s, phi, delta, part_p, T);
+  MG_CHECK_LAUNCH("mg_codec_fwd(unwrap)");
   hipLaunchKernelGGL(minmax_final, dim3(1), dim3(256), 0, s, part_m, gx * NB, mm);
-  hipLaunchKernelGGL(minmax_final, dim3(1), dim3(256), 0, s, part_p, NB, mm + 2);
+  hipLaunchKernelGGL(minmax_final, dim3(1), dim3(256), 0, s, part_p, NB / 64, mm + 2);
   const int S = (T - 1) / nb_vec;
   const int rem = (T - 1) % nb_vec;
   const size_t total = (size_t)S * NB * nb_vec;
