@@ -272,28 +272,99 @@ __global__ void __launch_bounds__(256) inv_unbark(const float* __restrict__ mp, 
   }
 }
 
-// ---- inverse pass 2: per row, phase -> [-pi,pi], sequential cumulative sum, mod 2pi, polar -> complex spectrum Z[k][t]
-__global__ void __launch_bounds__(64) inv_phase_polar(const float* __restrict__ mp, const float* __restrict__ m_in,
-                                                      const float* __restrict__ mm, float2* __restrict__ Z, int N,
-                                                      int W) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= NB) return;
+// ---- inverse pass 2: phase image -> [-pi, pi], cumulative sum over time (functions.py:115-118, a Python loop == sequential
+// fp32 cumsum per frequency row), mod 2 pi, polar -> complex.  Only the running sum is serial: inv_phase_cumsum tiles it through
+// LDS exactly like codec_unwrap_delta (4 loader waves, ONE scanner wave with lane = row, 4 storer waves; loads and stores in
+// different waves) and writes the running phase; inv_polar then does the remainder / sincos / scaling on the whole chip.
+__global__ void __launch_bounds__(576) inv_phase_cumsum(const float* __restrict__ mp, float* __restrict__ acc_out, int N,
+                                                        int W) {
+  extern __shared__ __attribute__((aligned(16))) float usm[];
+  float* ph_s = usm;               // [2][64][USTR]
+  float* ac_s = usm + 2 * UTILE;   // [2][64][USTR]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k0 = blockIdx.x * 64;
   const int TT = N * W;
-  const float range = mm[1] - mm[0];
-  float acc = 0.f;
-  for (int t = 0; t < TT; ++t) {
+  const int ntile = (TT + UT - 1) / UT;  // tile q covers frames t = 64 q + col
+  const bool scanner = wave == 0, loader = wave >= 1 && wave <= 4, storer = wave >= 5;
+  const int pcol = lane, prow0 = ((wave - 1) & 3) * 16;
+  float r0[16], r1[16], r2[16];
+
+  auto load_tile = [&](int q, float (&r)[16]) {  // unconditional: frames past the end re-read the last frame (never stored)
+    const long long tq = (long long)q * UT + pcol;
+    const int t = tq < TT ? (int)tq : TT - 1;
     const int n = t / W, j = t - n * W;
-    const float v = mp[(((size_t)n * 2 + 1) * NB + k) * W + j];
-    const float ph = (v + 1.f) / 2.f * 2.f * PI_F - PI_F;
-    acc = (t == 0) ? ph : acc + ph;
-    const float pm = py_mod(acc, TWO_PI_F);
-    const float mag = m_in[(size_t)k * TT + t] / range;
-    Z[(size_t)k * TT + t] = make_float2(mag * cosf(pm), mag * sinf(pm));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = mp[(((size_t)n * 2 + 1) * NB + k0 + prow0 + i) * W + j];
+  };
+  auto stage_tile = [&](int q, const float (&r)[16]) {
+    float* ph = ph_s + (q & 1) * UTILE;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ph[(prow0 + i) * USTR + pcol] = (r[i] + 1.f) / 2.f * 2.f * PI_F - PI_F;
+  };
+  auto store_tile = [&](int q) {
+    const float* o = ac_s + (q & 1) * UTILE;
+    const int t = q * UT + pcol;
+    if (t < TT) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc_out[(size_t)(k0 + prow0 + i) * TT + t] = o[(prow0 + i) * USTR + pcol];
+    }
+  };
+  float acc = 0.f;
+  if (loader) {
+    load_tile(0, r0);
+    load_tile(1, r1);
+    load_tile(2, r2);
+    stage_tile(0, r0);
+    load_tile(3, r0);
+  }
+  __syncthreads();
+  auto scan_tile = [&](int q) {
+    const float* ph = ph_s + (q & 1) * UTILE + lane * USTR;
+    float* o = ac_s + (q & 1) * UTILE + lane * USTR;
+#pragma unroll 4
+    for (int j = 0; j < UT; j += 4) {
+      const f32x4 pv = *reinterpret_cast<const f32x4*>(ph + j);
+      f32x4 ov;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc = (q == 0 && j == 0 && e == 0) ? pv[e] : acc + pv[e];  // the first frame STARTS the sum (keeps a -0.0 phase as it is)
+        ov[e] = acc;
+      }
+      *reinterpret_cast<f32x4*>(o + j) = ov;
+    }
+  };
+  auto iteration = [&](int q, float (&r)[16]) {
+    if (scanner) {
+      if (q < ntile) scan_tile(q);
+    } else if (loader) {
+      stage_tile(q + 1, r);
+      load_tile(q + 4, r);
+    } else {
+      if (q > 0 && q - 1 < ntile) store_tile(q - 1);
+    }
+    __syncthreads();
+  };
+  for (int q = 0; q < ntile; q += 3) {
+    iteration(q, r1);
+    iteration(q + 1, r2);
+    iteration(q + 2, r0);
+  }
+  if (storer) {
+    const int qe = ((ntile + 2) / 3) * 3;
+    if (qe - 1 < ntile) store_tile(qe - 1);
   }
 }
 
-// ---- inverse pass 3: per frame, 1024-point inverse real FFT (Nyquist bin = 0) times window * sqrt(sum w^2).
-// Plain O(N log N) radix-2 in LDS, one workgroup per frame: the inverse path is tiny (generate: a few thousand frames).
+__global__ void __launch_bounds__(256) inv_polar(const float* __restrict__ acc, const float* __restrict__ m_in,
+                                                 const float* __restrict__ mm, float2* __restrict__ Z, size_t total) {
+  const float range = mm[1] - mm[0];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const float pm = py_mod(acc[i], TWO_PI_F);
+    const float mag = m_in[i] / range;
+    Z[i] = make_float2(mag * cosf(pm), mag * sinf(pm));
+  }
+}
+
 __global__ void __launch_bounds__(256) inv_frames(const float2* __restrict__ Z, float* __restrict__ frames, int TT) {
   __shared__ float2 buf[NFFT];
   const int t = blockIdx.x;
@@ -434,7 +505,24 @@ extern "C" int mg_codec_inv(const float* magn_phase, const float* bark_scale, fl
   if (gx > 64) gx = 64;
   hipLaunchKernelGGL(inv_unbark, dim3(gx, NB), dim3(256), 0, s, magn_phase, bark_scale, m, part, N, W);
   hipLaunchKernelGGL(minmax_final, dim3(1), dim3(256), 0, s, part, gx * NB, mm);
-  hipLaunchKernelGGL(inv_phase_polar, dim3(NB / 64), dim3(64), 0, s, magn_phase, m, mm, Z, N, W);
+  static bool attr_set = false;  // benign race: idempotent
+  if (!attr_set) {
+    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&inv_phase_cumsum),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    if (ea != hipSuccess) {
+      mg_set_error("mg_codec_inv: hipFuncSetAttribute: %s", hipGetErrorString(ea));
+      return MG_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  float* run = frames;  // running phase [NB][TT]: borrows the frame buffer (TT*1024 floats), which inv_frames fills afterwards
+  hipLaunchKernelGGL(inv_phase_cumsum, dim3(NB / 64), dim3(576), (size_t)4 * UTILE * sizeof(float), s, magn_phase, run, N, W);
+  {
+    const size_t total = (size_t)NB * TT;
+    int pb = (int)((total + 255) / 256);
+    if (pb > 8192) pb = 8192;
+    hipLaunchKernelGGL(inv_polar, dim3(pb), dim3(256), 0, s, run, m, mm, Z, total);
+  }
   hipLaunchKernelGGL(inv_frames, dim3(TT), dim3(256), 0, s, Z, frames, TT);
   const long long out_len = (long long)HOP * (TT - 1);
   int blocks = (int)((out_len + 255) / 256);
