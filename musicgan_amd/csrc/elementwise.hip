@@ -2,6 +2,8 @@
 // pooling (both directions), LeakyReLU backward, fade-in blends, Linear(160->1), gradient-penalty helpers, fused Adam.
 // Reference ops: /root/reference/music_gan/networks/layers.py:11-17, generator.py:26-29,124, discriminator.py:24,103-124,
 // 166-184, train.py:64-70.  One thread owns 4 consecutive floats wherever the shape allows (16-byte accesses).
+#include <cstdlib>
+
 #include "mg_common.h"
 
 namespace {
@@ -105,6 +107,40 @@ __global__ void __launch_bounds__(256) pixelnorm_lrelu_bwd_k(const float* __rest
       for (int v = 0; v < V; ++v) o[v] = mg_lrelu_mask(t[v], slope) * r[v] * (g[v] - t[v] * pr[v] * dot[v]);
       st<V>(gpre + base + (size_t)c * HW, o);
     }
+  }
+}
+
+// Same arithmetic, one HBM pass instead of two over gp and y: the first sweep parks both in LDS (a thread only ever reads back
+// its own column: no barrier, no bank conflict -- LDS as a second register file), the second sweep works from there.
+// Large maps only (the loop-free form needs one pixel per thread); NT threads x C channels x 8 B of LDS.
+template <int NT>
+__global__ void __launch_bounds__(NT) pixelnorm_lrelu_bwd_lds_k(const float* __restrict__ gp, const float* __restrict__ y,
+                                                                const float* __restrict__ rn, float* __restrict__ gpre, int N,
+                                                                int C, int HW, float slope, int from_p) {
+  extern __shared__ __attribute__((aligned(16))) float park[];  // [2][C][NT]
+  float* gs = park;
+  float* ts = park + (size_t)C * NT;
+  const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+  const size_t total = (size_t)N * HW;
+  if (i >= total) return;
+  const int n = (int)(i / HW);
+  const int px = (int)(i - (size_t)n * HW);
+  const size_t base = (size_t)n * C * HW + px;
+  const float r = rn[(size_t)n * HW + px];
+  const float pr = from_p ? 1.f : r;
+  float dot = 0.f;
+#pragma unroll 8
+  for (int c = 0; c < C; ++c) {
+    const float g = gp[base + (size_t)c * HW], t = y[base + (size_t)c * HW];
+    gs[c * NT + threadIdx.x] = g;
+    ts[c * NT + threadIdx.x] = t;
+    dot = fmaf(g, t * pr, dot);
+  }
+  dot /= (float)C;
+#pragma unroll 8
+  for (int c = 0; c < C; ++c) {
+    const float g = gs[c * NT + threadIdx.x], t = ts[c * NT + threadIdx.x];
+    gpre[base + (size_t)c * HW] = mg_lrelu_mask(t, slope) * r * (g - t * pr * dot);
   }
 }
 
@@ -397,6 +433,26 @@ extern "C" int mg_pixelnorm_fwd(const float* y, float* p, float* rn, int N, int 
 extern "C" int mg_pixelnorm_lrelu_bwd(const float* gp, const float* y, const float* rn, float* gpre, int N, int C, int HW,
                                       float slope, int from_p, mg_stream_t stream) {
   MG_CHECK_ARG(gp && y && rn && gpre && N > 0 && C > 0 && HW > 0, "mg_pixelnorm_lrelu_bwd: bad arguments");
+  const size_t px_total = (size_t)N * HW;
+  if (px_total >= (size_t)4096 && C <= 128 && getenv("MG_PN_BWD_NOLDS") == nullptr) {
+    static bool attr_set = false;  // benign race: idempotent
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pixelnorm_lrelu_bwd_lds_k<256>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pixelnorm_lrelu_bwd_lds_k<128>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    if (C <= 64) {
+      hipLaunchKernelGGL(pixelnorm_lrelu_bwd_lds_k<256>, dim3((unsigned)((px_total + 255) / 256)), dim3(256),
+                         (size_t)2 * C * 256 * sizeof(float), (hipStream_t)stream, gp, y, rn, gpre, N, C, HW, slope, from_p);
+    } else {
+      hipLaunchKernelGGL(pixelnorm_lrelu_bwd_lds_k<128>, dim3((unsigned)((px_total + 127) / 128)), dim3(128),
+                         (size_t)2 * C * 128 * sizeof(float), (hipStream_t)stream, gp, y, rn, gpre, N, C, HW, slope, from_p);
+    }
+    MG_CHECK_LAUNCH("mg_pixelnorm_lrelu_bwd");
+    return MG_OK;
+  }
   if ((HW & 3) == 0)
     EW_LAUNCH(pixelnorm_lrelu_bwd_k<4>, ew_grid((size_t)N * HW / 4), 256, gp, y, rn, gpre, N, C, HW, slope, from_p);
   else EW_LAUNCH(pixelnorm_lrelu_bwd_k<1>, ew_grid((size_t)N * HW), 256, gp, y, rn, gpre, N, C, HW, slope, from_p);

@@ -465,3 +465,21 @@ def test_blend_lrelu_bwd_equals_the_four_kernels_it_replaces():
     gr4, a4, o4 = gr.reshape(-1)[:628], a.reshape(-1)[:628].clone(), o.reshape(-1)[:628].clone()  # vector path (n % 4 == 0)
     oa, oo = ops.blend_lrelu_bwd(gr4.clone(), a4, o4, 0.5, 0.5)
     assert torch.equal(oa, ops.lrelu_bwd(ops.axpby(0.5, gr4.clone()), a4))
+
+
+@pytest.mark.parametrize("shape", [(33, 48, 64, 64), (9, 112, 128, 128), (8, 64, 130, 126)])
+def test_pixelnorm_bwd_lds_path_is_bitwise_the_two_pass_kernel(shape, monkeypatch):
+    """Large maps take the single-HBM-pass form (operands parked in LDS): same arithmetic in the same order as the two-pass
+    kernel, so the outputs must be bit-identical -- both for C <= 64 (256 threads) and C > 64 (128 threads), ragged last block."""
+    ops = _ops()
+    n, c, h, w = shape
+    g = torch.Generator(device=DEV).manual_seed(51)
+    gp = torch.randn(n, c, h, w, device=DEV, generator=g)
+    p = torch.randn(n, c, h, w, device=DEV, generator=g)
+    rn = torch.rand(n, 1, h, w, device=DEV, generator=g) + 0.5
+    for from_p in (False, True):
+        monkeypatch.delenv("MG_PN_BWD_NOLDS", raising=False)
+        a = ops.pixelnorm_lrelu_bwd(gp, p, rn, from_p=from_p)
+        monkeypatch.setenv("MG_PN_BWD_NOLDS", "1")
+        b = ops.pixelnorm_lrelu_bwd(gp, p, rn, from_p=from_p)
+        assert torch.equal(a, b)
