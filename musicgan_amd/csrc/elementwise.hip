@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256) pixelnorm_lrelu_bwd_k(const float* __rest
 
 // Same arithmetic, one HBM pass instead of two over gp and y: the first sweep parks both in LDS (a thread only ever reads back
 // its own column: no barrier, no bank conflict -- LDS as a second register file), the second sweep works from there.
-// Large maps only (the loop-free form needs one pixel per thread); NT threads x C channels x 8 B of LDS.
+// One pixel per thread; NT threads x C channels x 8 B of LDS (C <= 128; wider layers keep the two-pass kernel).
 template <int NT>
 __global__ void __launch_bounds__(NT) pixelnorm_lrelu_bwd_lds_k(const float* __restrict__ gp, const float* __restrict__ y,
                                                                 const float* __restrict__ rn, float* __restrict__ gpre, int N,
@@ -434,7 +434,7 @@ extern "C" int mg_pixelnorm_lrelu_bwd(const float* gp, const float* y, const flo
                                       float slope, int from_p, mg_stream_t stream) {
   MG_CHECK_ARG(gp && y && rn && gpre && N > 0 && C > 0 && HW > 0, "mg_pixelnorm_lrelu_bwd: bad arguments");
   const size_t px_total = (size_t)N * HW;
-  if (px_total >= (size_t)4096 && C <= 128 && getenv("MG_PN_BWD_NOLDS") == nullptr) {
+  if (C <= 128 && getenv("MG_PN_BWD_NOLDS") == nullptr) {  // up to 128 KB of LDS per workgroup
     static bool attr_set = false;  // benign race: idempotent
     if (!attr_set) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pixelnorm_lrelu_bwd_lds_k<256>),
