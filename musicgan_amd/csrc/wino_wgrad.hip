@@ -233,28 +233,28 @@ __global__ void __launch_bounds__(512) wino_wgrad_mfma(const WwArgs a) {
   if (cb == 0 && t == 0 && chs < OT * 16 && o0 + chs < a.CoutP) a.slab_b[(size_t)split * a.CoutP + o0 + chs] = bsum;
 }
 
-// Sum the split-K slabs in a fixed order and apply  dW = G^T M G.  Block = 64 consecutive (c, o) pairs x 4 split-lanes (each lane
-// sums every 4th split), LDS-combined as ((l0 + l1) + (l2 + l3)) => deterministic.  Component slots per row: [nu0, nu3, nu1, nu2].
-__global__ void __launch_bounds__(256) wino_wgrad_reduce(const float* __restrict__ slab, const float* __restrict__ slab_b, int nsplit,
-                                                         float* __restrict__ gw, float* __restrict__ gb, int Cout, int Cin,
-                                                         int CoutP, int CinP, int accumulate) {
+// Sum the split-K slabs in a fixed order and apply  dW = G^T M G.  Block = 64 consecutive (c, o) pairs x 4 split-lanes x 4
+// component groups (a thread sums every 4th split of 4 components: 1024 threads keep enough loads in flight for what is a pure
+// latency problem), LDS-combined as ((l0 + l1) + (l2 + l3)) => deterministic.  Component slots per row: [nu0, nu3, nu1, nu2].
+__global__ void __launch_bounds__(1024) wino_wgrad_reduce(const float* __restrict__ slab, const float* __restrict__ slab_b, int nsplit,
+                                                          float* __restrict__ gw, float* __restrict__ gb, int Cout, int Cin,
+                                                          int CoutP, int CinP, int accumulate) {
   __shared__ float red[4][16][64];
-  const int el = threadIdx.x & 63, kl = threadIdx.x >> 6;
+  const int el = threadIdx.x & 63, kl = (threadIdx.x >> 6) & 3, cg = threadIdx.x >> 8;
   const int e = blockIdx.x * 64 + el;  // e = c * CoutP + o over the padded block
   const int total = CinP * CoutP;
-  float m[16];
-#pragma unroll
-  for (int s = 0; s < 16; ++s) m[s] = 0.f;
+  float m[4] = {0.f, 0.f, 0.f, 0.f};
   if (e < total) {
     for (int k = kl; k < nsplit; k += 4) {
-      const float* src = slab + (size_t)k * 16 * total + e;
+      const float* src = slab + ((size_t)k * 16 + cg * 4) * total + e;
 #pragma unroll
-      for (int s = 0; s < 16; ++s) m[s] += src[(size_t)s * total];
+      for (int s = 0; s < 4; ++s) m[s] += src[(size_t)s * total];
     }
   }
 #pragma unroll
-  for (int s = 0; s < 16; ++s) red[kl][s][el] = m[s];
+  for (int s = 0; s < 4; ++s) red[kl][cg * 4 + s][el] = m[s];
   __syncthreads();
+  if (cg != 0) return;
   if (kl != 0 || e >= total) return;
   const int c = e / CoutP, o = e % CoutP;
   float M[4][4];  // [xi][nu]
@@ -400,7 +400,7 @@ extern "C" int mg_wino3x3_wgrad(const float* x, const float* gy, float* gw, floa
   }
   if (rc != MG_OK) return rc;
   const int total = a.CinP * a.CoutP;
-  hipLaunchKernelGGL(wino_wgrad_reduce, dim3(mg_cdiv(total, 64)), dim3(256), 0, s, a.slab, a.slab_b, pl.nsplit, gw, gb, Cout, Cin,
+  hipLaunchKernelGGL(wino_wgrad_reduce, dim3(mg_cdiv(total, 64)), dim3(1024), 0, s, a.slab, a.slab_b, pl.nsplit, gw, gb, Cout, Cin,
                      a.CoutP, a.CinP, accumulate);
   MG_CHECK_LAUNCH("mg_wino3x3_wgrad(reduce)");
   return MG_OK;
