@@ -185,6 +185,13 @@ size_t mg_codec_inv_ws_bytes(int N, int W);
 int mg_codec_inv(const float* magn_phase, const float* bark_scale, float* wav_out, void* ws, size_t ws_bytes, int N, int W,
                  mg_stream_t stream);
 
+/* Per-batch input transform of the training loop, fused: ChannelMinMaxNorm -> ChangeRange(-1,1) -> Resize(S) (bilinear with
+ * anti-aliasing, align_corners = False: torchvision's tensor path) [audio/transforms.py:4-40, utils.py:70-86, train.py:138-140].
+ * x (N,2,H,W) float64 (x_is_f64 != 0: cast to float32 on read, == x.to(th.float)) or float32; out (N,2,S,S) float32, S <= H, W. */
+size_t mg_input_transform_ws_bytes(int N, int H, int W, int S);
+int mg_input_transform(const void* x, int x_is_f64, float* out, void* ws, size_t ws_bytes, int N, int H, int W, int S, float eps,
+                       mg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,8 @@ SIGNATURES = {
     "mg_gp_finish": (c_int, [_P, _P, _P, c_int, c_float, c_float, _P]),
     "mg_channel_sum": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "mg_adam_step": (c_int, [_P, c_int, c_float, c_float, c_float, c_float, _P]),
+    "mg_input_transform_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "mg_input_transform": (c_int, [_P, c_int, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_float, _P]),
     "mg_stft_1024": (c_int, [_P, _P, _P, c_int64, _P]),
     "mg_codec_fwd_ws_bytes": (c_size_t, [c_int]),
     "mg_codec_fwd": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, _P]),

@@ -424,3 +424,18 @@ def codec_inv(magn_phase: torch.Tensor, bark_scale: torch.Tensor) -> torch.Tenso
     wav = torch.empty((256 * (n * w - 1),), dtype=torch.float32, device=magn_phase.device)
     check(lib.mg_codec_inv(_p(magn_phase), _p(bark_scale), _p(wav), _p(ws), ws.numel(), n, w, _s()), "mg_codec_inv")
     return wav
+
+
+# ------------------------------------------------------------------ input transform (Grower)
+def input_transform(x: torch.Tensor, side: int, eps: float = 1e-8) -> torch.Tensor:
+    """ChannelMinMaxNorm -> ChangeRange(-1, 1) -> Resize(side) of a (N, 2, H, W) float64 / float32 batch, one fused pass on the
+    device (audio/transforms.py + utils.Grower of the reference, which run per batch on the CPU)."""
+    assert x.is_cuda and x.dim() == 4 and x.shape[1] == 2 and x.is_contiguous()
+    assert x.dtype in (torch.float64, torch.float32)
+    n, _, h, w = x.shape
+    lib = _lib.load()
+    out = torch.empty((n, 2, side, side), dtype=torch.float32, device=x.device)
+    ws = workspace(lib.mg_input_transform_ws_bytes(n, h, w, side), x.device)
+    check(lib.mg_input_transform(_p(x), int(x.dtype == torch.float64), _p(out), _p(ws), ws.numel(), n, h, w, side, eps, _s()),
+          "mg_input_transform")
+    return out

@@ -122,8 +122,8 @@ def train(run_name: str, input_dataset_path: str, output_dir: str, *, nb_epoch: 
             sampler.set_epoch(e)
         bar = tqdm(data_loader) if rank == 0 else data_loader
         for x_real in bar:
-            # float64 -> float32, per-channel min-max to [-1,1], resize to the current resolution: on the GPU
-            x_real = grower.scale_transform(x_real.to(device, th.float, non_blocking=True)).contiguous()
+            # float64 -> float32, per-channel min-max to [-1,1], resize to the current resolution: one fused pass on the GPU
+            x_real = grower.transform_batch(x_real.to(device, non_blocking=True))
             alpha = grower.alpha
             d = stepper.d_step(x_real, alpha)
             g = None

@@ -82,6 +82,14 @@ class Grower:
     def scale_transform(self) -> _Compose:
         return self.__transform
 
+    def transform_batch(self, x: th.Tensor) -> th.Tensor:
+        """`scale_transform(x.to(th.float))` of train.py:139-140.  A batch that already sits on the GPU (float64 as the dataset
+        stores it, or float32) goes through the fused kernel (ops.input_transform); a CPU batch takes the tensor expressions."""
+        if x.is_cuda:
+            from . import ops
+            return ops.input_transform(x.contiguous(), 512 // 2 ** self.__downscale)
+        return self.__transform(x.to(th.float))
+
     def state_dict(self):
         return {"curr_grow": self.__curr_grow, "sample_idx": self.__sample_idx,
                 "step_sample_idx": self.__step_sample_idx, "downscale": self.__downscale}

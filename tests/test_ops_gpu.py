@@ -483,3 +483,23 @@ def test_pixelnorm_bwd_lds_path_is_bitwise_the_two_pass_kernel(shape, monkeypatc
         monkeypatch.setenv("MG_PN_BWD_NOLDS", "1")
         b = ops.pixelnorm_lrelu_bwd(gp, p, rn, from_p=from_p)
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("case", [(3, 512, 128, torch.float64), (2, 512, 4, torch.float64), (2, 512, 512, torch.float32),
+                                  (2, 96, 32, torch.float64), (1, 100, 30, torch.float32), (2, 512, 64, torch.float32)])
+def test_input_transform_matches_the_tensor_expressions(case):
+    """mg_input_transform == ChannelMinMaxNorm -> ChangeRange(-1,1) -> Resize(S) evaluated by torch on the CPU (Resize = the
+    bilinear + antialias interpolate torchvision's tensor path calls), for every growth level's scale and a non-power-of-two one."""
+    ops = _ops()
+    from musicgan_amd import audio
+    n, hw, side, dt = case
+    g = torch.Generator().manual_seed(61)
+    x = (torch.rand(n, 2, hw, hw, generator=g, dtype=torch.float64) * 7 - 2).to(dt)
+    x[0, 1] *= 1e-3  # a channel with a very different range
+    xf = x.to(torch.float32)
+    ref = audio.ChangeRange(-1.0, 1.0)(audio.ChannelMinMaxNorm()(xf))
+    if side != hw:
+        ref = F.interpolate(ref, size=(side, side), mode="bilinear", antialias=True, align_corners=False)
+    got = ops.input_transform(x.to(DEV), side)
+    assert got.dtype == torch.float32 and tuple(got.shape) == (n, 2, side, side)
+    report("input transform", got, ref.double(), 3e-6)
