@@ -119,7 +119,10 @@ __global__ void __launch_bounds__(64 * WT * WC, 2) wino3x3_mfma(const WinoArgs a
 #pragma unroll
   for (int c = 0; c < 16; ++c)
 #pragma unroll
-    for (int ni = 0; ni < NIW; ++ni) acc[c][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ni = 0; ni < NIW; ++ni) {  // cleared with 64-bit moves: fp32 MFMA and VALU time add up on gfx950, every VALU counts
+      typedef double f64x2 __attribute__((ext_vector_type(2)));
+      acc[c][ni] = __builtin_bit_cast(f32x4, f64x2{0.0, 0.0});
+    }
 
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   f32x2 rP[NITEM][4];
@@ -237,7 +240,8 @@ __global__ void __launch_bounds__(64 * WT * WC, 2) wino3x3_mfma(const WinoArgs a
   // A^T M A + bias + LeakyReLU of out-channel tile ni -> on[g][2*i + j: pixel (i, j) of the lane's 2x2 tile].  The accumulator
   // of Winograd component (xi, nu) is acc[4*xi + slot(nu)] with slots [nu0, nu3, nu1, nu2] (see store_chunk); all math runs on
   // the f32x4 accumulators (g = 4 out-channels) so it packs.
-  auto transform = [&](int ni, float (&on)[4][4]) {
+  auto transform = [&](int ni, float (&on)[4][4], auto act_) {
+    constexpr bool ACT = decltype(act_)::value;  // bias + LeakyReLU present (forward paths)
     f32x4 bv4;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -259,10 +263,15 @@ __global__ void __launch_bounds__(64 * WT * WC, 2) wino3x3_mfma(const WinoArgs a
     r4[3] = (s1[1] - s1[2]) - s1[3];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f32x4 v = r4[q] + bv4;
-      const f32x4 w = v * slope_eff;  // 0 < slope <= 1: leaky_relu(v) == max(v, slope*v)
+      if constexpr (ACT) {
+        const f32x4 v = r4[q] + bv4;
+        const f32x4 w = v * slope_eff;  // 0 < slope <= 1: leaky_relu(v) == max(v, slope*v)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) on[g][q] = fmaxf(v[g], w[g]);
+        for (int g = 0; g < 4; ++g) on[g][q] = fmaxf(v[g], w[g]);
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) on[g][q] = r4[q][g];
+      }
     }
   };
   // one specialised copy of the store loop per epilogue kind, selected once (no flag tests inside the unrolled loops).
@@ -339,10 +348,12 @@ __global__ void __launch_bounds__(64 * WT * WC, 2) wino3x3_mfma(const WinoArgs a
   // no PixelNorm: one out-channel tile at a time (16 live outputs)
   auto tail = [&](auto mask_, auto pool_) {
     const float one[4] = {1.f, 1.f, 1.f, 1.f};
+    constexpr bool MASKED = decltype(mask_)::value;
 #pragma unroll
     for (int ni = 0; ni < NIW; ++ni) {
       float on[4][4];
-      transform(ni, on);
+      if (MASKED && a.bias == nullptr) transform(ni, on, std::false_type{});  // MASK_AUX excludes LRELU; no bias: plain A^T M A
+      else transform(ni, on, std::true_type{});
       store_tile(ni, on, one, mask_, std::false_type{}, pool_, std::true_type{});
     }
   };
@@ -350,7 +361,7 @@ __global__ void __launch_bounds__(64 * WT * WC, 2) wino3x3_mfma(const WinoArgs a
   auto tail_pn = [&](auto hasy_) {
     float o[NIW][4][4];
 #pragma unroll
-    for (int ni = 0; ni < NIW; ++ni) transform(ni, o[ni]);
+    for (int ni = 0; ni < NIW; ++ni) transform(ni, o[ni], std::true_type{});
     float rnv[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {  // padded out-channels hold exact zeros (zero filters, no bias) and add nothing
