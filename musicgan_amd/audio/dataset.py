@@ -1,24 +1,31 @@
-"""Dataset of `magn_phase_{idx}.pt` tensors written by create_dataset (/root/reference/music_gan/audio/dataset.py:14-44)."""
-import re
-from os import listdir
-from os.path import isdir, isfile, join
+"""Map-style dataset over the tensors create_dataset writes (interface of /root/reference/music_gan/audio/dataset.py:14-44:
+`AudioDataset(dataset_path)`, items are the float64 (2, 512, 512) tensors of `magn_phase_{idx}.pt`, in file-name order)."""
+import fnmatch
+import os
 
-import numpy as np
-import torch as th
+import torch
 from torch.utils.data import Dataset
+
+_PATTERN = "magn_phase_*.pt"
+
+
+def _sample_files(folder: str):
+    with os.scandir(folder) as it:
+        names = [e.name for e in it if e.is_file() and fnmatch.fnmatchcase(e.name, _PATTERN)
+                 and e.name[len("magn_phase_"):-len(".pt")].isdigit()]
+    names.sort()  # plain string order, as the reference sorts them
+    return tuple(names)
 
 
 class AudioDataset(Dataset):
     def __init__(self, dataset_path: str) -> None:
         super().__init__()
-        assert isdir(dataset_path)
-        pattern = re.compile(r"^magn_phase_\d+\.pt$")
-        files = [f for f in listdir(dataset_path) if isfile(join(dataset_path, f)) and pattern.match(f)]
-        self.__all_files = np.array(sorted(files))
-        self.__dataset_path = dataset_path
+        assert os.path.isdir(dataset_path)
+        self._root = dataset_path
+        self._names = _sample_files(dataset_path)
 
-    def __getitem__(self, index: int):
-        return th.load(join(self.__dataset_path, self.__all_files[index]))
+    def __len__(self) -> int:
+        return len(self._names)
 
-    def __len__(self):
-        return len(self.__all_files)
+    def __getitem__(self, index: int) -> torch.Tensor:
+        return torch.load(os.path.join(self._root, self._names[index]))

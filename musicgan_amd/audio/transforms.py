@@ -1,25 +1,29 @@
-"""Input transforms with the reference's semantics (/root/reference/music_gan/audio/transforms.py:4-40); element-wise host-side
-tensor expressions that work on whatever device the batch lives on."""
-import torch as th
+"""The two element-wise transforms of the input pipeline, interface of /root/reference/music_gan/audio/transforms.py:4-40.
+Plain tensor expressions that run wherever the batch lives; the training loop itself goes through the fused device kernel
+(`Grower.transform_batch` -> ops.input_transform), which evaluates the same formulas."""
+import torch
 
 
 class ChannelMinMaxNorm:
-    def __init__(self, epsilon: float = 1e-8):
-        self.__epsilon = epsilon
+    """(N, 2, H, W) -> each channel of each item mapped to [0, 1): (x - min) / (max - min + epsilon)."""
 
-    def __call__(self, x: th.Tensor) -> th.Tensor:
-        assert len(x.size()) == 4
-        assert x.size()[1] == 2
-        flat = x.reshape(x.size()[0], 2, -1)
-        x_max = flat.amax(dim=-1).view(-1, 2, 1, 1)
-        x_min = flat.amin(dim=-1).view(-1, 2, 1, 1)
-        return (x - x_min) / (x_max - x_min + self.__epsilon)
+    def __init__(self, epsilon: float = 1e-8):
+        self._eps = float(epsilon)
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        assert x.dim() == 4, f"expected (N, 2, H, W), got {tuple(x.shape)}"
+        assert x.shape[1] == 2, f"expected 2 channels (magnitude, phase), got {x.shape[1]}"
+        lo, hi = torch.aminmax(x.flatten(2), dim=2)
+        lo, hi = lo[..., None, None], hi[..., None, None]
+        return (x - lo) / (hi - lo + self._eps)
 
 
 class ChangeRange:
-    def __init__(self, lower_bond: float, upper_bound: float):
-        self.__range = upper_bound - lower_bond
-        self.__start = lower_bond
+    """[0, 1] -> [lower_bond, upper_bound] (the reference's argument spelling is part of the interface)."""
 
-    def __call__(self, x: th.Tensor) -> th.Tensor:
-        return x * self.__range + self.__start
+    def __init__(self, lower_bond: float, upper_bound: float):
+        self._offset = lower_bond
+        self._span = upper_bound - lower_bond
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        return x * self._span + self._offset

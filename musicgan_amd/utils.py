@@ -1,123 +1,123 @@
-"""Progressive-growing schedule and checkpoint writer with the reference's interfaces
-(/root/reference/music_gan/utils.py:14-86 Grower, :89-242 Saver).  Host-side bookkeeping, not part of the accelerated path."""
+"""Host-side bookkeeping of the training driver with the reference's interfaces: the progressive-growing schedule
+(`Grower`, /root/reference/music_gan/utils.py:14-86) and the checkpoint writer (`Saver`, :89-242).  Neither is part of the
+accelerated path; what is -- the per-batch input transform the schedule selects -- is reached through `transform_batch`."""
 from __future__ import annotations
 
-from os.path import join
-from typing import List
+import itertools
+import os
+from typing import Callable, List, Optional, Sequence
 
-import torch as th
+import torch
 import torch.nn.functional as F
 
 from . import audio
 from .networks import Discriminator, Generator
 
-
-class _Resize:
-    """Stand-in for torchvision.transforms.Resize(int) on (N,C,H,W) square tensors (utils.py:76-80): bilinear with
-    anti-aliasing (torchvision's current tensor default; the reference leaves the version unpinned)."""
-
-    def __init__(self, size: int):
-        self.size = size
-
-    def __call__(self, x: th.Tensor) -> th.Tensor:
-        if x.shape[-1] == self.size and x.shape[-2] == self.size:
-            return x
-        return F.interpolate(x, size=(self.size, self.size), mode="bilinear", antialias=True, align_corners=False)
+_FULL_SIDE = 512        # side of a stored sample
+_FIRST_DOWNSCALE = 7    # level 0 trains on 512 / 2**7 = 4 x 4 images
 
 
-class _Compose:
-    def __init__(self, fns):
-        self.fns = fns
+class _InputPipeline:
+    """ChannelMinMaxNorm -> ChangeRange(-1, 1) -> Resize(side) as tensor expressions (any device).  Resize stands in for
+    torchvision.transforms.Resize(int) on square (N, C, H, W) tensors: bilinear with anti-aliasing, torchvision's tensor
+    default (the reference leaves the version unpinned, utils.py:76-80)."""
 
-    def __call__(self, x):
-        for f in self.fns:
-            x = f(x)
-        return x
+    def __init__(self, side: int):
+        self.side = side
+        self._norm = audio.ChannelMinMaxNorm()
+        self._range = audio.ChangeRange(-1.0, 1.0)
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        y = self._range(self._norm(x))
+        if y.shape[-2:] != (self.side, self.side):
+            y = F.interpolate(y, size=(self.side, self.side), mode="bilinear", antialias=True, align_corners=False)
+        return y
 
 
 class Grower:
-    def __init__(self, n_grow: int, fadein_lengths: List[int], train_lengths: List[int]):
-        self.__curr_grow = 0
-        self.__n_grow = n_grow
-        self.__sample_idx = 0
-        self.__step_sample_idx = 0
-        self.__downscale = 7
-        self.__transform = Grower.__get_transform(self.__downscale)
-        assert len(fadein_lengths) == self.__n_grow + 1
-        assert len(train_lengths) == self.__n_grow
-        self.__fadein_l = fadein_lengths
-        acc, cum = 0, []
-        for t in train_lengths:
-            acc += t
-            cum.append(acc)
-        self.__train_l = cum
+    """Decides when the networks grow and how far the fade-in has progressed, from the number of samples seen.
 
+    `fadein_lengths[k]` samples blend level k in (alpha rises linearly to 1); level k ends once the cumulated
+    `train_lengths[:k + 1]` samples have been seen."""
+
+    def __init__(self, n_grow: int, fadein_lengths: List[int], train_lengths: List[int]):
+        assert len(fadein_lengths) == n_grow + 1
+        assert len(train_lengths) == n_grow
+        self._levels = n_grow
+        self._fade = list(fadein_lengths)
+        self._level_end = list(itertools.accumulate(train_lengths))
+        self._state = {"curr_grow": 0, "sample_idx": 0, "step_sample_idx": 0, "downscale": _FIRST_DOWNSCALE}
+        self._pipeline = _InputPipeline(self._side())
+
+    def _side(self) -> int:
+        return _FULL_SIDE // 2 ** self._state["downscale"]
+
+    # ---- schedule
     def grow(self, viewed_samples: int) -> bool:
-        self.__sample_idx += viewed_samples
-        self.__step_sample_idx += viewed_samples
-        if self.__curr_grow >= self.__n_grow:
+        st = self._state
+        st["sample_idx"] += viewed_samples
+        st["step_sample_idx"] += viewed_samples
+        level = st["curr_grow"]
+        if level >= self._levels or self._level_end[level] >= st["sample_idx"]:
             return False
-        if self.__train_l[self.__curr_grow] < self.__sample_idx:
-            self.__step_sample_idx = 0
-            self.__curr_grow += 1
-            self.__downscale -= 1
-            self.__transform = Grower.__get_transform(self.__downscale)
-            return True
-        return False
+        st.update(curr_grow=level + 1, step_sample_idx=0, downscale=st["downscale"] - 1)
+        self._pipeline = _InputPipeline(self._side())
+        return True
 
     @property
     def alpha(self) -> float:
-        return min(1., (1. + self.__step_sample_idx) / self.__fadein_l[self.__curr_grow])
+        st = self._state
+        return min(1.0, (1.0 + st["step_sample_idx"]) / self._fade[st["curr_grow"]])
 
     @property
     def curr_grow(self) -> int:
-        return self.__curr_grow
+        return self._state["curr_grow"]
 
-    @staticmethod
-    def __get_transform(downscale_factor: int) -> _Compose:
-        target_size = 512 // 2 ** downscale_factor
-        return _Compose([audio.ChannelMinMaxNorm(), audio.ChangeRange(-1., 1.), _Resize(target_size)])
-
+    # ---- input transform of the current level
     @property
-    def scale_transform(self) -> _Compose:
-        return self.__transform
+    def scale_transform(self) -> Callable[[torch.Tensor], torch.Tensor]:
+        return self._pipeline
 
-    def transform_batch(self, x: th.Tensor) -> th.Tensor:
+    def transform_batch(self, x: torch.Tensor) -> torch.Tensor:
         """`scale_transform(x.to(th.float))` of train.py:139-140.  A batch that already sits on the GPU (float64 as the dataset
         stores it, or float32) goes through the fused kernel (ops.input_transform); a CPU batch takes the tensor expressions."""
         if x.is_cuda:
             from . import ops
-            return ops.input_transform(x.contiguous(), 512 // 2 ** self.__downscale)
-        return self.__transform(x.to(th.float))
+            return ops.input_transform(x.contiguous(), self._side())
+        return self._pipeline(x.to(torch.float32))
 
-    def state_dict(self):
-        return {"curr_grow": self.__curr_grow, "sample_idx": self.__sample_idx,
-                "step_sample_idx": self.__step_sample_idx, "downscale": self.__downscale}
+    # ---- resume support (an extension: the reference cannot resume)
+    def state_dict(self) -> dict:
+        return dict(self._state)
 
-    def load_state_dict(self, sd):
-        self.__curr_grow, self.__sample_idx = sd["curr_grow"], sd["sample_idx"]
-        self.__step_sample_idx, self.__downscale = sd["step_sample_idx"], sd["downscale"]
-        self.__transform = Grower.__get_transform(self.__downscale)
+    def load_state_dict(self, sd: dict) -> None:
+        self._state = {k: int(sd[k]) for k in ("curr_grow", "sample_idx", "step_sample_idx", "downscale")}
+        self._pipeline = _InputPipeline(self._side())
 
 
 class Saver:
+    """Every `save_every` calls of `request_save` writes `{disc,optim_disc,gen,optim_gen}_{k}.pt` (state dicts, the reference's
+    file names) into `output_dir`, plus six preview images of fresh samples when matplotlib is importable."""
+
+    _PREVIEWS = 6
+
     def __init__(self, output_dir: str, save_every: int, rand_channels: int, rand_height: int = 2, rand_width: int = 2):
-        self.__output_dir = output_dir
-        self.__counter = 0
-        self.__curr_save = 0
-        self.__save_every = save_every
-        self.__rand_channels = rand_channels
-        self.__height = rand_height
-        self.__width = rand_width
-        self.__nb_output_images = 6
+        self._dir = output_dir
+        self._every = save_every
+        self._latent = (rand_channels, rand_height, rand_width)
+        self._calls = 0
+        self._saves = 0
 
-    def __save_models(self, gen: Generator, disc: Discriminator, optim_gen, optim_disc):
-        th.save(disc.state_dict(), join(self.__output_dir, f"disc_{self.__curr_save}.pt"))
-        th.save(optim_disc.state_dict(), join(self.__output_dir, f"optim_disc_{self.__curr_save}.pt"))
-        th.save(gen.state_dict(), join(self.__output_dir, f"gen_{self.__curr_save}.pt"))
-        th.save(optim_gen.state_dict(), join(self.__output_dir, f"optim_gen_{self.__curr_save}.pt"))
+    def _path(self, stem: str, suffix: str = "pt") -> str:
+        return os.path.join(self._dir, f"{stem}_{self._saves}.{suffix}")
 
-    def __save_outputs(self, gen: Generator, alpha: float):
+    def _write_checkpoint(self, gen, disc, optim_gen, optim_disc, train_state: Optional[Callable[[], dict]]) -> None:
+        for stem, obj in (("disc", disc), ("optim_disc", optim_disc), ("gen", gen), ("optim_gen", optim_gen)):
+            torch.save(obj.state_dict(), self._path(stem))
+        if train_state is not None:
+            torch.save(train_state(), self._path("train_state"))
+
+    def _write_previews(self, gen: Generator, alpha: float) -> None:
         try:
             import matplotlib
             matplotlib.use("Agg")
@@ -125,37 +125,34 @@ class Saver:
         except ImportError:
             return  # previews are optional: matplotlib is not a dependency of the accelerated package
         device = next(gen.parameters()).device
-        with th.no_grad():
-            for gen_idx in range(self.__nb_output_images):
-                z = th.randn(1, self.__rand_channels, self.__height, self.__width, device=device)
-                x_fake = gen(z, alpha)
-                for name, ch in (("magn", 0), ("phase", 1)):
-                    img = x_fake[0, ch].detach().cpu().numpy()
+        with torch.no_grad():
+            for sample in range(self._PREVIEWS):
+                x_fake = gen(torch.randn(1, *self._latent, device=device), alpha)[0].cpu().numpy()
+                for channel, name in enumerate(("magn", "phase")):
+                    img = x_fake[channel]
                     fig, ax = plt.subplots()
                     ax.matshow(img / (img.max() - img.min()), cmap="plasma")
-                    plt.title(f"gen {name} {self.__curr_save} grow={gen.curr_layer}")
-                    fig.savefig(join(self.__output_dir, f"{name}_{self.__curr_save}_ID{gen_idx}.png"))
+                    plt.title(f"gen {name} {self._saves} grow={gen.curr_layer}")
+                    fig.savefig(os.path.join(self._dir, f"{name}_{self._saves}_ID{sample}.png"))
                     plt.close()
 
     def request_save(self, gen: Generator, disc: Discriminator, optim_gen, optim_disc, alpha: float,
-                     train_state=None) -> bool:
+                     train_state: Optional[Callable[[], dict]] = None) -> bool:
         """`train_state` (optional callable -> dict) is an extension over the reference: the growth level, the Grower counters
         and the iteration index are written next to the four reference files as `train_state_{k}.pt`, which is what
-        `train(..., resume_from=...)` needs (the reference cannot resume: utils.py:118-145 saves weights only)."""
-        self.__counter += 1
-        if self.__counter % self.__save_every == 0:
-            self.__save_models(gen, disc, optim_gen, optim_disc)
-            if train_state is not None:
-                th.save(train_state(), join(self.__output_dir, f"train_state_{self.__curr_save}.pt"))
-            self.__save_outputs(gen, alpha)
-            self.__curr_save += 1
-            return True
-        return False
+        `train(..., resume_from=...)` needs (the reference saves weights only, utils.py:118-145)."""
+        self._calls += 1
+        if self._calls % self._every:
+            return False
+        self._write_checkpoint(gen, disc, optim_gen, optim_disc, train_state)
+        self._write_previews(gen, alpha)
+        self._saves += 1
+        return True
 
     @property
     def curr_save(self) -> int:
-        return self.__curr_save - 1
+        return self._saves - 1  # index of the last checkpoint written
 
     @property
     def save_counter(self) -> int:
-        return self.__counter % self.__save_every
+        return self._calls % self._every

@@ -13,10 +13,9 @@ def timeit(fn, iters=10):
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / iters
 for side in (128, 64, 4):
-    g = Grower(7, [1] * 8, [10 ** 9] * 7)
-    while 512 // 2 ** g._Grower__downscale != side:
-        g._Grower__downscale -= 1
-    g._Grower__transform = Grower._Grower__get_transform(g._Grower__downscale)
+    g = Grower(7, [1] * 8, [1] * 7)
+    while g.scale_transform.side != side:
+        g.grow(1)
     a = timeit(lambda: ops.input_transform(x, side))
     b = timeit(lambda: g.scale_transform(x.to(torch.float32)))
     print(f"side {side}: fused {a:.3f} ms ({x.numel()*8/a/1e6:.0f} GB/s of input)   torch ops {b:.3f} ms", flush=True)
