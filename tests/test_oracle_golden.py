@@ -145,3 +145,11 @@ def test_audio_oracle_inverse_matches_reference():
 def test_stft_known_shape_30s():
     # notebook cell 7: 30 s mono at 44.1 kHz -> [513, 5168] before the Nyquist drop
     assert OA.stft(np.zeros(44100 * 30, dtype=np.float32)).shape == (512, 5168)
+
+
+def test_bark_known_answer_from_the_notebook():
+    # notebook cell 35: bark(22050 Hz) = 6 asinh(22050 / 600) = 25.7848 -- the un-normalised last entry of the scale vector
+    assert abs(6.0 * np.arcsinh(22050.0 / 600.0) - 25.7848) < 1e-4
+    s = OA.bark_scale_vector(512)
+    raw = 6.0 * np.arcsinh(np.linspace(20.0, 22050.0, 512) / 600.0)
+    assert np.allclose(s, raw / np.linalg.norm(raw), rtol=1e-6) and abs(raw[-1] - 25.7848) < 1e-4
