@@ -19,6 +19,7 @@ struct C1Args {
   int so, sc;  // weight element (o,c) at w[o*so + c*sc]
   int flags;
   float slope;
+  int co_per;  // few-in kernel: output channels per blockIdx.y slice (small maps are latency-bound: more, shorter threads)
 };
 
 template <int V>
@@ -57,7 +58,8 @@ __global__ void __launch_bounds__(256) conv1x1_few_in(const C1Args a) {
         for (int v = 0; v < V; ++v) xv[c][v] = 0.f;
       }
     }
-    for (int o = 0; o < a.Cout; ++o) {
+    const int o_lo = blockIdx.y * a.co_per, o_hi = o_lo + a.co_per < a.Cout ? o_lo + a.co_per : a.Cout;
+    for (int o = o_lo; o < o_hi; ++o) {
       const float b = a.bias ? a.bias[o] : 0.f;
       float acc[V];
 #pragma unroll
@@ -107,7 +109,7 @@ __global__ void __launch_bounds__(256) conv1x1_few_out(const C1Args a) {
       for (int v = 0; v < V; ++v) acc[o][v] = b;
     }
     const float* xp = a.x + (size_t)n * a.Cin * a.HW + p;
-#pragma unroll 4
+#pragma unroll 8
     for (int c = 0; c < a.Cin; ++c) {
       float xv[V];
       load_v<V>(xp + (size_t)c * a.HW, xv);
@@ -305,16 +307,22 @@ extern "C" int mg_conv1x1(const float* x, const float* w, const float* bias, con
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.HW = HW;
   if (flags & MG_C1_TRANSPOSED) { a.so = 1; a.sc = Cout; } else { a.so = Cin; a.sc = 1; }
   a.flags = flags; a.slope = slope;
-  const bool vec = (HW & 3) == 0;
-  const int grid = c1_grid((size_t)N * (vec ? HW / 4 : HW));
+  bool vec = (HW & 3) == 0;
+  const size_t px = (size_t)N * HW;
   hipStream_t s = (hipStream_t)stream;
   if (Cin <= FEW) {
-    // few-in: MASK_AUX applies to the OUTPUT; TANH_BWD_IN to the input
-    if (vec) hipLaunchKernelGGL(conv1x1_few_in<4>, dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(conv1x1_few_in<1>, dim3(grid), dim3(256), 0, s, a);
+    // few-in: MASK_AUX applies to the OUTPUT; TANH_BWD_IN to the input.  Small maps are latency-bound on the serial loop over
+    // output channels, so slice those over blockIdx.y (more, shorter threads).
+    a.co_per = px >= ((size_t)1 << 21) ? Cout : (px >= ((size_t)1 << 19) ? 16 : 8);
+    const dim3 g2(c1_grid(vec ? px / 4 : px), mg_cdiv(Cout, a.co_per));
+    if (vec) hipLaunchKernelGGL(conv1x1_few_in<4>, g2, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(conv1x1_few_in<1>, g2, dim3(256), 0, s, a);
   } else {
-    // few-out: MASK_AUX applies to the INPUT (aux has Cin channels)
+    // few-out: MASK_AUX applies to the INPUT (aux has Cin channels).  Small maps: one pixel per thread (4x the threads).
     MG_CHECK_ARG(!(flags & MG_C1_TANH_BWD_IN), "mg_conv1x1: TANH_BWD_IN needs Cin<=4");
+    a.co_per = Cout;
+    if (px < ((size_t)1 << 20)) vec = false;
+    const int grid = c1_grid(vec ? px / 4 : px);
     if (vec) hipLaunchKernelGGL(conv1x1_few_out<4>, dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(conv1x1_few_out<1>, dim3(grid), dim3(256), 0, s, a);
   }
