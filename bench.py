@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense, exact fp32
-LEVEL_SIDE = {3: 32, 4: 64, 5: 128}
+LEVEL_SIDE = {3: 32, 4: 64, 5: 128, 6: 256, 7: 512}
 
 
 def build_nets(level: int, rand_channels: int, device):
@@ -145,7 +145,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--level", type=int, default=5, choices=[3, 4, 5])
+    ap.add_argument("--level", type=int, default=5, choices=[3, 4, 5, 6, 7])
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--rand-channels", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")

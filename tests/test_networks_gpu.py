@@ -279,20 +279,21 @@ def test_fused_d_step_equals_module_path(case, conv_mode):
         assert maxabs_err(grads[True][k], grads[False][k]) <= 2 * atol, f"fused vs module {k}"
 
 
-def test_full_size_step_is_algorithm_independent(monkeypatch):
+@pytest.mark.parametrize("level,batch", [(5, 64), (6, 8), (7, 3)])
+def test_full_size_step_is_algorithm_independent(monkeypatch, level, batch):
     """BASELINE.json's headline configuration (level 5, 2x128x128, batch 64) is too large for the CPU oracle inside a test, so
     the size-independent property is used: the critic and generator gradients of one full-size D step and G step must not depend
     on WHICH convolution algorithm computed them -- Winograd F(2x2,3x3)/F(3x3,2x2) + sub-pixel kernels (the product path)
     versus the direct implicit-GEMM kernels (validated against the oracle at the small sizes above).  The two paths share no
     multiply order, so agreement to fp32 round-off at full size checks indexing, tiling, halo handling and split-K at the sizes
-    the benchmark runs."""
+    the benchmark runs.  Levels 6 and 7 (256 x 256 and the final 512 x 512 maps, odd batch) cover the last two growth
+    steps of a full training run, which no fixture reaches."""
     import bench
     from musicgan_amd.optim import FusedAdam
     from musicgan_amd.train_step import ProGANStepper
 
-    level, batch = 5, 64
     side = bench.LEVEL_SIDE[level]
-    grads = {}
+    grads, terms = {}, {}
     for mode in ("product", "direct"):
         if mode == "direct":
             monkeypatch.setenv("MG_WINO", "0")
@@ -312,8 +313,16 @@ def test_full_size_step_is_algorithm_independent(monkeypatch):
         gd = {"D." + k: p.grad.detach().clone() for k, p in disc.named_parameters() if p.grad is not None}
         mg = st.g_step(batch, 0.5, DEV, z=z)
         gg = {"G." + k: p.grad.detach().clone() for k, p in gen.named_parameters() if p.grad is not None}
+        # un-cancelled scale of every critic gradient: d mean(D(x_real)) / dw alone.  At init the real and fake terms of the
+        # Wasserstein loss nearly cancel in the deep blocks (own max 7e-9 against terms of 3e-3 at level 6), so fp32 round-off
+        # of the TERMS -- measured 1e-7 of them -- is the floor of any comparison of the residue.
+        disc.zero_grad()
+        disc(x_real, 0.5).mean().backward()
+        terms[mode] = {"D." + k: p.grad.detach().clone() for k, p in disc.named_parameters() if p.grad is not None}
         grads[mode] = ({**gd, **gg}, float(md["disc_loss"]), float(md["grad_pen"]), float(mg["gen_loss"]))
     (ga, la, pa, qa), (gb, lb, pb, qb) = grads["product"], grads["direct"]
+    for k, t in terms["direct"].items():
+        assert maxabs_err(terms["product"][k], t) <= 2e-4 * float(t.abs().max()), k
     assert ga.keys() == gb.keys() and len(ga) > 40
     assert abs(la - lb) <= 1e-5 * max(1.0, abs(lb)) and abs(pa - pb) <= 1e-4 * max(1.0, abs(pb)) and abs(qa - qb) <= 1e-5 * max(1.0, abs(qb))
     for net in ("D.", "G."):
@@ -321,5 +330,8 @@ def test_full_size_step_is_algorithm_independent(monkeypatch):
         for k in gb:
             if k.startswith(net):
                 # per tensor: 2e-4 of its own max-norm, or (cancellation residues, see grad_atol) 2e-5 of the network's scale
+                # or of the tensor's un-cancelled term
                 tol = max(2e-4 * float(gb[k].abs().max()), 2e-5 * gmax)
+                if k in terms["direct"]:
+                    tol = max(tol, 2e-5 * float(terms["direct"][k].abs().max()))
                 assert maxabs_err(ga[k], gb[k]) <= tol, f"{k}: {maxabs_err(ga[k], gb[k]):.3e} > {tol:.3e}"
