@@ -30,8 +30,6 @@
 namespace {
 
 constexpr int WCC = 8;  // input channels per LDS chunk
-constexpr int WT = 2;   // tile groups (16 tiles each) per workgroup
-constexpr int TPB = WT * 16;  // tiles per workgroup
 constexpr float PN_EPS = 1e-8f;
 
 struct WinoArgs {
@@ -51,8 +49,10 @@ struct WinoArgs {
   int NT;  // out-channel tiles in the packed weights (padded)
 };
 
-template <int NIW, int WC>
-__global__ void __launch_bounds__(64 * WT * WC, 2) wino3x3_mfma(const WinoArgs a) {
+// WT = tile groups (16 tiles each) per workgroup: 2 (two workgroups per CU) or 4 (one 8..12-wave workgroup per CU)
+template <int NIW, int WC, int WT>
+__global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(const WinoArgs a) {
+  constexpr int TPB = WT * 16;  // tiles per workgroup
   constexpr int NTHR = 64 * WT * WC;
   constexpr int NITEMS = TPB * WCC;                    // (tile, channel) items per chunk
   constexpr int NITEM = (NITEMS + NTHR - 1) / NTHR;    // ... per thread
@@ -450,16 +450,17 @@ __global__ void wino3x3_pack_kernel(const float* __restrict__ w, float* __restri
   }
 }
 
-template <int NIW, int WC>
+template <int NIW, int WC, int WT>
 int launch_wino(const WinoArgs& a, dim3 grid, hipStream_t s) {
+  constexpr int TPB = WT * 16;
   constexpr size_t lds = (size_t)(16 * TPB * WCC + WC * NIW * 2048 + WC * TPB * 4) * sizeof(float);
   static bool attr_set = false;  // benign race: idempotent
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino3x3_mfma<NIW, WC>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino3x3_mfma<NIW, WC, WT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((wino3x3_mfma<NIW, WC>), grid, dim3(64 * WT * WC), lds, s, a);
+  hipLaunchKernelGGL((wino3x3_mfma<NIW, WC, WT>), grid, dim3(64 * WT * WC), lds, s, a);
   MG_CHECK_LAUNCH("mg_wino3x3");
   return MG_OK;
 }
@@ -512,12 +513,6 @@ extern "C" int mg_wino3x3(const float* x, const float* up, const float* bias, co
   a.nchunk = mg_cdiv(Cin, WCC);
   a.NT = wino_nt_padded(Cout);
   const int Ht = H / 2, Wt = W / 2;
-  a.TBW = mg_pow2_ceil(Wt) < 16 ? mg_pow2_ceil(Wt) : 16;  // 16 tiles = 32 pixels = one 128-byte line per row and channel
-  a.TBH = mg_pow2_ceil(Ht) < TPB / a.TBW ? mg_pow2_ceil(Ht) : TPB / a.TBW;
-  a.TBN = TPB / (a.TBW * a.TBH);
-  a.lgTBW = mg_ilog2(a.TBW); a.lgTBH = mg_ilog2(a.TBH);
-  a.blocks_x = mg_cdiv(Wt, a.TBW); a.blocks_y = mg_cdiv(Ht, a.TBH); a.blocks_n = mg_cdiv(N, a.TBN);
-  MG_CHECK_ARG((long long)a.TBN * Cin * H * W < (1ll << 29), "mg_wino3x3: image block too large for 32-bit offsets");
 
   // out-channel tiles per workgroup (wave groups x tiles per wave): 4 = 2x2, 3 = 3x1, 2 = 2x1 -- least padding wins
   int cfg = 4, best = mg_cdiv(nt, 4) * 4;
@@ -532,11 +527,36 @@ extern "C" int mg_wino3x3(const float* x, const float* up, const float* bias, co
     }
   }
   MG_CHECK_ARG(mg_cdiv(nt, cfg) * cfg <= a.NT, "mg_wino3x3: internal tile error");
+  // tiles per workgroup: 64 (one 8..12-wave workgroup per CU: every wave of the CU is in the same phase, so the VALU staging
+  // and epilogue never queue behind another workgroup's matrix instructions -- measured 70..140 cycles per VALU instruction
+  // when they do, tools/hwtests/valu_latency_under_mfma.hip -- and the filters are staged once per 64 tiles) when that still
+  // gives every CU two or more workgroups, else 32 (two workgroups per CU).
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    n_cu = v;
+  }
+  int wt = ((long long)N * Ht * Wt / 64) * mg_cdiv(nt, cfg) >= 2ll * n_cu ? 4 : 2;
+  {
+    const char* e = getenv("MG_WINO_WT");  // measurement override
+    if (e != nullptr && (atoi(e) == 2 || atoi(e) == 4)) wt = atoi(e);
+  }
+  const int tpb = wt * 16;
+  a.TBW = mg_pow2_ceil(Wt) < 16 ? mg_pow2_ceil(Wt) : 16;  // 16 tiles = 32 pixels = one 128-byte line per row and channel
+  a.TBH = mg_pow2_ceil(Ht) < tpb / a.TBW ? mg_pow2_ceil(Ht) : tpb / a.TBW;
+  a.TBN = tpb / (a.TBW * a.TBH);
+  a.lgTBW = mg_ilog2(a.TBW); a.lgTBH = mg_ilog2(a.TBH);
+  a.blocks_x = mg_cdiv(Wt, a.TBW); a.blocks_y = mg_cdiv(Ht, a.TBH); a.blocks_n = mg_cdiv(N, a.TBN);
+  MG_CHECK_ARG((long long)a.TBN * Cin * H * W < (1ll << 29), "mg_wino3x3: image block too large for 32-bit offsets");
   dim3 grid(a.blocks_x * a.blocks_y * a.blocks_n, mg_cdiv(nt, cfg));
   hipStream_t s = (hipStream_t)stream;
-  switch (cfg) {
-    case 4: return launch_wino<2, 2>(a, grid, s);
-    case 3: return launch_wino<1, 3>(a, grid, s);
-    default: return launch_wino<1, 2>(a, grid, s);
+  switch (cfg * 10 + wt) {
+    case 44: return launch_wino<2, 2, 4>(a, grid, s);
+    case 42: return launch_wino<2, 2, 2>(a, grid, s);
+    case 34: return launch_wino<1, 3, 4>(a, grid, s);
+    case 32: return launch_wino<1, 3, 2>(a, grid, s);
+    case 24: return launch_wino<1, 2, 4>(a, grid, s);
+    default: return launch_wino<1, 2, 2>(a, grid, s);
   }
 }
