@@ -197,22 +197,34 @@ __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(co
       if (NU4 * NTHR == U4 || tid + NTHR * j < U4) dstw[tid + NTHR * j] = rw[j];
   };
 
+  // operands of component pair cp+1 are requested from LDS before the MFMAs of pair cp are issued (two register sets): a wave
+  // that issues its reads only after its MFMAs leaves the matrix pipe idle for an LDS round trip every 8 instructions
   auto compute_chunk = [&]() {
     const float* va = Vs + wt * 2048 + lane * 4;
     const float* ub = Us + (wc * NIW) * 2048 + lane * 4;
+    f32x4 av[2], bv[2][NIW];
+    av[0] = *reinterpret_cast<const f32x4*>(va);  // {c0 k0, c1 k0, c0 k1, c1 k1}
+#pragma unroll
+    for (int ni = 0; ni < NIW; ++ni) bv[0][ni] = *reinterpret_cast<const f32x4*>(ub + ni * 2048);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1 + NIW, 0);
 #pragma unroll
     for (int cp = 0; cp < 8; ++cp) {
-      const f32x4 av = *reinterpret_cast<const f32x4*>(va + cp * 256);  // {c0 k0, c1 k0, c0 k1, c1 k1}
-      f32x4 bv[NIW];
+      const int cur = cp & 1, nxt = cur ^ 1;
+      if (cp + 1 < 8) {
+        av[nxt] = *reinterpret_cast<const f32x4*>(va + (cp + 1) * 256);
 #pragma unroll
-      for (int ni = 0; ni < NIW; ++ni) bv[ni] = *reinterpret_cast<const f32x4*>(ub + ni * 2048 + cp * 256);
+        for (int ni = 0; ni < NIW; ++ni) bv[nxt][ni] = *reinterpret_cast<const f32x4*>(ub + ni * 2048 + (cp + 1) * 256);
+      }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int par = 0; par < 2; ++par)
 #pragma unroll
           for (int ni = 0; ni < NIW; ++ni)
-            acc[2 * cp + par][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[ni][ks * 2 + par], av[ks * 2 + par], acc[2 * cp + par][ni], 0, 0, 0);
+            acc[2 * cp + par][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[cur][ni][ks * 2 + par], av[cur][ks * 2 + par], acc[2 * cp + par][ni], 0, 0, 0);
+      // pin that order (the machine scheduler otherwise sinks the reads below the MFMAs again to shorten live ranges)
+      if (cp + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1 + NIW, 0);  // DS reads of pair cp+1
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NIW, 0);                  // MFMAs of pair cp
     }
   };
 
