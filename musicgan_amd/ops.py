@@ -70,14 +70,14 @@ def pack_wino3x3(w: torch.Tensor, dgrad: bool) -> torch.Tensor:
 
 def wino3x3_supported(n: int, cout: int, h: int, w: int, *, ups=False, pixnorm=False, cin: int = 0) -> bool:
     """Whether conv3x3(..., wino=) may be used: even sizes, enough 2x2 tiles to fill the chip, for the fused PixelNorm all
-    channels of a pixel inside one workgroup, and one image's input planes within the kernel's 32-bit byte offsets (the long
+    channels of a pixel inside one workgroup, and a tile block's input and output planes within the kernel's 32-bit offsets (the long
     non-square maps of `generate` can exceed that; they then take the direct kernel)."""
     if os.environ.get("MG_WINO", "1") == "0" or ups or (h % 2) or (w % 2):
         return False
     if pixnorm and cout > 64:
         return False
     tiles = (h // 2) * (w // 2)
-    if max(cin, 1) * h * w * max(1, 32 // max(tiles, 1)) >= (1 << 29):  # images per 32-tile block x one image's planes
+    if max(cin, cout, 1) * h * w * max(1, 64 // max(tiles, 1)) >= (1 << 29):  # images per 64-tile block x one image's planes
         return False
     return n * h * w >= int(os.environ.get("MG_WINO_MIN_PIXELS", "8192"))  # fewer 2x2 tiles do not fill the chip
 
