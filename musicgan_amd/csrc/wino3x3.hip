@@ -8,7 +8,7 @@
 //
 // Per Winograd component xi (16 of them) this is a GEMM  M_xi[out-ch, tile] = U_xi[c, out-ch]^T * V_xi[tile, c]:
 //   M (A rows)  = NIW x 16 output channels per wave, WC channel groups per workgroup
-//   N (B cols)  = 16 tiles per wave (one 16x16x4 MFMA tile), WT = 2 tile groups per workgroup = 32 tiles = 128 output pixels
+//   N (B cols)  = 16 tiles per wave (one 16x16x4 MFMA tile), WT = 2 or 4 tile groups per workgroup = 32 / 64 tiles
 //   K           = input channels, 8 per LDS chunk (two MFMA k-steps: lane k-index rq holds channels 2rq and 2rq+1)
 // A wave keeps all 16 components of its (channel, tile) block in registers (16 x NIW accumulator tiles), so the output
 // transform, bias, LeakyReLU, PixelNorm, mask and 2x2 average pool are in-register epilogues, and because the filter fragment
@@ -19,8 +19,12 @@
 // ds_read_b128 feeds the operands of two components, and the weight image is a verbatim copy of the packed global layout.
 // Input patches come in through buffer loads: positions in the zero padding (and ragged tiles / channels) carry an
 // out-of-range offset and read back as 0.0 from the hardware bounds check, so the staging code has no masks or branches.
-// Workgroups are small (2 x WC waves, <= 256 registers) so that two of them share a CU: one's staging and epilogue run under
-// the other's matrix instructions ("issue early / write late" register prefetch of the next chunk inside each).
+// Two workgroup sizes: WT = 4 (64 tiles, 4 x WC waves, one workgroup per CU) when the grid gives every CU at least two of
+// them, else WT = 2 (32 tiles, two workgroups per CU).  The big one wins wherever it fills the chip because vector work of
+// one wave is starved (70-140 cycles per instruction, tools/hwtests/valu_latency_under_mfma.hip) while another wave of its
+// SIMD streams fp32 MFMAs, so co-resident workgroups in different phases do not overlap; with one workgroup per CU all waves
+// are in the same phase and the filters are staged once per 64 tiles.  Inside each: "issue early / write late" register
+// prefetch of the next chunk, and LDS operands of the next component pair requested before the current pair's MFMAs.
 // fp32 throughout; rounding differs from the direct form by ~1.2x rms (measured against fp64, tests/test_ops_gpu.py).
 #include <cstdlib>
 #include <type_traits>

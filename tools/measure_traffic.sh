@@ -17,7 +17,7 @@ def avg(kind, name):
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "wino3x3_mfma" in r["Kernel_Name"] and r["Counter_Name"] == name]
     return sum(v) / len(v)
 fetch_kb, write_kb = avg("fetch", "FETCH_SIZE"), avg("write", "WRITE_SIZE")
-out = {"kernel": "wino3x3_mfma<2,2> lrelu+avgpool 48->64@128x128, 192 images (y and pooled y written)",
+out = {"kernel": "wino3x3_mfma<2,2,4> lrelu+avgpool 48->64@128x128, 192 images (y and pooled y written)",
        "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB": write_kb, "fetch_correction": 2.0,
        "bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
        "algorithmic_bytes": 4.0 * 192 * (48 * 128 * 128 + 64 * 128 * 128 + 64 * 64 * 64)}
