@@ -19,38 +19,74 @@ constexpr int FPB = NWAVE * FPW;                  // frames per tile: 8 x 8 byte
 constexpr int XSTR = NB + 1;                      // per-frame LDS column (float2 units), padded: the transposed read-out is conflict-free
 constexpr size_t STFT_LDS = (size_t)(NFFT * 2 + NFFT + FPB * XSTR * 2) * sizeof(float);
 
-// complex numbers as register pairs: add / sub / scale / multiply compile to v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32
+// Complex numbers as register pairs.  Every swap / negate of a component rides on the operand-select and negate modifiers of
+// the packed instruction that consumes it (hipcc builds such vectors with v_mov / v_xor instead: a third of the kernel's
+// vector instructions), so a complex multiply is 2 instructions and a multiply by -i is free.
 typedef float c2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ c2 cmul(c2 a, c2 b) {  // (a.x b.x - a.y b.y, a.x b.y + a.y b.x)
-  return __builtin_elementwise_fma(c2{a.y, a.y}, c2{-b.y, b.x}, c2{a.x, a.x} * b);
+__device__ __forceinline__ c2 csub(c2 a, c2 b) {  // a - b
+  c2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
-__device__ __forceinline__ c2 mul_mi(c2 a) { return c2{a.y, -a.x}; }  // a * (-i)
+__device__ __forceinline__ c2 cmul(c2 a, c2 b) {  // (a.x b.x - a.y b.y, a.x b.y + a.y b.x)
+  c2 t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));  // (a.x b.x, a.x b.y)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,0,0]"
+      : "=v"(r) : "v"(a), "v"(b), "v"(t));  // (a.y * -b.y + t.x, a.y * b.x + t.y)
+  return r;
+}
+__device__ __forceinline__ c2 add_mi(c2 s, c2 d) {  // s + (-i) d = (s.x + d.y, s.y - d.x)
+  c2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(r) : "v"(s), "v"(d));
+  return r;
+}
+__device__ __forceinline__ c2 sub_mi(c2 s, c2 d) {  // s - (-i) d = (s.x - d.y, s.y + d.x)
+  c2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(r) : "v"(s), "v"(d));
+  return r;
+}
+__device__ __forceinline__ c2 add_conj(c2 a, c2 z) {  // a + conj z
+  c2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(z));
+  return r;
+}
+__device__ __forceinline__ c2 sub_conj(c2 a, c2 z) {  // a - conj z
+  c2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(r) : "v"(a), "v"(z));
+  return r;
+}
 
+// 4-point DFT; MI2: y2 is handed over without its pending factor -i
+template <bool MI2>
 __device__ __forceinline__ void dft4(c2 y0, c2 y1, c2 y2, c2 y3, c2& q0, c2& q1, c2& q2, c2& q3) {
-  const c2 s0 = y0 + y2, s1 = y0 - y2, s2 = y1 + y3, s3 = mul_mi(y1 - y3);
+  const c2 s0 = MI2 ? add_mi(y0, y2) : y0 + y2, s1 = MI2 ? sub_mi(y0, y2) : csub(y0, y2);
+  const c2 s2 = y1 + y3, t = csub(y1, y3);  // s3 = -i t
   q0 = s0 + s2;
-  q2 = s0 - s2;
-  q1 = s1 + s3;
-  q3 = s1 - s3;
+  q2 = csub(s0, s2);
+  q1 = add_mi(s1, t);
+  q3 = sub_mi(s1, t);
 }
 
 // in-place 8-point DFT, natural order in and out
 __device__ __forceinline__ void dft8(c2 (&v)[8]) {
   const float h = 0.70710678118654752440f;
   const c2 a0 = v[0] + v[4], a1 = v[1] + v[5], a2 = v[2] + v[6], a3 = v[3] + v[7];
-  c2 d0 = v[0] - v[4], d1 = v[1] - v[5], d2 = v[2] - v[6], d3 = v[3] - v[7];
-  d1 = (d1 + c2{d1.y, -d1.x}) * h;   // * W8^1 = (1 - i)/sqrt2
-  d2 = mul_mi(d2);                   // * W8^2 = -i
-  d3 = (c2{d3.y, -d3.x} - d3) * h;   // * W8^3 = (-1 - i)/sqrt2
-  dft4(a0, a1, a2, a3, v[0], v[2], v[4], v[6]);
-  dft4(d0, d1, d2, d3, v[1], v[3], v[5], v[7]);
+  c2 d0 = csub(v[0], v[4]), d1 = csub(v[1], v[5]), d2 = csub(v[2], v[6]), d3 = csub(v[3], v[7]);
+  d1 = add_mi(d1, d1) * h;           // * W8^1 = (1 - i)/sqrt2 : (d.x + d.y, d.y - d.x) h
+  {                                  // * W8^3 = (-1 - i)/sqrt2 : (d.y - d.x, -d.x - d.y) h   (W8^2 = -i of d2 rides into dft4)
+    c2 r;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[1,1]" : "=v"(r) : "v"(d3));
+    d3 = r * h;
+  }
+  dft4<false>(a0, a1, a2, a3, v[0], v[2], v[4], v[6]);
+  dft4<true>(d0, d1, d2, d3, v[1], v[3], v[5], v[7]);
 }
 
-// Persistent workgroups of 8 waves (two per CU: one's write-out runs under the other's FFTs): twiddles and window are built once
+// Persistent workgroups of 8 waves (two per CU: one's write-out runs under the other's FFTs; <= 128 registers): twiddles and window are built once
 // per workgroup, then each tile of 16 consecutive frames is transformed -- one wave = 2 frames, each in its own 4 KiB LDS column
 // that serves the two Stockham exchanges and finally holds the frame's 512 output bins, so there is no workgroup barrier inside
 // a frame -- and the 16 columns are read out transposed so that every global store instruction writes four 128-byte runs along t.
-__global__ void __launch_bounds__(64 * NWAVE) stft1024_kernel(const float* __restrict__ wav, float* __restrict__ out_re,
+__global__ void __launch_bounds__(64 * NWAVE, 2) stft1024_kernel(const float* __restrict__ wav, float* __restrict__ out_re,
                                                               float* __restrict__ out_im, long long L, int T, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   c2* tw = reinterpret_cast<c2*>(smem);                       // tw[m] = exp(-2 pi i m / 1024)
@@ -62,40 +98,53 @@ __global__ void __launch_bounds__(64 * NWAVE) stft1024_kernel(const float* __res
     float s, c;
     sincospif((float)m * (1.0f / 512.0f), &s, &c);  // angle = 2 pi m / 1024 = pi * m / 512
     tw[m] = c2{c, -s};
-    win[m] = (0.5f - 0.5f * c) * 0.05103103630798288f;  // 1/sqrt(384): sum of hann^2 over 1024 = 384
+    // Hann / sqrt(384) (sum of hann^2 over 1024 = 384), times the 1/2 of the real-FFT untangling: a power-of-two scale
+    // commutes exactly with every rounding of the (linear) transform, so it costs nothing here instead of 16 multiplies there
+    win[m] = (0.5f - 0.5f * c) * (0.5f * 0.05103103630798288f);
   }
   __syncthreads();
 
+  // Samples of a frame, 8 complex pairs per lane: requested one frame ahead (the next frame of the tile, or the first frame
+  // of the workgroup's next tile before the write-out of this one), so the HBM latency runs under a whole frame of FFT work
+  // instead of in front of it (a wave has nothing else to do: 4 waves per SIMD do not hide ~2500 cycles).
+  auto load_frame = [&](int t, c2 (&x)[8]) {
+    if (t < T) {
+      const long long base = (long long)t * HOP - NFFT / 2;  // sample index of padded position 0 of this frame
+      const bool interior = (base >= 0) && (base + NFFT <= L);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int n = 2 * (lane + 64 * r);
+        if (interior) {
+          x[r] = *reinterpret_cast<const c2*>(wav + base + n);
+        } else {
+          long long s0 = base + n, s1 = base + n + 1;
+          if (s0 < 0) s0 = -s0;
+          if (s1 < 0) s1 = -s1;
+          if (s0 >= L) s0 = 2 * (L - 1) - s0;
+          if (s1 >= L) s1 = 2 * (L - 1) - s1;
+          x[r] = c2{wav[s0], wav[s1]};
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) x[r] = c2{0.f, 0.f};
+    }
+  };
+
+  c2 xn[8];  // the frame in flight
+  if ((int)blockIdx.x < ntiles) load_frame(blockIdx.x * FPB + wave * FPW, xn);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int t0 = tile * FPB;
 #pragma unroll 1
     for (int f = 0; f < FPW; ++f) {
       const int fl = wave * FPW + f;  // frame slot in the tile
       c2* xb = xbuf + fl * XSTR;
-      const int t = t0 + fl;
       c2 v[8];
-      if (t < T) {
-        const long long base = (long long)t * HOP - NFFT / 2;  // sample index of padded position 0 of this frame
-        const bool interior = (base >= 0) && (base + NFFT <= L);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          const int n = 2 * (lane + 64 * r);
-          c2 x;
-          if (interior) {
-            x = *reinterpret_cast<const c2*>(wav + base + n);
-          } else {
-            long long s0 = base + n, s1 = base + n + 1;
-            if (s0 < 0) s0 = -s0;
-            if (s1 < 0) s1 = -s1;
-            if (s0 >= L) s0 = 2 * (L - 1) - s0;
-            if (s1 >= L) s1 = 2 * (L - 1) - s1;
-            x = c2{wav[s0], wav[s1]};
-          }
-          v[r] = x * *reinterpret_cast<const c2*>(win + n);
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = c2{0.f, 0.f};
+      for (int r = 0; r < 8; ++r) v[r] = xn[r] * *reinterpret_cast<const c2*>(win + 2 * (lane + 64 * r));
+      {  // one call site: next frame of this tile, first frame of the next tile, or nothing (t = T reads as zeros)
+        const int tnext = tile + (int)gridDim.x < ntiles ? (tile + (int)gridDim.x) * FPB + wave * FPW : T;
+        load_frame(f + 1 < FPW ? t0 + fl + 1 : tnext, xn);
       }
       // pass 0 (Ns = 1): no twiddles; out[8 j + r]
       dft8(v);
@@ -123,7 +172,7 @@ __global__ void __launch_bounds__(64 * NWAVE) stft1024_kernel(const float* __res
       // untangle: X[k] = (Z[k] + conj Z[512-k])/2 - i/2 * e^{-2 pi i k/1024} * (Z[k] - conj Z[512-k]),  k = lane + 64 r.
       // Z[512-k] sits in lane (64-lane)&63, register 7-r (lane != 0) or 8-r (lane == 0; r == 0 -> Z[0] itself).
       const int src = (64 - lane) & 63;
-      c2 zc[8];  // conj Z[512-k]
+      c2 zc[8];  // Z[512-k]
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         // value this lane must SEND for the receiver's register r: receiver lane l' = (64-lane)&63 wants register
@@ -131,15 +180,13 @@ __global__ void __launch_bounds__(64 * NWAVE) stft1024_kernel(const float* __res
         const c2 send_n0 = v[7 - r];
         const c2 send_0 = v[(8 - r) & 7];
         const c2 send = (lane == 0) ? send_0 : send_n0;
-        zc[r] = c2{__shfl(send.x, src), -__shfl(send.y, src)};
+        zc[r] = c2{__shfl(send.x, src), __shfl(send.y, src)};  // Z[512-k] (conjugated by the consumers; the 1/2 is in the window)
       }
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const int k = lane + 64 * r;
-        const c2 e = (v[r] + zc[r]) * 0.5f;
-        const c2 d = (v[r] - zc[r]) * 0.5f;
-        const c2 wd = cmul(tw[k], d);
-        xb[k] = e + c2{wd.y, -wd.x};  // e - i * wd  (pass 2 has read the column: the exchanges are done with it)
+        const c2 wd = cmul(tw[k], sub_conj(v[r], zc[r]));
+        xb[k] = add_mi(add_conj(v[r], zc[r]), wd);  // e - i * wd  (pass 2 has read the column: the exchanges are done with it)
       }
     }
     __syncthreads();
