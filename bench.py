@@ -208,6 +208,30 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     images_per_s = world * args.batch * args.steps / elapsed
 
+    # secondary figure: the reference's own cadence, five critic updates per generator update (train.py:189);
+    # images/s counts the real images consumed (one batch per critic update).  Single GPU only.
+    cadence = None
+    if world == 1:
+        def cycle():
+            for _ in range(5):
+                z = torch.randn(args.batch, args.rand_channels, 2, 2, device=device, generator=data_rng)
+                eps = torch.rand(args.batch, 1, 1, 1, device=device, generator=data_rng)
+                stepper.d_step(x_real, alpha, z=z, eps=eps)
+            z2 = torch.randn(args.batch, args.rand_channels, 2, 2, device=device, generator=data_rng)
+            stepper.g_step(args.batch, alpha, device, z=z2)
+        cycle()
+        stepper.finish()
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        ncyc = max(1, args.steps // 5)
+        for _ in range(ncyc):
+            cycle()
+        stepper.finish()
+        torch.cuda.synchronize()
+        tc = time.perf_counter() - tc
+        cadence = {"cadence": "5 critic updates : 1 generator update (reference train.py:189)", "cycles": ncyc,
+                   "ms_per_cycle": 1e3 * tc / ncyc, "images_per_s": 5 * args.batch * ncyc / tc}
+
     if os.environ.get("MG_BENCH_CHECKSUM") and rank == 0:
         cs = sum(float(p.detach().double().abs().sum()) for p in list(gen.parameters()) + list(disc.parameters()))
         print(f"weights_abs_sum {cs:.10e}", file=sys.stderr, flush=True)
@@ -231,6 +255,8 @@ def main():
                          "dominant_kernel": {**dom, "frac": dom["tflops"] / MFMA_F32_PEAK_TFLOPS,
                                              "executed_frac": dom["executed_tflops"] / MFMA_F32_PEAK_TFLOPS}},
         }
+        if cadence is not None:
+            line["secondary"] = cadence
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.level, args.rand_channels, args.cpu_batch, iters=2)
         print(json.dumps(line), flush=True)
