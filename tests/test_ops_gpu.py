@@ -346,12 +346,15 @@ WINO_SHAPES = [(2, 8, 8, 2, 2), (3, 32, 128, 4, 4), (2, 112, 96, 8, 8), (2, 96, 
                (1, 72, 112, 24, 40)]
 
 
-@pytest.mark.parametrize("cfg", ["", "2", "3", "4"])
+@pytest.mark.parametrize("cfg", ["", "2", "3", "4", "2w", "3w", "4w"])
 @pytest.mark.parametrize("shape", WINO_SHAPES)
 def test_wino3x3_fwd_dgrad_mask_pool(shape, cfg, monkeypatch):
     """mg_wino3x3 (Winograd F(2x2,3x3)) against fp64 conv2d: forward + bias + LeakyReLU (+ fused AvgPool2d), plain, data
     gradient through the transposed/flipped pack, and the masked (tangent / dgrad) epilogue -- for every out-channel tiling."""
     ops = _ops()
+    if cfg.endswith("w"):  # the 64-tile, one-workgroup-per-CU variant (picked by itself only for grids that fill the chip)
+        monkeypatch.setenv("MG_WINO_WT", "4")
+        cfg = cfg[:-1]
     if cfg:
         monkeypatch.setenv("MG_WINO_CFG", cfg)
     n, ci, co, h, w = shape
@@ -379,10 +382,13 @@ def test_wino3x3_fwd_dgrad_mask_pool(shape, cfg, monkeypatch):
     report("wino dgrad+mask pooled", gq, F.avg_pool2d(refm, 2), 2e-6)
 
 
+@pytest.mark.parametrize("wt", ["", "4"])
 @pytest.mark.parametrize("shape", [(2, 8, 8, 2, 2), (2, 64, 64, 32, 32), (1, 80, 48, 64, 16), (3, 24, 33, 6, 10),
                                    (2, 32, 16, 16, 16)])
-def test_wino3x3_pixnorm(shape):
+def test_wino3x3_pixnorm(shape, wt, monkeypatch):
     ops = _ops()
+    if wt:
+        monkeypatch.setenv("MG_WINO_WT", wt)
     n, ci, co, h, w = shape
     g = torch.Generator().manual_seed(22)
     x = torch.randn(n, ci, h, w, generator=g)
