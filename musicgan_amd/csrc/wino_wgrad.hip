@@ -19,6 +19,13 @@
 
 namespace {
 
+typedef float wg_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ wg_f32x2 pk_sub(wg_f32x2 x, wg_f32x2 y) {  // x - y as one packed instruction
+  wg_f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(y));
+  return d;
+}
+
 constexpr int KT = 8;                  // tiles per chunk
 constexpr int CH = 64;                 // channel slots per operand image (CT, OT <= 4)
 constexpr int IMG = 8 * 4 * CH * 4;    // floats per operand image: [8 comp pairs][4 tile pairs][64 channels][k-step 2][parity 2]
@@ -141,17 +148,18 @@ __global__ void __launch_bounds__(512) wino_wgrad_mfma(const WwArgs a) {
         const float fr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, own_x), 0x130, 0xf, 0xf, false));  // lane+1
         E[r] = f32x2{ledge ? (a.TBW > 1 ? rE[r] : 0.f) : fl, redge ? (a.TBW > 1 ? rE[r] : 0.f) : fr};
       }
+      // one v_pk_add_f32 per result pair, swaps and negations in the operand modifiers (hipcc builds them with v_mov / v_xor)
       f32x2 UE[4], UP[4];
-      UE[0] = E[0] - E[2];  UP[0] = P[0] - P[2];
-      UE[1] = E[1] + E[2];  UP[1] = P[1] + P[2];
-      UE[2] = E[2] - E[1];  UP[2] = P[2] - P[1];
-      UE[3] = E[1] - E[3];  UP[3] = P[1] - P[3];
+      UE[0] = pk_sub(E[0], E[2]);  UP[0] = pk_sub(P[0], P[2]);
+      UE[1] = E[1] + E[2];         UP[1] = P[1] + P[2];
+      UE[2] = pk_sub(E[2], E[1]);  UP[2] = pk_sub(P[2], P[1]);
+      UE[3] = pk_sub(E[1], E[3]);  UP[3] = pk_sub(P[1], P[3]);
       float* dst = st + ldst;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const f32x2 ps = __builtin_shufflevector(UP[i], UP[i], 1, 0);
-        const f32x2 v03 = f32x2{UE[i][0], -UE[i][1]} + f32x2{-ps[0], ps[1]};
-        const f32x2 v12 = UP[i] + f32x2{ps[0], -ps[1]};
+        f32x2 v03, v12;
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(v03) : "v"(UE[i]), "v"(UP[i]));  // (e0 - p1, p0 - e1)
+        asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(v12) : "v"(UP[i]));             // (p0 + p1, p1 - p0)
         *reinterpret_cast<f32x2*>(dst + (2 * i) * (4 * CH * 4)) = v03;
         *reinterpret_cast<f32x2*>(dst + (2 * i + 1) * (4 * CH * 4)) = v12;
       }
@@ -162,13 +170,19 @@ __global__ void __launch_bounds__(512) wino_wgrad_mfma(const WwArgs a) {
       f32x2 R[4];
       R[0] = t0;
       R[1] = t0 + t1;
-      R[2] = t0 - t1;
-      R[3] = -t1;
+      R[2] = pk_sub(t0, t1);
+      R[3] = t1;  // stands for -t1: the sign is folded into the modifiers below
       float* dst = st + IMG + ldst;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const f32x2 y03 = f32x2{R[i][0], -R[i][1]};
-        const f32x2 y12 = f32x2{R[i][0] + R[i][1], R[i][0] - R[i][1]};
+        f32x2 y03, y12;
+        if (i < 3) {
+          asm("v_pk_mul_f32 %0, %1, %2 neg_hi:[1,0]" : "=v"(y03) : "v"(R[i]), "v"(f32x2{1.f, 1.f}));                               // (r0, -r1)
+          asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(y12) : "v"(R[i]));           // (r0 + r1, r0 - r1)
+        } else {
+          asm("v_pk_mul_f32 %0, %1, %2 neg_lo:[1,0]" : "=v"(y03) : "v"(R[i]), "v"(f32x2{1.f, 1.f}));                               // (-t0, t1)
+          asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[1,1] neg_hi:[1,0]" : "=v"(y12) : "v"(R[i]));           // (-t0 - t1, -t0 + t1)
+        }
         *reinterpret_cast<f32x2*>(dst + (2 * i) * (4 * CH * 4)) = y03;
         *reinterpret_cast<f32x2*>(dst + (2 * i + 1) * (4 * CH * 4)) = y12;
       }
