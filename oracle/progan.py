@@ -309,3 +309,106 @@ def flops_per_image(rand_channels: int, level: int) -> Tuple[float, float]:
         d += 2 * 9 * co * co * t * t
     d += 2 * 160
     return g, d
+
+
+# --------------------------------------------------------------------------- the stateful loop (train.py:101-272)
+class GrowerState:
+    """utils.py:14-68 restated: sample counters -> (grow?, alpha).  `train_lengths` are cumulated (utils.py:39-43); growth when
+    the cumulated length is STRICTLY below the samples seen (utils.py:52); alpha read before grow() (train.py:152 vs :258)."""
+
+    def __init__(self, n_grow: int, fadein_lengths, train_lengths):
+        assert len(fadein_lengths) == n_grow + 1 and len(train_lengths) == n_grow
+        self.n_grow, self.fade = n_grow, list(fadein_lengths)
+        self.train_l, acc = [], 0
+        for t in train_lengths:
+            acc += t
+            self.train_l.append(acc)
+        self.curr_grow = self.sample_idx = self.step_sample_idx = 0
+
+    def grow(self, viewed: int) -> bool:
+        self.sample_idx += viewed
+        self.step_sample_idx += viewed
+        if self.curr_grow >= self.n_grow:
+            return False
+        if self.train_l[self.curr_grow] < self.sample_idx:
+            self.step_sample_idx = 0
+            self.curr_grow += 1
+            return True
+        return False
+
+    @property
+    def alpha(self) -> float:
+        return min(1.0, (1.0 + self.step_sample_idx) / self.fade[self.curr_grow])
+
+
+class AdamState:
+    """torch.optim.Adam as train.py:64-70,175,214,262-272 uses it: state per parameter OBJECT (aliased keys share it), created at
+    the first step in which the parameter has a gradient, `step` counted per parameter, parameters without gradient skipped.
+    Param groups only matter through that per-parameter step count (all groups share lr / betas)."""
+
+    def __init__(self, lr=1e-3, betas=(0.0, 0.9), eps=1e-8):
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.state: Dict[int, dict] = {}
+
+    def step(self, params: Dict[str, torch.Tensor], grads: Dict[str, torch.Tensor]) -> None:
+        done = set()
+        for k, g in grads.items():
+            p = params[k]
+            if id(p) in done:
+                continue
+            done.add(id(p))
+            # "param" keeps the tensor alive (as torch's optimizer does): a dropped head's id() must not be recycled
+            st = self.state.setdefault(id(p), {"step": 0, "exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p),
+                                               "param": p})
+            st["step"] += 1
+            new, st["exp_avg"], st["exp_avg_sq"] = adam_update(p, g.to(p.dtype), st["exp_avg"], st["exp_avg_sq"], st["step"],
+                                                               self.lr, self.betas[0], self.betas[1], self.eps)
+            p.copy_(new)
+
+    def of(self, p: torch.Tensor) -> Optional[dict]:
+        return self.state.get(id(p))
+
+
+class Trajectory:
+    """The body of the reference's training loop (train.py:135-272) on oracle states, one call of `iteration()` per loader batch:
+    D step every iteration (G not detached), G step when iter_idx % 5 == 0, Adam on the stepped net only, then Grower.grow(batch)
+    and -- when it fires and the nets still grow -- next_layer() on both (fresh head/stem drawn from the global RNG, seeded by the
+    caller through `growth_seed`)."""
+
+    def __init__(self, rand_channels: int, grower: GrowerState, dtype=torch.float32, wscale: float = 1.0):
+        self.gs, self.ds = GenState(rand_channels), DiscState(7)
+        self.dtype, self.grower = dtype, grower
+        for st in (self.gs, self.ds):
+            for k in list(st.params.keys()):
+                v = st.params[k]
+                st.params[k] = (v * wscale if k.endswith("weight") else v).to(dtype)
+        self.opt_g, self.opt_d = AdamState(), AdamState()
+        self.iter_idx = 0
+
+    def _retype_new(self, st, keys):
+        for k in keys:
+            st.params[k] = st.params[k].to(self.dtype)
+
+    def iteration(self, x_real, z, eps, z2=None, growth_seed: Optional[int] = None) -> dict:
+        gs, ds, dt = self.gs, self.ds, self.dtype
+        alpha = self.grower.alpha
+        rec = {"iter": self.iter_idx, "level": gs.curr_layer, "alpha": alpha}
+        d = d_step(gs, ds, x_real, z, eps, alpha, dtype=dt)
+        self.opt_d.step(ds.params, d["d_grads"])
+        rec.update(disc_loss=float(d["disc_loss"]), grad_pen=float(d["grad_pen"]), out_real=float(d["out_real"].mean()),
+                   out_fake=float(d["out_fake"].mean()), d_grads=d["d_grads"])
+        if self.iter_idx % 5 == 0:
+            g = g_step(gs, ds, z2, alpha, dtype=dt)
+            self.opt_g.step(gs.params, g["g_grads"])
+            rec.update(gen_loss=float(g["gen_loss"]), g_grads=g["g_grads"])
+        self.iter_idx += 1
+        rec["grew"] = False
+        if self.grower.grow(x_real.shape[0]) and gs.growing:
+            if growth_seed is not None:
+                torch.manual_seed(growth_seed)
+            gs.next_layer()
+            ds.next_layer()
+            self._retype_new(gs, ["_Generator__end_block.0.weight", "_Generator__end_block.0.bias"])
+            self._retype_new(ds, ["_Discriminator__start_block.0.weight", "_Discriminator__start_block.0.bias"])
+            rec["grew"] = True
+        return rec

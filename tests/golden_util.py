@@ -9,7 +9,10 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 FULL_MAX = 4096
 NSAMP = 509
 
-PROGAN_CASES = ["l0_rc8", "l1_rc8_fade", "l3_rc32_fade", "l2_direct", "l2_rc16_fade_scaled"]
+# the last two: weights scaled until the per-sample ||grad_x D(x~)|| straddles 1 / sits near 3 (penalty 0.02 / 40.8 instead of the
+# ~10 of a fresh critic): (||g|| - 1) of both signs, well-conditioned penalty gradients
+PROGAN_CASES = ["l0_rc8", "l1_rc8_fade", "l3_rc32_fade", "l2_direct", "l2_rc16_fade_scaled", "l2_rc16_gpnorm1",
+                "l2_rc16_gpnorm3"]
 
 
 def load(name):
@@ -62,3 +65,7 @@ def build_oracle_states(g):
                     seen.add(id(v))
                     v.mul_(ws)
     return gs, ds
+
+
+def trajectory_inputs(g, it):
+    return tuple(torch.from_numpy(g[f"{name}|{it}"]) for name in ("x_real", "z", "z2", "eps"))

@@ -52,6 +52,28 @@ def test_transforms_match_reference_formulas():
         ChannelMinMaxNorm()(torch.zeros(2, 3, 4, 4))
 
 
+def test_transforms_match_reference_fixture():
+    """tests/golden/transforms.npz: the reference's own ChannelMinMaxNorm / ChangeRange outputs (audio/transforms.py:4-40, run by
+    tools/gen_golden.py) incl. a constant channel, and its Grower.scale_transform at three levels (Resize through the
+    torchvision stand-in = aten bilinear + antialias)."""
+    from golden_util import load
+    from musicgan_amd.audio import ChangeRange, ChannelMinMaxNorm
+    from musicgan_amd.utils import Grower
+    g = load("transforms.npz")
+    x = torch.from_numpy(g["x64"]).to(torch.float)
+    norm = ChannelMinMaxNorm()(x)
+    assert np.max(np.abs(norm.numpy() - g["norm"])) <= 1e-7
+    assert np.max(np.abs(ChangeRange(-1.0, 1.0)(norm).numpy() - g["ranged"])) <= 2e-7
+    assert np.all(g["norm"][1, 0] == 0.0)  # constant channel: (x - min) / (0 + eps) == 0
+    big = torch.from_numpy(g["big32"]).double()
+    grower = Grower(7, [1] * 8, [1] * 7)
+    for level in range(6):
+        if level in (0, 3, 5):
+            y = grower.scale_transform(big.to(torch.float))
+            assert np.max(np.abs(y.numpy() - g[f"scaled_l{level}"])) <= 2e-6, level
+        grower.grow(2)
+
+
 def test_cli_flags_are_the_reference_flags():
     from musicgan_amd.__main__ import build_parser
     p = build_parser()

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import PROGAN_CASES, build_oracle_states, check_tensor, load, sha
+from golden_util import PROGAN_CASES, build_oracle_states, check_tensor, load, sample_idx, sha, trajectory_inputs
 from oracle import audio as OA
 from oracle import progan as O
 
@@ -97,6 +97,93 @@ def test_oracle_shapes_walk_and_nonsquare():
     assert torch.allclose(y, torch.from_numpy(g["ns_out"]), atol=2e-6, rtol=0)
     y = O.gen_forward(g2.params, 2, True, z, 0.37)
     assert torch.allclose(y, torch.from_numpy(g["ns_out_a037"]), atol=2e-6, rtol=0)
+
+
+def test_gp_regime_fixtures_cover_both_signs():
+    """The two scaled-weight fixtures leave the penalty-at-10 regime: per-sample ||grad_x D(x~)|| on both sides of 1 (gpnorm1)
+    and well above it (gpnorm3) -- evaluated with the oracle in fp64 on the fixture's inputs."""
+    norms = {}
+    for case in ("l2_rc16_gpnorm1", "l2_rc16_gpnorm3"):
+        g = load(f"progan_{case}.npz")
+        gs, ds = build_oracle_states(g)
+        x_real, z, eps = (torch.from_numpy(g[k]).double() for k in ("x_real", "z", "eps"))
+        gp_, dp_ = O._leafs(gs, torch.float64), O._leafs(ds, torch.float64)
+        x_fake = O.gen_forward(gp_, gs.curr_layer, gs.has_last, z, float(g["alpha"])).detach()
+        xi = (eps * x_real + (1 - eps) * x_fake).requires_grad_(True)
+        (gx,) = torch.autograd.grad(O.disc_forward(dp_, ds.curr_layer, ds.has_last, xi, float(g["alpha"])).sum(), xi)
+        norms[case] = gx.reshape(gx.shape[0], -1).norm(dim=1)
+        assert abs(float(10 * ((norms[case] - 1) ** 2).mean()) - float(g["grad_pen"])) < 1e-4
+    n1, n3 = norms["l2_rc16_gpnorm1"], norms["l2_rc16_gpnorm3"]
+    assert float(n1.min()) < 1.0 < float(n1.max()) and 0.5 < float(n1.min()) and float(n1.max()) < 2.0
+    assert float(n3.min()) > 1.5
+
+
+def _run_oracle_trajectory(g, dtype):
+    torch.manual_seed(int(g["seed"]))
+    tr = O.Trajectory(int(g["rand_channels"]), O.GrowerState(7, g["fadein"].tolist(), g["train_lengths"].tolist()),
+                      dtype=dtype, wscale=float(g["wscale"]))
+    recs = []
+    for it in range(int(g["iters"])):
+        x_real, z, z2, eps = trajectory_inputs(g, it)
+        recs.append(tr.iteration(x_real, z, eps, z2, growth_seed=int(g["seed"]) + 3000 + tr.gs.curr_layer))
+    return tr, recs
+
+
+def test_oracle_trajectory_matches_reference_loop():
+    """16 iterations of the reference's loop body (train.py:131-272: D step every iteration, G step every 5th, Adam with its
+    second-moment memory, two growths with add_param_group and the aliased old head/stem) run by the REFERENCE in float64
+    (tools/gen_golden.py::trajectory_case) against the oracle's restatement in float64: every loss of every iteration and the
+    final weights / Adam moments / per-parameter step counts."""
+    g = load("progan_trajectory.npz")
+    tr, recs = _run_oracle_trajectory(g, torch.float64)
+    assert [r["level"] for r in recs] == g["ref64|level"].astype(int).tolist() == [0] * 6 + [1] * 5 + [2] * 5
+    assert [int(r["grew"]) for r in recs] == g["ref64|grew"].astype(int).tolist()
+    for it, r in enumerate(recs):
+        assert r["alpha"] == pytest.approx(float(g["ref64|alpha"][it]), abs=1e-15)
+        for key in ("disc_loss", "grad_pen", "out_real", "out_fake"):
+            ref = float(g[f"ref64|{key}"][it])
+            assert abs(r[key] - ref) <= 1e-9 * max(1.0, abs(ref)), f"iteration {it} {key}: {r[key]} vs {ref}"
+        ref = float(g["ref64|gen_loss"][it])
+        assert (it % 5 == 0) == ("gen_loss" in r) == (not np.isnan(ref))
+        if it % 5 == 0:
+            assert abs(r["gen_loss"] - ref) <= 1e-9 * max(1.0, abs(ref))
+    for pre, st, opt in (("g", tr.gs, tr.opt_g), ("d", tr.ds, tr.opt_d)):
+        assert list(st.params.keys()) == list(g[f"{pre}_keys"])
+        steps = dict(zip(g[f"adam_steps|{pre}|keys"].tolist(), g[f"adam_steps|{pre}"].tolist()))
+        for k, p in st.params.items():
+            if f"final64|{pre}|{k}|samp" not in g.files:  # aliased key: the reference's named_parameters() lists the object once
+                continue
+            idx = sample_idx(p.numel())
+            assert np.max(np.abs(p.reshape(-1).numpy()[idx] - g[f"final64|{pre}|{k}|samp"])) <= 1e-9, k
+            ast = opt.of(p)
+            assert (ast["step"] if ast else 0) == steps[k], f"Adam step count of {k}"
+            if ast:
+                ref = g[f"final64|{pre}|{k}|exp_avg_sq|samp"]
+                assert np.max(np.abs(ast["exp_avg_sq"].reshape(-1).numpy()[idx] - ref)) <= 1e-9 * max(1.0, float(ref.max())), k
+    # the step counts the loop must produce (three growths: after iterations 5, 10 and -- with no step behind it -- 15): blocks
+    # count from the iteration that brought them into the graph, heads / stems from their own growth (added param groups)
+    sg = dict(zip(g["adam_steps|g|keys"].tolist(), g["adam_steps|g"].tolist()))
+    assert sg["_Generator__gen_blocks.0.0.weight"] == 4 and sg["_Generator__gen_blocks.1.0.weight"] == 2
+    assert sg["_Generator__gen_blocks.2.0.weight"] == 1 and sg["_Generator__gen_blocks.3.0.weight"] == 0
+    assert sg["_Generator__end_block.0.weight"] == 0 and sg["_Generator__last_end_block.0.0.weight"] == 1
+    sd = dict(zip(g["adam_steps|d|keys"].tolist(), g["adam_steps|d"].tolist()))
+    assert sd["_Discriminator__conv_blocks.7.0.weight"] == 16 and sd["_Discriminator__conv_blocks.6.0.weight"] == 10
+    assert sd["_Discriminator__conv_blocks.5.0.weight"] == 5 and sd["_Discriminator__conv_blocks.4.0.weight"] == 0
+    assert sd["_Discriminator__start_block.0.weight"] == 0 and sd["_Discriminator__last_start_block.1.0.weight"] == 5
+    assert g["adam_groups|g"].tolist() == [34, 2, 2, 2] and g["adam_groups|d"].tolist() == [40, 2, 2, 2]
+
+
+def test_oracle_trajectory_fp32_tracks_reference_fp32():
+    """Same loop in float32 against the reference's float32 run (as the reference really trains).  Both leave the float64
+    trajectory by 1e-9 .. 2e-4 (stored); the oracle must stay within a few times that of the reference's float32 run."""
+    g = load("progan_trajectory.npz")
+    _, recs = _run_oracle_trajectory(g, torch.float32)
+    for key in ("disc_loss", "grad_pen"):
+        ref32, ref64 = g[f"ref32|{key}"], g[f"ref64|{key}"]
+        own = np.abs(ref32 - ref64)
+        for it, r in enumerate(recs):
+            tol = 10 * own[it] + 2e-6 * max(1.0, abs(ref64[it]))
+            assert abs(r[key] - ref32[it]) <= tol, f"iteration {it} {key}: {r[key]} vs {ref32[it]} (tol {tol:.1e})"
 
 
 def test_flop_model_matches_survey():

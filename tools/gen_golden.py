@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from ref_loader import load_audio, load_networks, wav_store  # noqa: E402
+from ref_loader import load_audio, load_networks, load_utils, wav_store  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 FULL_MAX = 4096
@@ -134,6 +134,177 @@ def progan_case(tag, seed, rand_channels, n_grow, alpha, batch, g_end_layer=0, d
           f"g_loss {g_loss.item():.6f}  ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+
+def _scale_weights(nets_list, wscale):
+    with torch.no_grad():
+        for net in nets_list:
+            for k, p in net.named_parameters():
+                if k.endswith("weight"):
+                    p.mul_(wscale)
+
+
+def find_wscale(seed, rand_channels, n_grow, alpha, batch, target_norm):
+    """Weight scale (bisection, 3 significant digits) at which the MEDIAN per-sample ||grad_x D(x~)|| of the reference critic
+    equals `target_norm` on this case's inputs -- leaves the near-zero-critic regime of a fresh init, where the penalty sits at
+    10 and its gradient is a cancellation residue."""
+    nets = load_networks()
+
+    def med_norm(ws):
+        torch.manual_seed(seed)
+        gen, disc = nets.Generator(rand_channels), nets.Discriminator(7)
+        for _ in range(n_grow):
+            gen.next_layer()
+            disc.next_layer()
+        _scale_weights((gen, disc), ws)
+        side = 2 * 2 ** (gen.curr_layer + 1)
+        rng = torch.Generator().manual_seed(seed + 1000)
+        z = torch.randn(batch, rand_channels, 2, 2, generator=rng)
+        torch.randn(batch, rand_channels, 2, 2, generator=rng)
+        x_real = torch.rand(batch, 2, side, side, generator=rng) * 2 - 1
+        torch.manual_seed(seed + 2000)
+        eps = torch.rand(batch, 1, 1, 1)
+        with torch.no_grad():
+            x_fake = gen(z, alpha)
+        xi = (eps * x_real + (1 - eps) * x_fake).requires_grad_(True)
+        (g,) = torch.autograd.grad(disc(xi, alpha).sum(), xi)
+        return float(g.reshape(batch, -1).norm(dim=1).median())
+
+    lo, hi = 1.0, 8.0
+    for _ in range(40):
+        mid = 0.5 * (lo + hi)
+        if med_norm(mid) < target_norm:
+            lo = mid
+        else:
+            hi = mid
+    return float(f"{0.5 * (lo + hi):.3g}")
+
+
+def trajectory_case(tag, seed, rand_channels, batch, iters, fadein, train_lengths, wscale=1.0):
+    """The reference's training loop body (train.py:131-272) for `iters` loader batches on the reference's own Generator /
+    Discriminator / Grower and torch.optim.Adam: D step every iteration, G step when iter_idx % 5 == 0, growth through
+    Grower.grow + next_layer + add_param_group.  Only the device (CPU), the injected inputs (z, x_real at the level's size, the
+    RNG seed in front of gradient_penalty's eps draw and of next_layer's fresh head/stem) and the dtype differ from train.py.
+
+    Run twice: float64 (the yard-stick the oracle is pinned on: deterministic to ~1e-12, so the whole trajectory can be
+    compared) and float32 (as the reference really runs; stored to document that the reference's own fp32 trajectory leaves
+    its fp64 one within a few iterations -- Adam(beta1=0) moves every weight by ~lr*sign(g), so round-off in near-zero gradient
+    entries is amplified to O(lr) per step and the GAN dynamics do the rest)."""
+    nets, U = load_networks(), load_utils()
+    betas = (0.0, 0.9)
+
+    def run(dtype):
+        torch.manual_seed(seed)
+        gen, disc = nets.Generator(rand_channels, end_layer=0), nets.Discriminator(start_layer=7)
+        init_sha = ([sha(v) for v in gen.state_dict().values()], [sha(v) for v in disc.state_dict().values()])
+        if wscale != 1.0:
+            _scale_weights((gen, disc), wscale)
+        gen, disc = gen.to(dtype), disc.to(dtype)
+        og = torch.optim.Adam(gen.parameters(), lr=1e-3, betas=betas)
+        od = torch.optim.Adam(disc.parameters(), lr=1e-3, betas=betas)
+        grower = U.Grower(n_grow=7, fadein_lengths=list(fadein), train_lengths=list(train_lengths))
+        rng = torch.Generator().manual_seed(seed + 1000)
+        recs, inputs, heads = [], [], []
+        for it in range(iters):
+            side = 4 * 2 ** gen.curr_layer
+            x_real = torch.rand(batch, 2, side, side, generator=rng) * 2 - 1
+            z = torch.randn(batch, rand_channels, 2, 2, generator=rng)
+            z2 = torch.randn(batch, rand_channels, 2, 2, generator=rng)
+            alpha = grower.alpha
+            x_fake = gen(z.to(dtype), alpha)
+            out_real, out_fake = disc(x_real.to(dtype), alpha), disc(x_fake, alpha)
+            d_loss = nets.wasserstein_discriminator_loss(out_real, out_fake)
+            torch.manual_seed(seed + 2000 + it)  # gradient_penalty draws eps = th.rand(batch,1,1,1) from the global generator
+            eps = torch.rand(batch, 1, 1, 1)
+            torch.manual_seed(seed + 2000 + it)
+            gp = disc.gradient_penalty(x_real.to(dtype), x_fake, alpha)
+            gen.zero_grad()
+            disc.zero_grad()
+            (d_loss + gp).backward()
+            od.step()
+            r = {"level": gen.curr_layer, "alpha": alpha, "disc_loss": d_loss.item(), "grad_pen": gp.item(),
+                 "out_real": out_real.mean().item(), "out_fake": out_fake.mean().item(), "gen_loss": np.nan, "grew": 0}
+            if it % 5 == 0:
+                x_fake = gen(z2.to(dtype), alpha)
+                out_fake = disc(x_fake, alpha)
+                g_loss = nets.wasserstein_generator_loss(out_fake)
+                gen.zero_grad()
+                disc.zero_grad()
+                g_loss.backward()
+                og.step()
+                r["gen_loss"] = g_loss.item()
+            inputs.append((x_real, z, z2, eps))
+            if grower.grow(batch) and gen.growing:
+                torch.manual_seed(seed + 3000 + gen.curr_layer)  # fresh head / stem come from the global generator
+                gen.next_layer()
+                disc.next_layer()
+                heads.append([sha(p) for p in gen.end_block_params()] + [sha(p) for p in disc.start_block_parameters()])
+                gen, disc = gen.to(dtype), disc.to(dtype)
+                og.add_param_group({"params": gen.end_block_params(), "lr": 1e-3, "betas": betas})
+                od.add_param_group({"params": disc.start_block_parameters(), "lr": 1e-3, "betas": betas})
+                r["grew"] = 1
+            recs.append(r)
+        return recs, inputs, heads, gen, disc, og, od, init_sha
+
+    r64, inputs, heads, gen, disc, og, od, init_sha = run(torch.float64)
+    r32 = run(torch.float32)[0]
+    store = {"seed": seed, "rand_channels": rand_channels, "batch": batch, "iters": iters, "wscale": wscale,
+             "fadein": np.array(fadein), "train_lengths": np.array(train_lengths),
+             "g_init_sha": np.array(init_sha[0]), "d_init_sha": np.array(init_sha[1]), "new_head_sha": np.array(heads)}
+    for it, (x_real, z, z2, eps) in enumerate(inputs):
+        store.update({f"x_real|{it}": x_real.numpy(), f"z|{it}": z.numpy(), f"z2|{it}": z2.numpy(), f"eps|{it}": eps.numpy()})
+    for name, recs in (("ref64", r64), ("ref32", r32)):
+        for key in ("level", "alpha", "disc_loss", "grad_pen", "out_real", "out_fake", "gen_loss", "grew"):
+            store[f"{name}|{key}"] = np.array([r[key] for r in recs], dtype=np.float64)
+    # final state of the float64 run: every parameter (subsampled), and the Adam state the loop built up
+    store["g_keys"] = np.array(list(gen.state_dict().keys()))
+    store["d_keys"] = np.array(list(disc.state_dict().keys()))
+    for pre, net, opt in (("g", gen, og), ("d", disc, od)):
+        steps = {}
+        for k, p in net.named_parameters():
+            store[f"final64|{pre}|{k}|samp"] = p.detach().reshape(-1).numpy()[sample_idx(p.numel())]
+            st = opt.state.get(p)
+            steps[k] = int(st["step"]) if st else 0
+            if st:
+                store[f"final64|{pre}|{k}|exp_avg_sq|samp"] = st["exp_avg_sq"].reshape(-1).numpy()[sample_idx(p.numel())]
+        store[f"adam_steps|{pre}|keys"] = np.array(list(steps.keys()))
+        store[f"adam_steps|{pre}"] = np.array(list(steps.values()))
+        store[f"adam_groups|{pre}"] = np.array([len(gr["params"]) for gr in opt.param_groups])
+    path = os.path.join(OUT, f"progan_{tag}.npz")
+    np.savez_compressed(path, **store)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB): levels {[int(r['level']) for r in r64]}")
+    for a, b in zip(r64, r32):
+        print(f"   L{a['level']} alpha {a['alpha']:.3f}  d_loss {a['disc_loss']:+.6e} (fp32 off by {abs(a['disc_loss'] - b['disc_loss']):.1e})"
+              f"  gp {a['grad_pen']:.6f} (fp32 off by {abs(a['grad_pen'] - b['grad_pen']):.1e})")
+
+
+def transforms_case():
+    """audio/transforms.py:4-40 (ChannelMinMaxNorm, ChangeRange) run by the reference itself on float32 and on float64-born
+    samples the way train.py:139 feeds them (`.to(th.float)` first), plus the reference Grower's whole scale_transform at two
+    levels.  The Resize inside scale_transform is the torchvision stand-in of tools/ref_loader.py (aten bilinear + antialias):
+    `scaled_*` is therefore pinned on torch, `norm_*` / `ranged_*` on the reference's own code alone."""
+    audio, U = load_audio(), load_utils()
+    rng = torch.Generator().manual_seed(31)
+    x = torch.randn(3, 2, 64, 64, generator=rng, dtype=torch.float64) * torch.tensor([1.0, 40.0]).view(1, 2, 1, 1) + 3.0
+    x[1, 0] = 0.25  # a constant channel: (x - min) / (0 + eps)
+    xf = x.to(torch.float)
+    norm = audio.ChannelMinMaxNorm()(xf)
+    ranged = audio.ChangeRange(-1.0, 1.0)(norm)
+    store = {"x64": x.numpy(), "norm": norm.numpy(), "ranged": ranged.numpy()}
+    # one stored sample (2,512,512) as create_dataset writes it (float64 on disk; values kept float32-representable so the
+    # fixture stores 2 MB instead of 4), through the reference Grower's scale_transform at levels 0, 3 and 5
+    big = torch.rand(1, 2, 512, 512, generator=rng) * 2 - 1
+    big[:, 1] = big[:, 1].cumsum(-1) * 0.01
+    store["big32"] = big.numpy()
+    grower = U.Grower(n_grow=7, fadein_lengths=[1] * 8, train_lengths=[1] * 7)
+    for level in range(6):
+        if level in (0, 3, 5):
+            store[f"scaled_l{level}"] = grower.scale_transform(big.to(torch.float64).to(torch.float)).numpy()
+        grower.grow(2)
+    path = os.path.join(OUT, "transforms.npz")
+    np.savez_compressed(path, **store)
+    print("wrote", path, f"({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 def progan_shapes_case():
     """The walk of networks/test_networks.py:4-38 (shapes at every level, growing flags), plus a non-square
     forward as generate.py:47-54 uses it."""
@@ -214,5 +385,13 @@ if __name__ == "__main__":
     progan_case("l2_direct", seed=14, rand_channels=16, n_grow=0, alpha=0.6, batch=2, g_end_layer=2,
                 d_start_layer=5)
     progan_case("l2_rc16_fade_scaled", seed=15, rand_channels=16, n_grow=2, alpha=0.5, batch=4, wscale=1.7)
+    # the well-conditioned penalty regime: weights scaled until the median ||grad_x D(x~)|| is ~1 (samples on both sides of 1,
+    # so (||g|| - 1) takes both signs) and ~3 (all positive)
+    for tag, target in (("l2_rc16_gpnorm1", 1.0), ("l2_rc16_gpnorm3", 3.0)):
+        ws = find_wscale(seed=16, rand_channels=16, n_grow=2, alpha=0.5, batch=4, target_norm=target)
+        progan_case(tag, seed=16, rand_channels=16, n_grow=2, alpha=0.5, batch=4, wscale=ws)
+    trajectory_case("trajectory", seed=21, rand_channels=8, batch=3, iters=16, fadein=[1, 12, 12, 12, 12, 12, 12, 12],
+                    train_lengths=[15, 15, 15, 15, 15, 15, 15])
+    transforms_case()
     progan_shapes_case()
     audio_case()

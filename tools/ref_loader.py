@@ -104,3 +104,58 @@ def load_audio():
 
 def wav_store():
     return _WAV_STORE
+
+
+def _install_torchvision_standin():
+    """`music_gan/utils.py:7` needs torchvision.transforms.{Compose, Resize} (absent, unpinned).  Compose is restated
+    verbatim (call the transforms in order); Resize(int) on a square (N,C,H,W) tensor is restated on aten's bilinear
+    interpolation with anti-aliasing, torchvision's tensor default -- so anything that goes through Resize is pinned on torch,
+    not on torchvision (recorded in DESIGN.md).  The schedule arithmetic of `Grower` (grow / alpha) never touches it."""
+    import torch
+
+    if "torchvision" in sys.modules:
+        return
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+
+    class Compose:
+        def __init__(self, transforms):
+            self.transforms = transforms
+
+        def __call__(self, x):
+            for t in self.transforms:
+                x = t(x)
+            return x
+
+    class Resize:
+        def __init__(self, size):
+            self.size = size
+
+        def __call__(self, x):
+            if tuple(x.shape[-2:]) == (self.size, self.size):
+                return x
+            return torch.nn.functional.interpolate(x, size=(self.size, self.size), mode="bilinear", antialias=True,
+                                                   align_corners=False)
+
+    tvt.Compose, tvt.Resize = Compose, Resize
+    tv.transforms = tvt
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.transforms"] = tvt
+
+
+def load_utils():
+    """The reference's `utils.py` (Grower, Saver) as module `music_gan.utils`."""
+    _install_torchaudio_standin()
+    _install_torchvision_standin()
+    import matplotlib
+    matplotlib.use("Agg")
+    _load("networks")
+    _load("audio")
+    name = "music_gan.utils"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF_ROOT, "utils.py"))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
