@@ -368,7 +368,10 @@ __global__ void __launch_bounds__(256) conv3x3_tiny(const ConvArgs a) {
   const bool ups = (a.flags & MG_CONV_UPS_IN) != 0;
   const int HWin = a.Hin * a.Win;
   const float* xn = a.x + (size_t)n * a.Cin * HWin;
-  float acc = a.bias != nullptr ? a.bias[o] : 0.f;
+  // fp64 accumulation (each fp32 product is exact in fp64; the work is a few hundred fmas per thread on a full-rate fp64 VALU): this
+  // layer's output is the classifier's input, and the classifier weight gradient -- a difference of mean features -- inherits its
+  // round-off one to one (tools/diag_act_noise.py: 4.2x the CPU library's rms error with a sequential fp32 sum, 1x with this)
+  double acc64 = a.bias != nullptr ? (double)a.bias[o] : 0.0;
   for (int t = 0; t < 9; ++t) {
     const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
     if (yy < 0 || yy >= a.H || xx < 0 || xx >= a.W) continue;
@@ -376,8 +379,9 @@ __global__ void __launch_bounds__(256) conv3x3_tiny(const ConvArgs a) {
     const float* wt = a.wp + (size_t)t * CC * a.OPF + o;
 #pragma unroll 4
     for (int c = 0; c < a.Cin; ++c)
-      acc = fmaf(xn[(size_t)c * HWin + sp], wt[((size_t)(c >> 3) * 9 * CC + (c & 7)) * a.OPF], acc);
+      acc64 += (double)xn[(size_t)c * HWin + sp] * (double)wt[((size_t)(c >> 3) * 9 * CC + (c & 7)) * a.OPF];
   }
+  float acc = (float)acc64;
   const size_t idx = ((size_t)n * a.Cout + o) * HW + pix;
   if (a.flags & MG_CONV_LRELU) acc = mg_lrelu(acc, a.slope);
   if (a.flags & MG_CONV_MASK_AUX) acc *= mg_lrelu_mask(a.aux[idx], a.slope);

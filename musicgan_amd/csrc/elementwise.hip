@@ -369,11 +369,11 @@ __global__ void __launch_bounds__(1024) channel_sum_k(const float* __restrict__ 
 __global__ void __launch_bounds__(64) linear1_fwd_k(const float* __restrict__ x, const float* __restrict__ w,
                                                     const float* __restrict__ b, float* __restrict__ y, int K) {
   const int n = blockIdx.x;
-  float s = 0.f;
-  for (int k = threadIdx.x; k < K; k += 64) s = fmaf(w[k], x[(size_t)n * K + k], s);
+  double s = 0.0;  // K = 160 exact products summed in fp64: the critic score feeds a difference of batch means
+  for (int k = threadIdx.x; k < K; k += 64) s += (double)w[k] * (double)x[(size_t)n * K + k];
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
-  if (threadIdx.x == 0) y[n] = s + (b ? b[0] : 0.f);
+  if (threadIdx.x == 0) y[n] = (float)(s + (b ? (double)b[0] : 0.0));
 }
 
 __global__ void __launch_bounds__(256) linear1_bwd_k(const float* __restrict__ x, const float* __restrict__ w,

@@ -259,6 +259,15 @@ def d_step(gs: GenState, ds: DiscState, x_real, z, eps, alpha, dtype=torch.float
     }
 
 
+def real_term_grads(ds: DiscState, x_real, alpha, dtype=torch.float64):
+    """d mean(D(x_real)) / d theta: ONE of the summands of the critic gradient (criterion.py:12-14).  At a fresh init the real and
+    the fake term nearly cancel in the deep blocks and in the classifier; the un-cancelled term is the scale fp32 round-off of such
+    a residue has to be judged on."""
+    dp_ = _leafs(ds, dtype)
+    disc_forward(dp_, ds.curr_layer, ds.has_last, x_real.to(dtype), alpha).mean().backward()
+    return OrderedDict((k, dp_[k].grad.detach()) for k in ds.live_keys())
+
+
 def g_step(gs: GenState, ds: DiscState, z, alpha, dtype=torch.float32):
     """train.py:191-213."""
     gp_, dp_ = _leafs(gs, dtype), _leafs(ds, dtype)
@@ -389,7 +398,9 @@ class Trajectory:
         for k in keys:
             st.params[k] = st.params[k].to(self.dtype)
 
-    def iteration(self, x_real, z, eps, z2=None, growth_seed: Optional[int] = None) -> dict:
+    def iteration(self, x_real, z, eps, z2=None, growth_seed: Optional[int] = None, defer_growth: bool = False) -> dict:
+        """`defer_growth`: stop in front of train.py:258 (state inspection by the lock-step test); the caller then runs
+        `end_of_iteration(batch, growth_seed)` itself."""
         gs, ds, dt = self.gs, self.ds, self.dtype
         alpha = self.grower.alpha
         rec = {"iter": self.iter_idx, "level": gs.curr_layer, "alpha": alpha}
@@ -402,13 +413,19 @@ class Trajectory:
             self.opt_g.step(gs.params, g["g_grads"])
             rec.update(gen_loss=float(g["gen_loss"]), g_grads=g["g_grads"])
         self.iter_idx += 1
-        rec["grew"] = False
-        if self.grower.grow(x_real.shape[0]) and gs.growing:
+        if not defer_growth:
+            rec["grew"] = self.end_of_iteration(x_real.shape[0], growth_seed)
+        return rec
+
+    def end_of_iteration(self, batch: int, growth_seed: Optional[int] = None) -> bool:
+        """train.py:258-272."""
+        gs, ds = self.gs, self.ds
+        if self.grower.grow(batch) and gs.growing:
             if growth_seed is not None:
                 torch.manual_seed(growth_seed)
             gs.next_layer()
             ds.next_layer()
             self._retype_new(gs, ["_Generator__end_block.0.weight", "_Generator__end_block.0.bias"])
             self._retype_new(ds, ["_Discriminator__start_block.0.weight", "_Discriminator__start_block.0.bias"])
-            rec["grew"] = True
-        return rec
+            return True
+        return False

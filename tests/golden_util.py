@@ -69,3 +69,25 @@ def build_oracle_states(g):
 
 def trajectory_inputs(g, it):
     return tuple(torch.from_numpy(g[f"{name}|{it}"]) for name in ("x_real", "z", "z2", "eps"))
+
+
+GRAD_TOL = 1e-3
+
+
+def maxabs_err(a, b):
+    return float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max())
+
+
+def grad_atol(k, ref64, ref32, terms64=None):
+    """Absolute error budget of gradient tensor k against the fp64 oracle -- SURVEY 8(c): the larger of
+      * 1e-3 of the tensor's own max-norm, and
+      * twice the plain-PyTorch fp32 evaluation's own deviation from fp64 on that tensor;
+    and, for critic tensors (`terms64` = oracle.real_term_grads), 1e-6 of the max-norm of ONE un-cancelled summand of that
+    gradient, d mean(D(x_real))/d theta: the critic gradient is -term_real + term_fake + penalty term, and where those cancel
+    (classifier weight and deep-block biases at a fresh init: |g| ~ 1e-6 .. exactly 0 from summands ~ 1e-2) the fp32 round-off
+    of the summands (~2e-7 relative, tools/diag_act_noise.py) is all that is left of the tensor -- no fp32 implementation can be
+    closer than that to fp64, the CPU one is at 1e-7 .. 4e-7 of the term."""
+    tol = max(GRAD_TOL * float(ref64[k].abs().max()), 2.0 * maxabs_err(ref32[k], ref64[k]))
+    if terms64 is not None:
+        tol = max(tol, 1e-6 * float(terms64[k].abs().max()))
+    return tol

@@ -8,13 +8,12 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import PROGAN_CASES, build_oracle_states, check_tensor, load, sample_idx
+from golden_util import GRAD_TOL, PROGAN_CASES, build_oracle_states, check_tensor, grad_atol, load, maxabs_err, sample_idx
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 FWD_TOL = 1e-5
-GRAD_TOL = 1e-3
 
 
 def build_modules(g):
@@ -38,26 +37,6 @@ def build_modules(g):
 def maxrel(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
-
-
-def maxabs_err(a, b):
-    return float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max())
-
-
-def grad_atol(k, ref64, ref32):
-    """Absolute error budget of gradient tensor k against the fp64 oracle, the largest of
-      * 1e-3 of the tensor's own max-norm,
-      * five times the plain-PyTorch fp32 evaluation's own deviation from fp64 on that tensor (the fp32 MFMA accumulates
-        K <= 1440 products sequentially, one rounding per fma, where the CPU library uses blocked partial sums: activations
-        carry ~2e-6 instead of ~5e-7 relative round-off, which cancellation-dominated gradients amplify alike),
-      * 5e-5 of the largest gradient entry anywhere in the network: tensors whose entries sit 3+ orders below the network's
-        gradient scale are cancellation residues (e.g. the classifier weight: -mean(real features) + mean(fake features)
-        + penalty term, |g| ~ 1e-6 from summands ~ 1e-2) and carry the fp32 round-off of their summands (a few 1e-7 of
-        0.05-sized features = 1e-8 absolute, which is what is observed), not of themselves; the plain-PyTorch fp32
-        evaluation deviates by 1.5e-3 relative on the same tensor."""
-    gmax = max(float(v.abs().max()) for v in ref64.values())
-    own = float(ref64[k].abs().max())
-    return max(GRAD_TOL * own, 5.0 * maxabs_err(ref32[k], ref64[k]), 5e-5 * gmax)
 
 
 @pytest.fixture(params=["auto", "wino_everywhere"])
@@ -91,6 +70,7 @@ def test_train_step_matches_reference_golden(case, conv_mode):
     oargs = (torch.from_numpy(g["x_real"]), torch.from_numpy(g["z"]), torch.from_numpy(g["eps"]), alpha)
     o64 = O.d_step(gs, ds, *oargs, dtype=torch.float64)
     o32 = O.d_step(gs, ds, *oargs, dtype=torch.float32)
+    terms = O.real_term_grads(ds, oargs[0], alpha)
 
     def grad_tol(k, which="d_grads"):
         # 1e-3 * max|g| vs fp64, or twice the plain-PyTorch fp32 evaluation's own deviation from fp64
@@ -113,8 +93,9 @@ def test_train_step_matches_reference_golden(case, conv_mode):
     # the loss is a difference of two output means, each carrying the forward tolerance
     out_scale = max(float(np.abs(g["out_real"]).max()), float(np.abs(g["out_fake"]).max()))
     assert abs(float(d_loss) - float(g["disc_loss"])) <= 1e-6 + 2 * FWD_TOL * out_scale
-    assert abs(float(grad_pen) - float(g["grad_pen"])) <= 1e-5
-    assert abs(float(grad_pen) - float(o64["grad_pen"])) <= 1e-5
+    gp_tol = 1e-5 * max(1.0, float(g["grad_pen"]) / 10.0)  # 1e-6 relative to the penalty of a fresh critic (10)
+    assert abs(float(grad_pen) - float(g["grad_pen"])) <= gp_tol
+    assert abs(float(grad_pen) - float(o64["grad_pen"])) <= gp_tol
 
     live = {k: p for k, p in disc.named_parameters() if p.grad is not None}
     assert sorted(live.keys()) == sorted(g["dstep_d_live"])
@@ -122,7 +103,7 @@ def test_train_step_matches_reference_golden(case, conv_mode):
     for k, p in live.items():
         e = maxrel(p.grad, o64["d_grads"][k])
         worst = max(worst, e)
-        atol = grad_atol(k, o64["d_grads"], o32["d_grads"])
+        atol = grad_atol(k, o64["d_grads"], o32["d_grads"], terms)
         assert maxabs_err(p.grad, o64["d_grads"][k]) <= atol, f"D grad {k}: rel {e:.3e} vs fp64 oracle"
         own = max(float(o64["d_grads"][k].abs().max()), 1e-30)
         check_tensor(g, f"dstep_dgrad|{k}", p.grad, 2 * max(grad_tol(k), atol / own), what="golden ")
@@ -144,11 +125,15 @@ def test_train_step_matches_reference_golden(case, conv_mode):
         exp, _, _ = O.adam_update(w0.double().cpu(), gr.double().cpu(), torch.zeros_like(w0).double().cpu(),
                                   torch.zeros_like(w0).double().cpu(), 1)
         assert maxrel(p, exp) <= 2e-6, f"Adam kernel {k}"
-        # (b) vs the reference's weights: the first step is lr*g/(|g|+1e-8), which amplifies fp32 round-off of entries with
-        # |g| ~ 1e-8 (the near-zero penalty gradients of a fresh critic); bound: a small fraction of one lr step
-        samp = g[f"dstep_dparam|{k}|samp"]
+        # (b) vs the reference's post-Adam weights, element by element: the first step is w - lr*g/(|g|+1e-8), so a gradient
+        # error dg moves the result by lr*dg/(|g|+1e-8) -- the gradient budget of this tensor carried through the update rule
+        # (tight wherever |g| is above the budget, i.e. for nearly every entry; a wrong bias correction would scale every step)
+        samp, gsamp = g[f"dstep_dparam|{k}|samp"], g[f"dstep_dgrad|{k}|samp"]
         got = p.detach().cpu().reshape(-1).numpy()[sample_idx(p.numel())]
-        assert float(np.abs(got - samp).max()) <= 0.25 * 1e-3, f"post-Adam {k}"
+        budget = 2 * grad_atol(k, o64["d_grads"], o32["d_grads"], terms)  # ours and the reference's fp32 gradient, both vs fp64
+        tol = 1e-3 * np.minimum(2.0, budget / (np.abs(gsamp) + 1e-8)) + 2e-7
+        assert np.all(np.abs(got - samp) <= tol), f"post-Adam {k}: {np.abs(got - samp).max():.2e}"
+        assert float(np.mean(tol < 0.05 * 1e-3)) > (0.5 if gsamp.size > 64 else 0.0), f"post-Adam {k}: check is vacuous"
 
     # ---- G step, train.py:191-214
     x_fake2 = gen(z2, alpha)
@@ -166,7 +151,13 @@ def test_train_step_matches_reference_golden(case, conv_mode):
     for k, p in gen.named_parameters():
         samp = g[f"gstep_gparam|{k}|samp"]
         got = p.detach().cpu().reshape(-1).numpy()[sample_idx(p.numel())]
-        assert float(np.abs(got - samp).max()) <= 0.25 * 1e-3, f"post-Adam {k}"
+        if f"gstep_ggrad|{k}|samp" not in g.files:
+            assert np.array_equal(got, samp), f"{k}: parameter without gradient must not move"
+            continue
+        gsamp = g[f"gstep_ggrad|{k}|samp"]
+        budget = 2 * GRAD_TOL * float(g[f"gstep_ggrad|{k}|maxabs"])
+        tol = 1e-3 * np.minimum(2.0, budget / (np.abs(gsamp) + 1e-8)) + 2e-7
+        assert np.all(np.abs(got - samp) <= tol), f"post-Adam {k}: {np.abs(got - samp).max():.2e}"
     print(f"{case}: worst D-grad rel err vs fp64 {worst:.2e}")
 
 
@@ -226,6 +217,7 @@ def test_level4_step_against_oracle(conv_mode):
     eps = torch.rand(n, 1, 1, 1, generator=rng)
     ref = O.d_step(gs, ds, x_real, z, eps, 0.5, dtype=torch.float64, detach_fake=True)
     ref32 = O.d_step(gs, ds, x_real, z, eps, 0.5, dtype=torch.float32, detach_fake=True)
+    terms = O.real_term_grads(ds, x_real, 0.5)
     x_fake = gen(z.to(DEV), 0.5).detach()
     out_real = disc(x_real.to(DEV), 0.5)
     out_fake = disc(x_fake, 0.5)
@@ -236,12 +228,91 @@ def test_level4_step_against_oracle(conv_mode):
     assert maxrel(x_fake, ref["x_fake"]) <= FWD_TOL
     for k, p in disc.named_parameters():
         if p.grad is not None:
-            atol = grad_atol(k, ref["d_grads"], ref32["d_grads"])
+            atol = grad_atol(k, ref["d_grads"], ref32["d_grads"], terms)
             assert maxabs_err(p.grad, ref["d_grads"][k]) <= atol, f"{k}: rel {maxrel(p.grad, ref['d_grads'][k]):.2e}"
     assert all(p.grad is None for p in gen.parameters())
 
 
-@pytest.mark.parametrize("case", ["l1_rc8_fade", "l3_rc32_fade", "l2_direct"])
+
+_ORACLE_CACHE = {}
+
+
+def _oracle_full_step(level, batch):
+    """fp64 / fp32 CPU oracle of one D step + one G step (critic not yet updated) at a BASELINE.json size; cached across the
+    kernel-mode parametrisation (L4 batch 32 in fp64 with the double backward takes a few seconds on the box's 16 cores)."""
+    key = (level, batch)
+    if key not in _ORACLE_CACHE:
+        import bench
+        from oracle import progan as O
+        torch.set_num_threads(bench.host_cpu_share())
+        torch.manual_seed(0)
+        gs, ds = O.GenState(32), O.DiscState(7)
+        for _ in range(level):
+            gs.next_layer()
+            ds.next_layer()
+        side = bench.LEVEL_SIDE[level]
+        rng = torch.Generator().manual_seed(1234)
+        x_real = torch.rand(batch, 2, side, side, generator=rng) * 2 - 1
+        z = torch.randn(batch, 32, 2, 2, generator=rng)
+        z2 = torch.randn(batch, 32, 2, 2, generator=rng)
+        eps = torch.rand(batch, 1, 1, 1, generator=rng)
+        res = {"inputs": (x_real, z, z2, eps), "terms": O.real_term_grads(ds, x_real, 0.5)}
+        for name, dt in (("64", torch.float64), ("32", torch.float32)):
+            res["d" + name] = O.d_step(gs, ds, x_real, z, eps, 0.5, dtype=dt, detach_fake=True)
+            res["g" + name] = O.g_step(gs, ds, z2, 0.5, dtype=dt)
+        _ORACLE_CACHE[key] = res
+    return _ORACLE_CACHE[key]
+
+
+@pytest.mark.parametrize("level,batch", [(5, 2), (4, 32)])
+def test_full_size_step_against_fp64_oracle(level, batch, conv_mode):
+    """BASELINE.json's shapes against the ORACLE (not against another HIP path): the headline level 5 (2x128x128; batch 2 -- the
+    critic then runs on 6 images, every kernel on the tiling it uses at batch 64) and configs[1] in full (level 4, 2x64x64,
+    batch 32), through the product's training path -- ProGANStepper's fused critic step and its generator step: generated
+    images, critic scores' means, both losses, the penalty, every critic gradient and every generator gradient."""
+    import bench
+    from musicgan_amd.optim import FusedAdam
+    from musicgan_amd.train_step import ProGANStepper
+    ref = _oracle_full_step(level, batch)
+    x_real, z, z2, eps = (t.to(DEV) for t in ref["inputs"])
+    gen, disc = bench.build_nets(level, 32, DEV)
+    og = FusedAdam(gen.parameters(), lr=1e-3, betas=(0.0, 0.9))
+    od = FusedAdam(disc.parameters(), lr=1e-3, betas=(0.0, 0.9))
+    od.step = lambda *a, **k: None  # keep the gradients observable and the critic un-updated for the G step, as in the oracle
+    og.step = lambda *a, **k: None
+    st = ProGANStepper(gen, disc, og, od, 32)
+    with torch.no_grad():
+        assert maxrel(gen(z, 0.5), ref["d64"]["x_fake"]) <= FWD_TOL
+    m = st.d_step(x_real, 0.5, z=z, eps=eps)
+    d64, d32 = ref["d64"], ref["d32"]
+    out_scale = float(d64["out_real"].abs().max())
+    assert abs(float(m["disc_loss"]) - float(d64["disc_loss"])) <= 1e-6 + 2 * FWD_TOL * out_scale
+    assert abs(float(m["out_real_mean"]) - float(d64["out_real"].mean())) <= 1e-6 + FWD_TOL * out_scale
+    assert abs(float(m["out_fake_mean"]) - float(d64["out_fake"].mean())) <= 1e-6 + FWD_TOL * out_scale
+    assert abs(float(m["grad_pen"]) - float(d64["grad_pen"])) <= 1e-5
+    live = {k: p.grad for k, p in disc.named_parameters() if p.grad is not None}
+    assert sorted(live) == sorted(d64["d_grads"])
+    worst = 0.0
+    for k, gr in live.items():
+        atol = grad_atol(k, d64["d_grads"], d32["d_grads"], ref["terms"])
+        e = maxabs_err(gr, d64["d_grads"][k])
+        worst = max(worst, e / atol)
+        assert e <= atol, f"D grad {k}: {e:.3e} > {atol:.3e} (own max {float(d64['d_grads'][k].abs().max()):.2e})"
+    mg = st.g_step(batch, 0.5, DEV, z=z2)
+    g64, g32 = ref["g64"], ref["g32"]
+    assert abs(float(mg["gen_loss"]) - float(g64["gen_loss"])) <= 1e-6 + FWD_TOL * float(g64["out_fake"].abs().max())
+    live = {k: p.grad for k, p in gen.named_parameters() if p.grad is not None}
+    assert sorted(live) == sorted(g64["g_grads"])
+    for k, gr in live.items():
+        atol = grad_atol(k, g64["g_grads"], g32["g_grads"])
+        e = maxabs_err(gr, g64["g_grads"][k])
+        worst = max(worst, e / atol)
+        assert e <= atol, f"G grad {k}: {e:.3e} > {atol:.3e}"
+    assert all(p.grad is None for p in disc.parameters())  # the G step leaves no critic gradient behind (train.py:209)
+    print(f"level {level} batch {batch} [{conv_mode}]: worst gradient error / budget {worst:.2f}")
+
+
+@pytest.mark.parametrize("case", ["l1_rc8_fade", "l3_rc32_fade", "l2_direct", "l2_rc16_gpnorm1", "l2_rc16_gpnorm3"])
 def test_fused_d_step_equals_module_path(case, conv_mode):
     """ProGANStepper's fused critic step (one batched pass over [real|fake|interpolated], in-place tangent pass, one wgrad
     launch per layer) produces the gradients of the reference-shaped module path and of the fp64 oracle."""
@@ -256,6 +327,7 @@ def test_fused_d_step_equals_module_path(case, conv_mode):
     oargs = (torch.from_numpy(g["x_real"]), torch.from_numpy(g["z"]), torch.from_numpy(g["eps"]), alpha)
     o64 = O.d_step(gs, ds, *oargs, dtype=torch.float64, detach_fake=True)
     o32 = O.d_step(gs, ds, *oargs, dtype=torch.float32, detach_fake=True)
+    terms = O.real_term_grads(ds, oargs[0], alpha)
     grads = {}
     for fused in (False, True):
         gen, disc = build_modules(g)
@@ -265,7 +337,7 @@ def test_fused_d_step_equals_module_path(case, conv_mode):
         st = ProGANStepper(gen, disc, og, od, int(g["rand_channels"]), fused_d_step=fused)
         m = st.d_step(x_real, alpha, z=z, eps=eps)
         assert abs(float(m["disc_loss"]) - float(o64["disc_loss"])) <= 1e-6 + 2e-5 * float(np.abs(g["out_real"]).max())
-        assert abs(float(m["grad_pen"]) - float(o64["grad_pen"])) <= 1e-5
+        assert abs(float(m["grad_pen"]) - float(o64["grad_pen"])) <= 1e-5 * max(1.0, float(o64["grad_pen"]) / 10.0)
         grads[fused] = {k: p.grad.detach().clone() for k, p in disc.named_parameters() if p.grad is not None}
         assert all(p.grad is None for p in gen.parameters())
     assert sorted(grads[True].keys()) == sorted(grads[False].keys()) == sorted(o64["d_grads"].keys())
@@ -274,7 +346,7 @@ def test_fused_d_step_equals_module_path(case, conv_mode):
             # clf bias: d/db of -(mean D(real) - mean D(fake)) is exactly -1 + 1 = 0; fp32 leaves one rounding of 1/N sums
             assert float(grads[True][k].abs().max()) <= 1e-6 and float(grads[False][k].abs().max()) <= 1e-6
             continue
-        atol = grad_atol(k, o64["d_grads"], o32["d_grads"])
+        atol = grad_atol(k, o64["d_grads"], o32["d_grads"], terms)
         assert maxabs_err(grads[True][k], ref) <= atol, f"fused {k}: rel {maxrel(grads[True][k], ref):.2e}"
         assert maxabs_err(grads[True][k], grads[False][k]) <= 2 * atol, f"fused vs module {k}"
 

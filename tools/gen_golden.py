@@ -40,7 +40,9 @@ def put_tensor(store, name, t):
     store[name + "|maxabs"] = np.float64(t.abs().max().item())
 
 
-def progan_case(tag, seed, rand_channels, n_grow, alpha, batch, g_end_layer=0, d_start_layer=7, wscale=1.0):
+def progan_case(tag, seed, rand_channels, n_grow, alpha, batch, g_end_layer=0, d_start_layer=7, wscale=1.0,
+                min_kink_margin=None):
+    """Returns False (nothing written) when `min_kink_margin` is given and some LeakyReLU input of the step is closer to 0."""
     nets = load_networks()
     torch.manual_seed(seed)
     gen = nets.Generator(rand_channels, end_layer=g_end_layer)
@@ -75,6 +77,15 @@ def progan_case(tag, seed, rand_channels, n_grow, alpha, batch, g_end_layer=0, d
     x_real = torch.rand(batch, 2, side, side, generator=rng) * 2 - 1
     eps = torch.rand(batch, 1, 1, 1, generator=rng)
     store.update(z=z.numpy(), z2=z2.numpy(), x_real=x_real.numpy(), eps=eps.numpy())
+
+    if min_kink_margin is not None:
+        torch.manual_seed(seed + 2000)
+        e = torch.rand(batch, 1, 1, 1)
+        margin = kink_margin(nets, gen, disc, alpha, [z, z2], [x_real, lambda f: e * x_real + (1 - e) * f[0]])
+        if margin < min_kink_margin:
+            print(f"   {tag}: seed {seed} rejected, LeakyReLU input within {margin:.1e} rms of the kink")
+            return False
+        store["kink_margin"] = margin
 
     optim_gen = torch.optim.Adam(gen.parameters(), lr=1e-3, betas=(0.0, 0.9))
     optim_disc = torch.optim.Adam(disc.parameters(), lr=1e-3, betas=(0.0, 0.9))
@@ -132,7 +143,31 @@ def progan_case(tag, seed, rand_channels, n_grow, alpha, batch, g_end_layer=0, d
     np.savez_compressed(path, **store)
     print(f"wrote {path}: L{gen.curr_layer} side {side} d_loss {d_loss.item():.6f} gp {gp.item():.6f} "
           f"g_loss {g_loss.item():.6f}  ({os.path.getsize(path) / 1024:.0f} KiB)")
+    return True
 
+
+
+def kink_margin(nets_mod, gen, disc, alpha, z_list, x_list):
+    """Smallest |LeakyReLU input| / rms(that layer's inputs) over G(z) for z in z_list and D(x) for x in x_list (x may be a callable
+    taking the generated samples).  LeakyReLU's derivative jumps at 0: an input within fp32 round-off (~1e-6 of the layer's rms)
+    of the kink makes every fp32 implementation's gradient a coin flip there, so fixtures keep clear of it."""
+    worst = [float("inf")]
+
+    def hook(_m, inp):
+        x = inp[0].detach()
+        worst[0] = min(worst[0], float(x.abs().min() / x.pow(2).mean().sqrt()))
+
+    hs = [m.register_forward_pre_hook(hook) for net in (gen, disc) for m in net.modules()
+          if isinstance(m, torch.nn.LeakyReLU)]
+    with torch.no_grad():
+        fakes = [gen(z, alpha) for z in z_list]
+        for x in x_list:
+            disc(x(fakes) if callable(x) else x, alpha)
+        for f in fakes:
+            disc(f, alpha)
+    for h in hs:
+        h.remove()
+    return worst[0]
 
 
 def _scale_weights(nets_list, wscale):
@@ -148,29 +183,31 @@ def find_wscale(seed, rand_channels, n_grow, alpha, batch, target_norm):
     equals `target_norm` on this case's inputs -- leaves the near-zero-critic regime of a fresh init, where the penalty sits at
     10 and its gradient is a cancellation residue."""
     nets = load_networks()
+    torch.manual_seed(seed)
+    gen, disc = nets.Generator(rand_channels), nets.Discriminator(7)
+    for _ in range(n_grow):
+        gen.next_layer()
+        disc.next_layer()
+    base = [p.detach().clone() for net in (gen, disc) for p in net.parameters()]
+    side = 2 * 2 ** (gen.curr_layer + 1)
+    rng = torch.Generator().manual_seed(seed + 1000)
+    z = torch.randn(batch, rand_channels, 2, 2, generator=rng)
+    torch.randn(batch, rand_channels, 2, 2, generator=rng)
+    x_real = torch.rand(batch, 2, side, side, generator=rng) * 2 - 1
+    torch.manual_seed(seed + 2000)
+    eps = torch.rand(batch, 1, 1, 1)
 
     def med_norm(ws):
-        torch.manual_seed(seed)
-        gen, disc = nets.Generator(rand_channels), nets.Discriminator(7)
-        for _ in range(n_grow):
-            gen.next_layer()
-            disc.next_layer()
-        _scale_weights((gen, disc), ws)
-        side = 2 * 2 ** (gen.curr_layer + 1)
-        rng = torch.Generator().manual_seed(seed + 1000)
-        z = torch.randn(batch, rand_channels, 2, 2, generator=rng)
-        torch.randn(batch, rand_channels, 2, 2, generator=rng)
-        x_real = torch.rand(batch, 2, side, side, generator=rng) * 2 - 1
-        torch.manual_seed(seed + 2000)
-        eps = torch.rand(batch, 1, 1, 1)
         with torch.no_grad():
+            for p, b in zip([p for net in (gen, disc) for p in net.parameters()], base):
+                p.copy_(b * ws if p.dim() > 1 else b)
             x_fake = gen(z, alpha)
         xi = (eps * x_real + (1 - eps) * x_fake).requires_grad_(True)
         (g,) = torch.autograd.grad(disc(xi, alpha).sum(), xi)
         return float(g.reshape(batch, -1).norm(dim=1).median())
 
     lo, hi = 1.0, 8.0
-    for _ in range(40):
+    for _ in range(14):
         mid = 0.5 * (lo + hi)
         if med_norm(mid) < target_norm:
             lo = mid
@@ -246,7 +283,7 @@ def trajectory_case(tag, seed, rand_channels, batch, iters, fadein, train_length
         return recs, inputs, heads, gen, disc, og, od, init_sha
 
     r64, inputs, heads, gen, disc, og, od, init_sha = run(torch.float64)
-    r32 = run(torch.float32)[0]
+    r32, _, _, gen32, disc32 = run(torch.float32)[:5]
     store = {"seed": seed, "rand_channels": rand_channels, "batch": batch, "iters": iters, "wscale": wscale,
              "fadein": np.array(fadein), "train_lengths": np.array(train_lengths),
              "g_init_sha": np.array(init_sha[0]), "d_init_sha": np.array(init_sha[1]), "new_head_sha": np.array(heads)}
@@ -266,6 +303,8 @@ def trajectory_case(tag, seed, rand_channels, batch, iters, fadein, train_length
             steps[k] = int(st["step"]) if st else 0
             if st:
                 store[f"final64|{pre}|{k}|exp_avg_sq|samp"] = st["exp_avg_sq"].reshape(-1).numpy()[sample_idx(p.numel())]
+        for k, p in (gen32 if pre == "g" else disc32).named_parameters():  # the float32 run's final weights, for the noise scale
+            store[f"final32|{pre}|{k}|samp"] = p.detach().reshape(-1).numpy()[sample_idx(p.numel())]
         store[f"adam_steps|{pre}|keys"] = np.array(list(steps.keys()))
         store[f"adam_steps|{pre}"] = np.array(list(steps.values()))
         store[f"adam_groups|{pre}"] = np.array([len(gr["params"]) for gr in opt.param_groups])
@@ -387,9 +426,13 @@ if __name__ == "__main__":
     progan_case("l2_rc16_fade_scaled", seed=15, rand_channels=16, n_grow=2, alpha=0.5, batch=4, wscale=1.7)
     # the well-conditioned penalty regime: weights scaled until the median ||grad_x D(x~)|| is ~1 (samples on both sides of 1,
     # so (||g|| - 1) takes both signs) and ~3 (all positive)
+    # (seeds scanned until no LeakyReLU input of the step lies within 2e-6 rms of the kink -- twice the round-off the HIP kernels were measured at: with ~1e6 activations per step roughly
+    # one seed in 20 qualifies; closer inputs make the mask, hence the gradient, depend on fp32 summation order)
     for tag, target in (("l2_rc16_gpnorm1", 1.0), ("l2_rc16_gpnorm3", 3.0)):
-        ws = find_wscale(seed=16, rand_channels=16, n_grow=2, alpha=0.5, batch=4, target_norm=target)
-        progan_case(tag, seed=16, rand_channels=16, n_grow=2, alpha=0.5, batch=4, wscale=ws)
+        for seed in range(16, 2000):
+            ws = find_wscale(seed=seed, rand_channels=16, n_grow=2, alpha=0.5, batch=4, target_norm=target)
+            if progan_case(tag, seed=seed, rand_channels=16, n_grow=2, alpha=0.5, batch=4, wscale=ws, min_kink_margin=2e-6):
+                break
     trajectory_case("trajectory", seed=21, rand_channels=8, batch=3, iters=16, fadein=[1, 12, 12, 12, 12, 12, 12, 12],
                     train_lengths=[15, 15, 15, 15, 15, 15, 15])
     transforms_case()
