@@ -116,6 +116,7 @@ def test_train_step_matches_reference_golden(case, conv_mode):
     before = {k: (p.detach().clone(), None if p.grad is None else p.grad.detach().clone())
               for k, p in disc.named_parameters()}
     optim_disc.step()
+    adam_tight = adam_total = 0
     for k, p in disc.named_parameters():
         w0, gr = before[k]
         if gr is None:
@@ -133,7 +134,12 @@ def test_train_step_matches_reference_golden(case, conv_mode):
         budget = 2 * grad_atol(k, o64["d_grads"], o32["d_grads"], terms)  # ours and the reference's fp32 gradient, both vs fp64
         tol = 1e-3 * np.minimum(2.0, budget / (np.abs(gsamp) + 1e-8)) + 2e-7
         assert np.all(np.abs(got - samp) <= tol), f"post-Adam {k}: {np.abs(got - samp).max():.2e}"
-        assert float(np.mean(tol < 0.05 * 1e-3)) > (0.5 if gsamp.size > 64 else 0.0), f"post-Adam {k}: check is vacuous"
+        adam_tight += int(np.sum(tol < 0.1 * 1e-3))
+        adam_total += tol.size
+
+    # the element-wise bound must bite: tighter than 10% of an Adam step on a good share of the compared weights (it is slack only
+    # where |g| is below the gradient budget -- there Adam's normalisation lets ANY fp32 evaluation move by up to a full step)
+    assert adam_tight > 0.15 * adam_total, f"post-Adam comparison is vacuous: {adam_tight} of {adam_total}"
 
     # ---- G step, train.py:191-214
     x_fake2 = gen(z2, alpha)
@@ -143,7 +149,8 @@ def test_train_step_matches_reference_golden(case, conv_mode):
     disc.zero_grad()
     g_loss.backward()
     assert maxrel(x_fake2, torch.from_numpy(g["x_fake2"])) <= FWD_TOL
-    assert abs(float(g_loss) - float(g["gen_loss"])) <= 1e-6
+    # a mean of critic scores: the forward tolerance times their scale (scores reach +-80 in the scaled-weight fixtures)
+    assert abs(float(g_loss) - float(g["gen_loss"])) <= 1e-6 + FWD_TOL * float(np.abs(g["out_fake2"]).max())
     for k, p in gen.named_parameters():
         if p.grad is not None:
             check_tensor(g, f"gstep_ggrad|{k}", p.grad, GRAD_TOL, what="golden ")

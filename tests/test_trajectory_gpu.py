@@ -219,9 +219,9 @@ def test_fused_adam_multi_step_matches_torch_adam(grad_scale):
         for i, (pc, pd) in enumerate(zip(cpu, dev)):
             st_c, st_d = ref.state.get(pc, {}), opt.state.get(pd, {})
             assert (int(st_d["step"]) if st_d else 0) == (int(st_c["step"]) if st_c else 0)
-            # one step moves a weight by at most lr; fp32 round-off of the update is <= 1e-6 of that plus one ulp of the weight
+            # one step moves a weight by at most lr; fp32 round-off of the update is <= 2e-6 of that plus one ulp of the weight
             err = float((pd.detach().double().cpu() - pc.detach()).abs().max())
-            assert err <= (step + 1) * (2e-6 * LR + 6e-8 * float(pc.abs().max())), f"step {step} tensor {i}: {err:.2e}"
+            assert err <= (step + 1) * (2e-6 * LR + 1.2e-7 * float(pc.abs().max())), f"step {step} tensor {i}: {err:.2e}"
             if st_c:
                 v_c, v_d = st_c["exp_avg_sq"], st_d["exp_avg_sq"].double().cpu()
                 assert float((v_d - v_c).abs().max()) <= 1e-6 * float(v_c.max()), f"step {step} exp_avg_sq {i}"
