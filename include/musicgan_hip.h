@@ -155,7 +155,8 @@ int mg_gp_finish(const float* sumsq, float* penalty, float* coef, int N, float f
 int mg_channel_sum(const float* x, float* out, int N, int C, int HW, int accumulate, mg_stream_t stream);
 
 /* ------------------------------------------------------------------ fused Adam [train.py:64-70,175,214]
- * Multi-tensor torch.optim.Adam step (amsgrad off, weight_decay 0).  desc is a DEVICE array of n_tensors records. */
+ * Multi-tensor torch.optim.Adam step (amsgrad off, weight_decay 0).  desc is a HOST array of n_tensors records (device pointers
+ * inside); the records are passed to the kernel by value, so the call neither copies nor synchronises. */
 typedef struct {
   float* param;
   const float* grad;

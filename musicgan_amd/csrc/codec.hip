@@ -453,15 +453,14 @@ extern "C" int mg_codec_fwd(const float* stft_c64, const float* bark_scale, floa
   if (gx > 64) gx = 64;
   hipLaunchKernelGGL(codec_abs_angle, dim3(gx, NB), dim3(256), 0, s, reinterpret_cast<const float2*>(stft_c64),
                      bark_scale, magn, phi, part_m, T);
-  static bool attr_set = false;  // benign race: idempotent
-  if (!attr_set) {
+  static MgPerDevice once;  // the LDS limit is a per-device function attribute
+  if (mg_first_use_on_device(once)) {
     const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&codec_unwrap_delta),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     if (ea != hipSuccess) {
       mg_set_error("mg_codec_fwd: hipFuncSetAttribute: %s", hipGetErrorString(ea));
       return MG_ELAUNCH;
     }
-    attr_set = true;
   }
   MG_CHECK_LAUNCH("mg_codec_fwd(abs_angle)");
   hipLaunchKernelGGL(codec_unwrap_delta, dim3(NB / 64), dim3(UNWRAP_THREADS), UNWRAP_LDS, s, phi, delta, part_p, T);
@@ -505,15 +504,14 @@ extern "C" int mg_codec_inv(const float* magn_phase, const float* bark_scale, fl
   if (gx > 64) gx = 64;
   hipLaunchKernelGGL(inv_unbark, dim3(gx, NB), dim3(256), 0, s, magn_phase, bark_scale, m, part, N, W);
   hipLaunchKernelGGL(minmax_final, dim3(1), dim3(256), 0, s, part, gx * NB, mm);
-  static bool attr_set = false;  // benign race: idempotent
-  if (!attr_set) {
+  static MgPerDevice once;  // the LDS limit is a per-device function attribute
+  if (mg_first_use_on_device(once)) {
     const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&inv_phase_cumsum),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     if (ea != hipSuccess) {
       mg_set_error("mg_codec_inv: hipFuncSetAttribute: %s", hipGetErrorString(ea));
       return MG_ELAUNCH;
     }
-    attr_set = true;
   }
   float* run = frames;  // running phase [NB][TT]: borrows the frame buffer (TT*1024 floats), which inv_frames fills afterwards
   hipLaunchKernelGGL(inv_phase_cumsum, dim3(NB / 64), dim3(576), (size_t)4 * UTILE * sizeof(float), s, magn_phase, run, N, W);

@@ -409,11 +409,10 @@ __global__ void conv3x3_pack_kernel(const float* __restrict__ w, float* __restri
 
 template <int NI, int MI, bool PF, int SUB = 1>
 int launch_conv_pf(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-  static bool attr_set = false;  // benign race: idempotent
-  if (!attr_set) {
+  static MgPerDevice once;  // the LDS limit is a per-device function attribute
+  if (mg_first_use_on_device(once)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma<NI, MI, PF, SUB>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   hipLaunchKernelGGL((conv3x3_mfma<NI, MI, PF, SUB>), grid, dim3(256), lds, s, a);
   MG_CHECK_LAUNCH("mg_conv3x3");

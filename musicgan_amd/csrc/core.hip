@@ -12,5 +12,16 @@ void mg_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+int mg_cu_count() {
+  static int cus[MG_MAX_DEVICES] = {};
+  const int d = mg_current_device();
+  if (cus[d] == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || v <= 0) v = 256;
+    cus[d] = v;
+  }
+  return cus[d];
+}
+
 extern "C" int mg_version(void) { return 100; }
 extern "C" const char* mg_last_error(void) { return g_err; }

@@ -401,9 +401,15 @@ __global__ void __launch_bounds__(256) linear1_bwd_k(const float* __restrict__ x
 }
 
 // ---------------------------------------------------------------- Adam
-__global__ void __launch_bounds__(256) adam_k(const mg_adam_tensor_t* __restrict__ desc, float beta1, float beta2,
-                                              float eps, float grad_scale) {
-  const mg_adam_tensor_t d = desc[blockIdx.y];
+// The tensor records travel in the kernel-argument segment (ADAM_CHUNK per launch): no descriptor upload, hence no host
+// synchronisation per optimizer step (a pageable host-to-device copy waits for the stream to drain) and nothing to keep alive.
+constexpr int ADAM_CHUNK = 48;
+struct AdamChunk {
+  mg_adam_tensor_t t[ADAM_CHUNK];
+};
+
+__global__ void __launch_bounds__(256) adam_k(const AdamChunk desc, float beta1, float beta2, float eps, float grad_scale) {
+  const mg_adam_tensor_t d = desc.t[blockIdx.y];
   const float step_size = d.step_size, bc2s = d.bc2_sqrt;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.numel; i += (int64_t)gridDim.x * blockDim.x) {
     const float g = d.grad[i] * grad_scale;
@@ -435,13 +441,12 @@ extern "C" int mg_pixelnorm_lrelu_bwd(const float* gp, const float* y, const flo
   MG_CHECK_ARG(gp && y && rn && gpre && N > 0 && C > 0 && HW > 0, "mg_pixelnorm_lrelu_bwd: bad arguments");
   const size_t px_total = (size_t)N * HW;
   if (C <= 128 && getenv("MG_PN_BWD_NOLDS") == nullptr) {  // up to 128 KB of LDS per workgroup
-    static bool attr_set = false;  // benign race: idempotent
-    if (!attr_set) {
+    static MgPerDevice once;  // the LDS limit is a per-device function attribute
+    if (mg_first_use_on_device(once)) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pixelnorm_lrelu_bwd_lds_k<256>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pixelnorm_lrelu_bwd_lds_k<128>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
     }
     if (C <= 64) {
       hipLaunchKernelGGL(pixelnorm_lrelu_bwd_lds_k<256>, dim3((unsigned)((px_total + 255) / 256)), dim3(256),
@@ -586,8 +591,16 @@ extern "C" int mg_channel_sum(const float* x, float* out, int N, int C, int HW, 
 extern "C" int mg_adam_step(const mg_adam_tensor_t* desc, int n_tensors, float beta1, float beta2, float eps,
                             float grad_scale, mg_stream_t stream) {
   MG_CHECK_ARG(desc && n_tensors > 0, "mg_adam_step: bad arguments");
-  hipLaunchKernelGGL(adam_k, dim3(64, n_tensors), dim3(256), 0, (hipStream_t)stream, desc, beta1, beta2, eps,
-                     grad_scale);
-  MG_CHECK_LAUNCH("mg_adam_step");
+  for (int first = 0; first < n_tensors; first += ADAM_CHUNK) {
+    const int n = n_tensors - first < ADAM_CHUNK ? n_tensors - first : ADAM_CHUNK;
+    AdamChunk c;
+    for (int i = 0; i < n; ++i) {
+      c.t[i] = desc[first + i];
+      MG_CHECK_ARG(c.t[i].param && c.t[i].grad && c.t[i].exp_avg && c.t[i].exp_avg_sq && c.t[i].numel >= 0,
+                   "mg_adam_step: record %d has a null pointer", first + i);
+    }
+    hipLaunchKernelGGL(adam_k, dim3(64, n), dim3(256), 0, (hipStream_t)stream, c, beta1, beta2, eps, grad_scale);
+    MG_CHECK_LAUNCH("mg_adam_step");
+  }
   return MG_OK;
 }

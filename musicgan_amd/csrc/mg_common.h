@@ -28,6 +28,25 @@ void mg_set_error(const char* fmt, ...);
     }                                                                      \
   } while (0)
 
+// One-time per-DEVICE setup (function attributes such as the dynamic-LDS limit are per device; a process may drive several GPUs).
+#define MG_MAX_DEVICES 64
+struct MgPerDevice {
+  bool done[MG_MAX_DEVICES] = {};
+};
+static inline int mg_current_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MG_MAX_DEVICES) d = 0;
+  return d;
+}
+// true exactly once per device (benign race: the guarded setup is idempotent)
+static inline bool mg_first_use_on_device(MgPerDevice& f) {
+  const int d = mg_current_device();
+  if (f.done[d]) return false;
+  f.done[d] = true;
+  return true;
+}
+int mg_cu_count();  // compute units of the current device (cached per device, core.hip)
+
 static inline int mg_ilog2(int v) {
   int l = 0;
   while ((1 << l) < v) ++l;

@@ -220,13 +220,10 @@ extern "C" int mg_stft_1024(const float* wav, float* out_re, float* out_im, int6
   MG_CHECK_ARG(L / HOP + 1 < (1ll << 30), "mg_stft_1024: too many frames");
   const int T = (int)(L / HOP) + 1;
   const int ntiles = (T + FPB - 1) / FPB;
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    n_cu = v;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stft1024_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  }
+  const int n_cu = mg_cu_count();
+  static MgPerDevice once;
+  if (mg_first_use_on_device(once))
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stft1024_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const int blocks = ntiles < 2 * n_cu ? ntiles : 2 * n_cu;  // two 78 KB workgroups per CU, persistent over the tiles
   hipLaunchKernelGGL(stft1024_kernel, dim3(blocks), dim3(64 * NWAVE), STFT_LDS, (hipStream_t)stream, wav, out_re, out_im,
                      (long long)L, T, ntiles);

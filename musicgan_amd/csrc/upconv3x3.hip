@@ -490,11 +490,10 @@ __global__ void downconv_pack_kernel(const float* __restrict__ w, float* __restr
 
 template <int NI>
 int launch_down(const DownArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static MgPerDevice once;  // the LDS limit is a per-device function attribute
+  if (mg_first_use_on_device(once)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&downconv4x4s2_mfma<NI>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   hipLaunchKernelGGL((downconv4x4s2_mfma<NI>), grid, dim3(256), lds, s, a);
   MG_CHECK_LAUNCH("mg_upconv3x3_dgrad");
@@ -530,11 +529,10 @@ __global__ void upconv3x3_pack_kernel(const float* __restrict__ w, float* __rest
 
 template <int NI>
 int launch_up(const UpArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static MgPerDevice once;  // the LDS limit is a per-device function attribute
+  if (mg_first_use_on_device(once)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&upconv3x3_mfma<NI>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
-    attr_set = true;
   }
   hipLaunchKernelGGL((upconv3x3_mfma<NI>), grid, dim3(256), lds, s, a);
   MG_CHECK_LAUNCH("mg_upconv3x3");

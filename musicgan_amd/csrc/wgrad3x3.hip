@@ -424,11 +424,10 @@ bool plan_wgrad(int N, int Cin, int Cout, int H, int W, WgradPlan& pl) {
 
 template <int WO, int NIX, bool T32>
 int launch_wgrad_t(const WgradPlan& pl, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static MgPerDevice once;  // the LDS limit is a per-device function attribute
+  if (mg_first_use_on_device(once)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_mfma<WO, NIX, T32>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   dim3 grid(pl.nsplit, pl.a.oblocks * pl.cblocks);
   hipLaunchKernelGGL((wgrad3x3_mfma<WO, NIX, T32>), grid, dim3(64 * pl.a.ogroups * pl.a.nct), pl.lds, s, pl.a);

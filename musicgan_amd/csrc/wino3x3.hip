@@ -470,11 +470,10 @@ template <int NIW, int WC, int WT>
 int launch_wino(const WinoArgs& a, dim3 grid, hipStream_t s) {
   constexpr int TPB = WT * 16;
   constexpr size_t lds = (size_t)(16 * TPB * WCC + WC * NIW * 2048 + WC * TPB * 4) * sizeof(float);
-  static bool attr_set = false;  // benign race: idempotent
-  if (!attr_set) {
+  static MgPerDevice once;  // the LDS limit is a per-device function attribute
+  if (mg_first_use_on_device(once)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino3x3_mfma<NIW, WC, WT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   hipLaunchKernelGGL((wino3x3_mfma<NIW, WC, WT>), grid, dim3(64 * WT * WC), lds, s, a);
   MG_CHECK_LAUNCH("mg_wino3x3");
@@ -547,12 +546,7 @@ extern "C" int mg_wino3x3(const float* x, const float* up, const float* bias, co
   // and epilogue never queue behind another workgroup's matrix instructions -- measured 70..140 cycles per VALU instruction
   // when they do, tools/hwtests/valu_latency_under_mfma.hip -- and the filters are staged once per 64 tiles) when that still
   // gives every CU two or more workgroups, else 32 (two workgroups per CU).
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    n_cu = v;
-  }
+  const int n_cu = mg_cu_count();
   int wt = ((long long)N * Ht * Wt / 64) * mg_cdiv(nt, cfg) >= 2ll * n_cu ? 4 : 2;
   {
     const char* e = getenv("MG_WINO_WT");  // measurement override

@@ -348,12 +348,7 @@ void plan_ww(int N, int Cin, int Cout, int H, int W, WwPlan& pl) {
   pl.CT = mg_cdiv(ct, pl.ncb) <= 3 ? 3 : 4;
   pl.OT = mg_cdiv(ot, a.nob) <= 3 ? 3 : 4;
   a.CinP = ct * 16; a.CoutP = ot * 16;
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    n_cu = v;
-  }
+  const int n_cu = mg_cu_count();
   const int ny = pl.ncb * a.nob;
   int ns = n_cu / ny > 0 ? n_cu / ny : 1;  // one 8-wave workgroup (128 KB of LDS) per CU
   if (ns > a.nblk) ns = a.nblk;
@@ -365,11 +360,10 @@ void plan_ww(int N, int Cin, int Cout, int H, int W, WwPlan& pl) {
 template <int CT, int OT, bool UPS>
 int launch_ww(const WwArgs& a, dim3 grid, hipStream_t s) {
   constexpr size_t lds = (size_t)2 * STAGE * sizeof(float);
-  static bool attr_set = false;  // benign race: idempotent
-  if (!attr_set) {
+  static MgPerDevice once;  // the LDS limit is a per-device function attribute
+  if (mg_first_use_on_device(once)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_wgrad_mfma<CT, OT, UPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
-    attr_set = true;
   }
   hipLaunchKernelGGL((wino_wgrad_mfma<CT, OT, UPS>), grid, dim3(512), lds, s, a);
   MG_CHECK_LAUNCH("mg_wino3x3_wgrad");

@@ -11,7 +11,6 @@ import ctypes
 import math
 from typing import List
 
-import numpy as np
 import torch
 
 from . import _lib
@@ -62,12 +61,10 @@ class FusedAdam(torch.optim.Optimizer):
                 device = p.device
             if not recs:
                 continue
-            arr = (AdamTensor * len(recs))(*recs)
-            host = np.frombuffer(arr, dtype=np.uint8).copy()
-            desc = torch.from_numpy(host).to(device)
+            arr = (AdamTensor * len(recs))(*recs)  # host records; the library hands them to the kernel by value
             with torch.cuda.device(device):
                 stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-                check(lib.mg_adam_step(ctypes.c_void_p(desc.data_ptr()), len(recs), beta1, beta2, eps,
+                check(lib.mg_adam_step(ctypes.cast(arr, ctypes.c_void_p), len(recs), beta1, beta2, eps,
                                        float(self.grad_scale), stream), "mg_adam_step")
             for p in touched:  # the kernel wrote behind autograd's back: bump versions so packed-weight caches refresh
                 torch.autograd.graph.increment_version(p)

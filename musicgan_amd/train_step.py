@@ -23,8 +23,11 @@ from .dist import GradBucket, is_distributed
 
 class ProGANStepper:
     def __init__(self, gen, disc, optim_gen, optim_disc, rand_channels: int, height: int = 2, width: int = 2,
-                 fused_d_step: bool = True):
+                 fused_d_step: bool = True, noise: Optional[torch.Generator] = None):
+        """`noise`: device generator the latents and the penalty's epsilon are drawn from when they are not injected (None: the
+        default generator, as the reference does).  Data-parallel runs give every rank its own stream."""
         self.gen, self.disc = gen, disc
+        self.noise = noise
         self.optim_gen, self.optim_disc = optim_gen, optim_disc
         self.rand_channels, self.h, self.w = rand_channels, height, width
         self.fused_d_step = fused_d_step
@@ -36,7 +39,8 @@ class ProGANStepper:
             optim_disc.grad_scale = self.bucket_d.grad_scale
 
     def _latent(self, n: int, device, generator=None) -> torch.Tensor:
-        return torch.randn(n, self.rand_channels, self.h, self.w, device=device, generator=generator)
+        return torch.randn(n, self.rand_channels, self.h, self.w, device=device,
+                           generator=generator if generator is not None else self.noise)
 
     def _update(self, bucket: GradBucket, net, optim) -> None:
         if self.dp:
@@ -62,6 +66,8 @@ class ProGANStepper:
             x_fake = self.gen(z, alpha)
         out_fake = self.disc(x_fake, alpha)
         disc_loss = networks.wasserstein_discriminator_loss(out_real, out_fake)
+        if eps is None and self.noise is not None:
+            eps = torch.rand(n, 1, 1, 1, device=x_real.device, generator=self.noise)
         if eps is None:
             grad_pen = self.disc.gradient_penalty(x_real, x_fake, alpha)
         else:
@@ -80,7 +86,7 @@ class ProGANStepper:
         n = x_real.shape[0]
         dev = x_real.device
         if eps is None:
-            eps = torch.rand(n, 1, 1, 1, device=dev)
+            eps = torch.rand(n, 1, 1, 1, device=dev, generator=self.noise)
         if self.dp:
             self.bucket_d.wait()
             self.bucket_g.wait()

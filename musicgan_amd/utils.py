@@ -149,6 +149,27 @@ class Saver:
         self._saves += 1
         return True
 
+    # ---- extensions for data-parallel runs and resume (the reference has neither)
+    def due(self) -> bool:
+        """Whether the next `request_save` call writes a checkpoint."""
+        return (self._calls + 1) % self._every == 0
+
+    def tick(self) -> None:
+        """Count one call without writing (ranks other than 0 keep their cadence in step with rank 0)."""
+        self._calls += 1
+        if self._calls % self._every == 0:
+            self._saves += 1
+
+    def state_dict(self) -> dict:
+        return {"calls": self._calls, "saves": self._saves}
+
+    def state_dict_after_save(self) -> dict:
+        """The counters as they stand once the checkpoint being written is complete (for the `train_state` written with it)."""
+        return {"calls": self._calls, "saves": self._saves + 1}
+
+    def load_state_dict(self, sd: dict) -> None:
+        self._calls, self._saves = int(sd["calls"]), int(sd["saves"])
+
     @property
     def curr_save(self) -> int:
         return self._saves - 1  # index of the last checkpoint written

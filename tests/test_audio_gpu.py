@@ -103,7 +103,9 @@ def test_drivers_end_to_end_tiny_corpus(tmp_path):
     saved = sorted(f for f in os.listdir(out_dir) if f.endswith(".pt"))  # (+ 12 preview PNGs when matplotlib is installed)
     assert saved == ["disc_0.pt", "gen_0.pt", "optim_disc_0.pt", "optim_gen_0.pt", "train_state_0.pt"]
     st = torch.load(str(out_dir / "train_state_0.pt"))
-    assert st["iter_idx"] == 4 and st["level"] == 0 and st["grower"]["sample_idx"] == 6  # grow() runs after the save
+    # the checkpoint is taken after the iteration's growth bookkeeping: 4 iterations x batch 2 = 8 samples seen
+    assert st["iter_idx"] == 4 and st["level"] == 0 and st["grower"]["sample_idx"] == 8
+    assert st["saver"] == {"calls": 4, "saves": 1} and st["epoch"] == 1 and st["epoch_pos"] == 2
     # checkpoint keys are the reference's (gen_{k}.pt loads into a reference Generator): utils.py:118-145
     gsd = torch.load(str(out_dir / "gen_0.pt"))
     assert "_Generator__gen_blocks.0.0.weight" in gsd and "_Generator__end_block.0.bias" in gsd
@@ -121,3 +123,137 @@ def test_drivers_end_to_end_tiny_corpus(tmp_path):
     musicgan_amd.generate(str(tmp_path / "gen"), 8, ck, 1, 1)
     w, sr = wavio.load(str(tmp_path / "gen" / "sound_0.wav"))
     assert sr == 44100 and tuple(w.shape) == (1, 256 * 511) and bool(torch.isfinite(w).all())
+
+
+def _tiny_dataset(tmp_path, n=6):
+    """n stored samples (2, 512, 512) float64 in create_dataset's format, values as the codec would leave them."""
+    data = tmp_path / "data"
+    data.mkdir()
+    rng = torch.Generator().manual_seed(17)
+    for i in range(n):
+        x = torch.rand(2, 512, 512, generator=rng, dtype=torch.float64) * 2 - 1
+        torch.save(x, str(data / f"magn_phase_{i}.pt"))
+    return data
+
+
+def test_resume_is_bit_identical(tmp_path):
+    """6 iterations straight == 4 iterations + resume + 2 (the reference can only save, utils.py:118-145):
+    weights, Adam moments and step counts, Grower counters and the train state of the last checkpoint are identical bit for
+    bit, across a growth before the interruption and another one after it; resuming IN PLACE continues the checkpoint
+    numbering instead of overwriting `*_0.pt` (the files written before the interruption stay untouched)."""
+    from musicgan_amd.train import train
+    data = _tiny_dataset(tmp_path)
+    kw = dict(nb_epoch=10, batch_size=2, num_workers=0, save_every=2, rand_channels=8,
+              fadein_lengths=[1, 6, 6, 6, 6, 6, 6, 6], train_lengths=[5, 4, 100, 100, 100, 100, 100])
+    torch.manual_seed(123)
+    a = tmp_path / "straight"
+    train("a", str(data), str(a), max_iters=6, **kw)
+    torch.manual_seed(123)
+    b = tmp_path / "interrupted"
+    train("b", str(data), str(b), max_iters=4, **kw)
+    before = {f: os.path.getmtime(str(b / f)) for f in os.listdir(b) if f.endswith(".pt")}
+    assert sorted(before) == sorted(f"{s}_{k}.pt" for s in ("disc", "gen", "optim_disc", "optim_gen", "train_state")
+                                    for k in (0, 1))
+    torch.manual_seed(999)  # the resumed run must not depend on the process's RNG state
+    train("b", str(data), str(b), max_iters=6, resume_from=str(b), **kw)
+    assert all(os.path.getmtime(str(b / f)) == t for f, t in before.items()), "resume overwrote an earlier checkpoint"
+    sa, sb = torch.load(str(a / "train_state_2.pt")), torch.load(str(b / "train_state_2.pt"))
+    assert sa["level"] == sb["level"] == 2 and sa["iter_idx"] == sb["iter_idx"] == 6  # grew after iterations 3 and 5
+    assert sa["grower"] == sb["grower"] and sa["saver"] == sb["saver"] == {"calls": 6, "saves": 3}
+    assert (sa["epoch"], sa["epoch_pos"]) == (sb["epoch"], sb["epoch_pos"]) == (1, 3)  # end of the second pass over 6 samples
+    assert all(torch.equal(x, y) for x, y in zip(sa["noise_rng"], sb["noise_rng"]))
+    for net in ("gen", "disc"):
+        wa, wb = torch.load(str(a / f"{net}_2.pt")), torch.load(str(b / f"{net}_2.pt"))
+        assert list(wa.keys()) == list(wb.keys())
+        for k in wa:
+            assert torch.equal(wa[k], wb[k]), f"{net} {k} differs after resume"
+        oa, ob = torch.load(str(a / f"optim_{net}_2.pt")), torch.load(str(b / f"optim_{net}_2.pt"))
+        assert oa["state"].keys() == ob["state"].keys() and len(oa["param_groups"]) == len(ob["param_groups"]) == 3
+        for ga, gb in zip(oa["param_groups"], ob["param_groups"]):  # (load_state_dict adds torch's default keys)
+            assert all(ga[key] == gb[key] for key in ("lr", "betas", "eps", "params"))
+        for i in oa["state"]:
+            for key in ("step", "exp_avg", "exp_avg_sq"):
+                assert torch.equal(oa["state"][i][key].cpu(), ob["state"][i][key].cpu()), f"optim_{net} state {i} {key}"
+
+
+def test_training_loop_has_no_host_sync_between_metric_readbacks(tmp_path):
+    """the reference blocks on 4-6 `.item()` calls per iteration (train.py:180-186,218-221).  Here a whole
+    D step + G step + metric push (incl. both fused Adam steps and the device-side input transform) must not synchronise the host
+    at all -- checked with PyTorch's sync debug mode, which raises on any blocking call -- and a metric window comes back with
+    exactly one device-to-host copy."""
+    from musicgan_amd.networks import Discriminator, Generator
+    from musicgan_amd.optim import FusedAdam
+    from musicgan_amd.train import MetricWindow
+    from musicgan_amd.train_step import ProGANStepper
+    from musicgan_amd.utils import Grower
+    torch.manual_seed(0)
+    gen, disc = Generator(8).to(DEV), Discriminator(7).to(DEV)
+    for _ in range(2):
+        gen.next_layer()
+        disc.next_layer()
+    og = FusedAdam(gen.parameters(), lr=1e-3, betas=(0.0, 0.9))
+    od = FusedAdam(disc.parameters(), lr=1e-3, betas=(0.0, 0.9))
+    noise = torch.Generator(device=DEV)
+    noise.manual_seed(1)
+    st = ProGANStepper(gen, disc, og, od, 8, noise=noise)
+    grower = Grower(7, [1, 50, 50, 50, 50, 50, 50, 50], [1, 1, 1000, 1, 1, 1, 1])
+    grower.grow(2)
+    grower.grow(2)
+    assert grower.curr_grow == 2
+    metrics = MetricWindow(8, DEV)
+    raw = torch.rand(4, 2, 512, 512, dtype=torch.float64).pin_memory()
+
+    def iteration(i):
+        x = grower.transform_batch(raw.to(DEV, non_blocking=True))
+        d = st.d_step(x, grower.alpha)
+        g = st.g_step(4, grower.alpha, DEV) if i % 5 == 0 else None
+        metrics.push(d, g)
+        grower.grow(4)
+
+    iteration(0)  # warm-up: library load, workspaces, first allocations
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        for i in range(5, 11):
+            iteration(i)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.set_sync_debug_mode("warn")
+    try:
+        with pytest.warns(UserWarning) as rec:
+            metrics.flush()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert len([w for w in rec if "synchroniz" in str(w.message)]) == 1, [str(w.message) for w in rec]
+    assert all(v == v for v in metrics.hist["disc_loss"][-7:]) and metrics.last["gen_loss"] == metrics.last["gen_loss"]
+
+
+def test_create_dataset_sharded_equals_single_process(tmp_path, monkeypatch):
+    """create_dataset under WORLD_SIZE=2 (files dealt round-robin to the ranks, no collective): rank 0 and rank 1 writing into one
+    directory produce exactly the files of the single-process run -- same global `magn_phase_{idx}` numbering
+    (create_dataset.py:32,64 of the reference: files in glob order, samples in time order), same contents; a file too short for
+    one sample is skipped without consuming an index."""
+    import musicgan_amd
+    from musicgan_amd.audio import wavio
+    rng = torch.Generator().manual_seed(9)
+    wav_dir = tmp_path / "wav"
+    wav_dir.mkdir()
+    lengths = [256 * 1030, 256 * 100, 256 * 520, 256 * 1600, 256 * 515]  # 2, 0 (skipped), 1, 3, 1 samples
+    for i, n in enumerate(lengths):
+        wavio.save(str(wav_dir / f"s{i}.wav"), torch.rand(2 if i % 2 else 1, n, generator=rng) - 0.5, 44100)
+    single, sharded = tmp_path / "single", tmp_path / "sharded"
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    musicgan_amd.create_dataset(str(wav_dir / "*.wav"), str(single))
+    for rank in (1, 0):
+        monkeypatch.setenv("RANK", str(rank))
+        monkeypatch.setenv("WORLD_SIZE", "2")
+        monkeypatch.setenv("LOCAL_RANK", "0")
+        musicgan_amd.create_dataset(str(wav_dir / "*.wav"), str(sharded))
+        if rank == 1:
+            part = sorted(os.listdir(sharded))
+            assert 0 < len(part) < 7  # rank 1 alone wrote only its files' samples
+    names = sorted(os.listdir(single))
+    assert names == sorted(os.listdir(sharded)) == sorted(f"magn_phase_{i}.pt" for i in range(7))
+    for n in names:
+        assert torch.equal(torch.load(str(single / n)), torch.load(str(sharded / n))), n

@@ -1,0 +1,67 @@
+"""GPU: the data-parallel code path of the training step (side HIP stream, flat gradient bucket, RCCL all-reduce, fused Adam queued
+behind it, per-rank noise) on ONE GPU -- a 1-rank "nccl" process group with MG_FORCE_DP=1 runs exactly the code N ranks run.
+The N > 1 arithmetic (sum of per-rank gradients == concatenated-batch gradient) is covered on CPU by tests/test_dist_cpu.py."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture
+def one_rank_nccl(monkeypatch):
+    import torch.distributed as dist
+    monkeypatch.setenv("MG_FORCE_DP", "1")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", str(29650 + os.getpid() % 200))
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    yield
+    dist.destroy_process_group()
+
+
+def _run(steps, level=3, batch=4):
+    import bench
+    from musicgan_amd.optim import FusedAdam
+    from musicgan_amd.train_step import ProGANStepper
+    gen, disc = bench.build_nets(level, 32, DEV)
+    og = FusedAdam(gen.parameters(), lr=1e-3, betas=(0.0, 0.9))
+    od = FusedAdam(disc.parameters(), lr=1e-3, betas=(0.0, 0.9))
+    st = ProGANStepper(gen, disc, og, od, 32)
+    side = bench.LEVEL_SIDE[level]
+    rng = torch.Generator(device=DEV).manual_seed(77)
+    x_real = torch.rand(batch, 2, side, side, device=DEV, generator=rng) * 2 - 1
+    losses = []
+    for i in range(steps):
+        z = torch.randn(batch, 32, 2, 2, device=DEV, generator=rng)
+        eps = torch.rand(batch, 1, 1, 1, device=DEV, generator=rng)
+        z2 = torch.randn(batch, 32, 2, 2, device=DEV, generator=rng)
+        d = st.d_step(x_real, 0.5, z=z, eps=eps)
+        losses.append(d["disc_loss"])
+        if i % 2 == 0:  # both orders of the overlap: D step after a G step, and D step after a D step
+            losses.append(st.g_step(batch, 0.5, DEV, z=z2)["gen_loss"])
+    st.finish()
+    torch.cuda.synchronize()
+    weights = {("G." if net is gen else "D.") + k: p.detach().clone() for net in (gen, disc) for k, p in net.named_parameters()}
+    return st, weights, [float(v) for v in losses]
+
+
+def test_data_parallel_path_is_bit_identical_to_single_process(one_rank_nccl, monkeypatch):
+    """Three critic + two generator updates through the final stepper (fused critic step) with the DP machinery live, against
+    the same run without it: every weight bit-identical, every loss equal."""
+    st_dp, w_dp, l_dp = _run(3)
+    assert st_dp.dp and st_dp.bucket_d.stream() is not None and st_dp.bucket_g.stream() is not None
+    assert st_dp.optim_disc.grad_scale == 1.0
+    monkeypatch.setenv("MG_FORCE_DP", "0")
+    st_sp, w_sp, l_sp = _run(3)
+    assert not st_sp.dp
+    assert l_dp == l_sp
+    assert w_dp.keys() == w_sp.keys()
+    for k in w_dp:
+        assert torch.equal(w_dp[k], w_sp[k]), k
+    # gradients of the DP run are views into ONE flat buffer per network (what was all-reduced)
+    flat = st_dp.bucket_g._flat  # the run's last update was a generator step
+    live = [p for p in st_dp.gen.parameters() if p.grad is not None]
+    assert flat is not None and sum(p.numel() for p in live) == flat.numel()
+    assert all(flat.data_ptr() <= p.grad.data_ptr() < flat.data_ptr() + 4 * flat.numel() for p in live)

@@ -509,3 +509,22 @@ def test_input_transform_matches_the_tensor_expressions(case):
     got = ops.input_transform(x.to(DEV), side)
     assert got.dtype == torch.float32 and tuple(got.shape) == (n, 2, side, side)
     report("input transform", got, ref.double(), 3e-6)
+
+
+def test_input_transform_matches_reference_fixture():
+    """mg_input_transform against tests/golden/transforms.npz: the REFERENCE's ChannelMinMaxNorm / ChangeRange outputs
+    (audio/transforms.py:4-40; `side` == input size makes the resize the identity, so this part is pinned on the reference alone,
+    incl. the constant channel that divides by eps) and its Grower.scale_transform at levels 0, 3, 5 on a stored float64 sample
+    (Resize through the torchvision stand-in: pinned on aten's bilinear + antialias)."""
+    ops = _ops()
+    from golden_util import load
+    g = load("transforms.npz")
+    x64 = torch.from_numpy(g["x64"])
+    got = ops.input_transform(x64.to(DEV), 64)
+    assert float((got.cpu() - torch.from_numpy(g["ranged"])).abs().max()) <= 5e-7
+    got32 = ops.input_transform(x64.float().to(DEV), 64)
+    assert torch.equal(got32, got)  # train.py:139 casts to float first: feeding float64 or float32 gives the same result
+    big = torch.from_numpy(g["big32"]).double().to(DEV)
+    for level, side in ((0, 4), (3, 32), (5, 128)):
+        y = ops.input_transform(big, side)
+        assert float((y.cpu() - torch.from_numpy(g[f"scaled_l{level}"])).abs().max()) <= 3e-6, level
