@@ -61,6 +61,56 @@ def flops_per_image(level: int, rand_channels: int) -> float:
     return 4 * g + 12 * d
 
 
+def executed_flops_per_image(level: int, rand_channels: int, batch: int) -> float:
+    """FLOPs the MFMA pipe actually executes per image and D+G step: the same layer walk as `flops_per_image`, each 3x3
+    convolution pass weighted 1/2.25 where the engine runs it in Winograd F(2x2,3x3) / F(3x3,2x2) or sub-pixel form (the kernel
+    choice predicates of musicgan_amd.ops, evaluated for the batch each pass really sees: 3N in the fused critic step, N
+    elsewhere) and 1 where it takes the direct implicit GEMM.  Static arithmetic; padding of odd channel counts not counted."""
+    from musicgan_amd import ops
+    tail = [128, 112, 96, 80, 64, 48, 32, 16]
+    ins = [rand_channels] + tail[:-1]
+    dch = [(16, 32), (32, 48), (48, 64), (64, 80), (80, 96), (96, 112), (112, 128), (128, 144), (144, 160)]
+    n = batch
+    W = 1.0 / 2.25
+
+    def conv(nb, cin, cout, h, w, pixnorm=False):  # forward-like pass (forward, data gradient, tangent)
+        return 18.0 * cin * cout * h * w * nb * (W if ops.wino3x3_supported(nb, cout, h, w, pixnorm=pixnorm, cin=cin) else 1.0)
+
+    def wgrad(nb, cin, cout, h, w, ups=False):
+        return 18.0 * cin * cout * h * w * nb * (W if ops.wino_wgrad_supported(nb, cin, cout, h, w, ups=ups) else 1.0)
+
+    def gen_pass(backward: bool) -> float:
+        f, s = 0.0, 2
+        for i in range(level + 1):
+            ci, co = ins[i], tail[i]
+            f += conv(n, ci, ci, s, s, pixnorm=True)
+            sub = ops.upconv3x3_supported(co, s, n * ci * s * s)
+            f += 18.0 * ci * co * 4 * s * s * n * (W if sub else 1.0)
+            if backward:
+                f += wgrad(n, ci, co, 2 * s, 2 * s, ups=True) + wgrad(n, ci, ci, s, s)
+                f += 18.0 * ci * co * 4 * s * s * n * (W if ops.upconv3x3_dgrad_supported(s, s, n * co * 4 * s * s) else 1.0)
+                if i > 0:
+                    f += conv(n, ci, ci, s, s)
+            s *= 2
+        return f + 4.0 * n * (tail[level] * s * s + (tail[level - 1] * (s // 2) ** 2 if level > 0 else 0)) * (3 if backward else 1)
+
+    def disc_pass(nb, passes_fwd_like: int, with_wgrad: bool) -> float:
+        f, t = 0.0, LEVEL_SIDE[level]
+        for i in range(7 - level, 9):
+            ci, co = dch[i]
+            f += passes_fwd_like * (conv(nb, ci, co, t, t) + conv(nb, co, co, t // 2, t // 2))
+            if with_wgrad:
+                f += wgrad(nb, ci, co, t, t) + wgrad(nb, co, co, t // 2, t // 2)
+            t //= 2
+        side = LEVEL_SIDE[level]
+        small = 4.0 * nb * (dch[7 - level][0] * side * side + (dch[7 - level][1] * (side // 2) ** 2 if level > 0 else 0)) + 320.0 * nb
+        return f + small * (passes_fwd_like + (1 if with_wgrad else 0))
+
+    d_step = gen_pass(False) + disc_pass(3 * n, 2, True) + disc_pass(n, 1, False)  # fwd + dgrad over 3N, wgrad over 3N, tangent over N
+    g_step = gen_pass(True) + disc_pass(n, 2, False)
+    return (d_step + g_step) / n
+
+
 def dominant_kernel_probe(device, batch: int, iters: int = 10):
     """Time the dominant kernel of the step -- the first discriminator conv 48->64 @128x128 + LeakyReLU + fused AvgPool2d over the
     fused critic step's batch [real|fake|interpolated] = 3*batch images, Winograd F(2x2,3x3) kernel wino3x3_mfma<2,2,4> (173.9
@@ -96,6 +146,109 @@ def dominant_kernel_probe(device, batch: int, iters: int = 10):
         with open(tpath) as f:
             out["hbm_traffic"] = json.load(f)
     return out
+
+
+def time_step(level: int, batch: int, rand_channels: int, device, steps: int, warmup: int, seed: int = 1234):
+    """ms per D+G step of a fresh single-GPU stepper at (level, batch), HIP events on the launch stream, nothing skipped."""
+    from musicgan_amd.optim import FusedAdam
+    from musicgan_amd.train_step import ProGANStepper
+    gen, disc = build_nets(level, rand_channels, device)
+    og = FusedAdam(gen.parameters(), lr=1e-3, betas=(0.0, 0.9))
+    od = FusedAdam(disc.parameters(), lr=1e-3, betas=(0.0, 0.9))
+    stepper = ProGANStepper(gen, disc, og, od, rand_channels)
+    side = LEVEL_SIDE[level]
+    rng = torch.Generator(device=device).manual_seed(seed)
+    x_real = torch.rand(batch, 2, side, side, device=device, generator=rng) * 2 - 1
+
+    def one():
+        z = torch.randn(batch, rand_channels, 2, 2, device=device, generator=rng)
+        eps = torch.rand(batch, 1, 1, 1, device=device, generator=rng)
+        z2 = torch.randn(batch, rand_channels, 2, 2, device=device, generator=rng)
+        stepper.d_step(x_real, 0.5, z=z, eps=eps)
+        stepper.g_step(batch, 0.5, device, z=z2)
+
+    for _ in range(warmup):
+        one()
+    stream = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(steps):
+        one()
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
+def config2_record(device, rand_channels: int, cpu: bool):
+    """BASELINE.json configs[1]: ProGAN 2x64x64 (level 4), batch 32, one MI355X -- same step, same accounting as the headline."""
+    level, batch = 4, 32
+    ms = time_step(level, batch, rand_channels, device, steps=30, warmup=5)
+    ips = batch / ms * 1e3
+    fpi, xfpi = flops_per_image(level, rand_channels), executed_flops_per_image(level, rand_channels, batch)
+    rec = {"workload": "ProGAN level 4 WGAN-GP D+G step, 2x64x64, batch 32, alpha 0.5", "value": ips, "unit": "images/s",
+           "ms_per_step": ms, "steps": 30, "warmup": 5,
+           "roofline": {"bound": "mfma", "achieved": fpi * ips / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": fpi * ips / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                        "executed_frac": xfpi * ips / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                        "basis": f"{fpi / 1e9:.2f} algorithmic / {xfpi / 1e9:.2f} executed GFLOP per image"}}
+    if cpu:
+        rec["cpu_baseline"] = cpu_baseline(level, rand_channels, batch, iters=1)
+    return rec
+
+
+def stft_record(device, cpu: bool):
+    """BASELINE.json configs[4] on one GPU: one 10-minute 44.1 kHz file (mono U(-0.5,0.5), seed 7; 103 360 frames) through
+    mg_stft_1024 (audio/functions.py:38-62) and through STFT + codec (wav_to_stft + stft_to_phase_magn, :38-94), HIP events on the
+    launch stream, input resident in HBM.  Roofline: 5 120 algorithmic bytes per frame (1 024 B of new samples in, 4 096 B of
+    complex bins out) against 8 TB/s."""
+    from musicgan_amd import audio, ops
+    L = 44100 * 600
+    g = torch.Generator(device=device).manual_seed(7)
+    wav = torch.rand(L, device=device, generator=g) - 0.5
+    T = 1 + L // 256
+
+    def timeit(fn, iters):
+        for _ in range(3):
+            fn()
+        stream = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(iters):
+            fn()
+        e1.record(stream)
+        e1.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    ms_stft = timeit(lambda: ops.stft_1024(wav), 50)
+    ms_both = timeit(lambda: audio.stft_to_phase_magn(ops.stft_1024(wav)), 10)
+    mp = torch.stack(audio.stft_to_phase_magn(ops.stft_1024(wav)), dim=1)[:8].contiguous()  # 8 samples = 4 096 frames
+    fps = T / (ms_stft * 1e-3)
+    rec = {"workload": "10 min mono 44.1 kHz synthetic file, n_fft 1024 hop 256: 103 360 frames -> 201 samples (2x512x512)",
+           "metric": "STFT frames/s (mg_stft_1024)", "value": fps, "unit": "frames/s", "ms_per_file": ms_stft,
+           "stft_plus_codec": {"ms_per_file": ms_both, "frames_per_s": T / (ms_both * 1e-3),
+                               "samples_per_s": ((T - 1) // 512) / (ms_both * 1e-3)},
+           "roofline": {"bound": "hbm", "achieved": 5120.0 * fps / 1e9, "peak": 8000.0, "unit": "GB/s",
+                        "frac": 5120.0 * fps / 8e12, "traffic": None,
+                        "basis": "5 120 algorithmic bytes per frame x frames per launch / HIP-event launch time"}}
+    ms_inv = timeit(lambda: audio.functions.magn_phase_to_waveform(mp), 10)
+    rec["inverse"] = {"workload": "8 samples (4 096 frames) -> waveform, mg_codec_inv (functions.py:97-139)",
+                      "ms": ms_inv, "frames_per_s": 4096 / (ms_inv * 1e-3)}
+    if cpu:
+        torch.set_num_threads(host_cpu_share())
+        w = wav.cpu()
+        win = torch.hann_window(1024)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            c = torch.stft(w, 1024, 256, 1024, win, center=True, pad_mode="reflect", normalized=False, onesided=True,
+                           return_complex=True)
+            c = (c / win.pow(2.0).sum().sqrt())[:-1]
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        rec["cpu_baseline"] = {"value": T / best, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": "the same 10-minute file through torch.stft (what the reference's torchaudio call "
+                                         "lowers to, functions.py:53-62) + normalisation + Nyquist drop, min of 3"}
+    return rec
 
 
 def host_cpu_share() -> int:
@@ -149,6 +302,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--rand-channels", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the config-2 (L4 bs32) and STFT records")
     ap.add_argument("--cpu-batch", type=int, default=64)
     args = ap.parse_args()
 
@@ -237,6 +391,7 @@ def main():
         print(f"weights_abs_sum {cs:.10e}", file=sys.stderr, flush=True)
     if rank == 0:
         fpi = flops_per_image(args.level, args.rand_channels)
+        xfpi = executed_flops_per_image(args.level, args.rand_channels, args.batch)
         achieved = fpi * images_per_s / world / 1e12
         dom = dominant_kernel_probe(device, args.batch)
         line = {
@@ -250,8 +405,11 @@ def main():
                        "global_batch": world * args.batch, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_F32_PEAK_TFLOPS,
+                         "executed_frac": xfpi * images_per_s / world / 1e12 / MFMA_F32_PEAK_TFLOPS,
                          "traffic": (dom.get("hbm_traffic") or {}).get("bytes_per_launch"),
-                         "basis": f"whole step, per GPU: {fpi / 1e9:.2f} algorithmic GFLOP/image (4*Gf+12*Df) x images/s",
+                         "basis": f"whole step, per GPU: {fpi / 1e9:.2f} algorithmic GFLOP/image (4*Gf+12*Df) x images/s; "
+                                  f"executed_frac: {xfpi / 1e9:.2f} GFLOP/image actually issued to the MFMA pipe "
+                                  f"(Winograd / sub-pixel passes count 1/2.25)",
                          "dominant_kernel": {**dom, "frac": dom["tflops"] / MFMA_F32_PEAK_TFLOPS,
                                              "executed_frac": dom["executed_tflops"] / MFMA_F32_PEAK_TFLOPS}},
         }
@@ -259,6 +417,10 @@ def main():
             line["secondary"] = cadence
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.level, args.rand_channels, args.cpu_batch, iters=2)
+        if world == 1 and not args.no_extra and args.level == 5:
+            # SURVEY 8(d)'s other single-GPU figures, timed in the same run: BASELINE.json configs[1] and configs[4]
+            line["l4_bs32"] = config2_record(device, args.rand_channels, cpu=not args.no_cpu_baseline)
+            line["stft"] = stft_record(device, cpu=not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
