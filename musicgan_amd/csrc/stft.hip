@@ -16,8 +16,15 @@ constexpr int NFFT = 1024, HOP = 256, NB = 512;  // NB = complex points = output
 constexpr int NWAVE = 8;                          // waves per workgroup
 constexpr int FPW = 2;                            // frames per wave and tile
 constexpr int FPB = NWAVE * FPW;                  // frames per tile: 8 x 8 bytes = one 64-byte run per bin row
-constexpr int XSTR = NB + 1;                      // per-frame LDS column (float2 units), padded: the transposed read-out is conflict-free
-constexpr size_t STFT_LDS = (size_t)(NFFT * 2 + NFFT + FPB * XSTR * 2) * sizeof(float);
+// per-frame LDS column (float2 units).  XSTR = 2 (mod 32): in the transposed read-out the 16 frames of one bin row land on the
+// even 8-byte slots of the 256-byte bank row and the next bin row's on the odd ones, so a 32-lane ds_read_b64 group is conflict-free
+constexpr int XSTR = NB + 2;
+// twiddle tables, each laid out in the order its pass reads it (lane-contiguous or broadcast: no bank conflicts):
+//   tw[k]       = e^{-2 pi i k / 1024}, k < 512                     (untangling; lane k & 63)
+//   tw1[r][k]   = e^{-2 pi i r k / 64},  r, k < 8                    (pass 1; 8 distinct addresses per instruction)
+//   tw2[r][j]   = e^{-2 pi i r j / 512}, r < 8, j < 64               (pass 2; lane j)
+constexpr int TW_FLOATS = (NB + 64 + 512) * 2;
+constexpr size_t STFT_LDS = (size_t)(TW_FLOATS + NFFT + FPB * XSTR * 2) * sizeof(float);
 
 // Complex numbers as register pairs.  Every swap / negate of a component rides on the operand-select and negate modifiers of
 // the packed instruction that consumes it (hipcc builds such vectors with v_mov / v_xor instead: a third of the kernel's
@@ -89,18 +96,31 @@ __device__ __forceinline__ void dft8(c2 (&v)[8]) {
 __global__ void __launch_bounds__(64 * NWAVE, 2) stft1024_kernel(const float* __restrict__ wav, float* __restrict__ out_re,
                                                               float* __restrict__ out_im, long long L, int T, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  c2* tw = reinterpret_cast<c2*>(smem);                       // tw[m] = exp(-2 pi i m / 1024)
-  float* win = smem + NFFT * 2;                                // Hann / sqrt(sum w^2)
+  c2* tw = reinterpret_cast<c2*>(smem);                       // tw[k], k < 512
+  c2* tw1 = tw + NB;                                           // tw1[r * 8 + k]
+  c2* tw2 = tw1 + 64;                                          // tw2[r * 64 + j]
+  float* win = smem + TW_FLOATS;                               // Hann / sqrt(sum w^2)
   c2* xbuf = reinterpret_cast<c2*>(win + NFFT);                // [FPB][XSTR] one column per frame of the tile
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int m = tid; m < NFFT; m += 64 * NWAVE) {
     float s, c;
     sincospif((float)m * (1.0f / 512.0f), &s, &c);  // angle = 2 pi m / 1024 = pi * m / 512
-    tw[m] = c2{c, -s};
+    if (m < NB) tw[m] = c2{c, -s};
     // Hann / sqrt(384) (sum of hann^2 over 1024 = 384), times the 1/2 of the real-FFT untangling: a power-of-two scale
     // commutes exactly with every rounding of the (linear) transform, so it costs nothing here instead of 16 multiplies there
     win[m] = (0.5f - 0.5f * c) * (0.5f * 0.05103103630798288f);
+    // the pass twiddles are the same 1024-th roots (identical bits to indexing one table): tw1[r][k] = root 16 r k, tw2[r][j] = root 2 r j
+    if (m < 64) {
+      float s1, c1;
+      sincospif((float)(((m >> 3) * (m & 7) * 16) & (NFFT - 1)) * (1.0f / 512.0f), &s1, &c1);
+      tw1[m] = c2{c1, -s1};
+    }
+    if (m < 512) {
+      float s2, c2_;
+      sincospif((float)(((m >> 6) * (m & 63) * 2) & (NFFT - 1)) * (1.0f / 512.0f), &s2, &c2_);
+      tw2[m] = c2{c2_, -s2};
+    }
   }
   __syncthreads();
 
@@ -149,24 +169,31 @@ __global__ void __launch_bounds__(64 * NWAVE, 2) stft1024_kernel(const float* __
       // pass 0 (Ns = 1): no twiddles; out[8 j + r]
       dft8(v);
       __builtin_amdgcn_wave_barrier();
+      // Exchange 1: element e = 8 j + r is stored at e ^ ((e >> 4) & 7).  A ds_write_b64 is served in groups of 16 contiguous
+      // lanes over 32 banks (16 eight-byte slots): unswizzled, 8 j + r puts the 16 lanes on 2 slots (8-way conflict); the XOR
+      // with j >> 1 spreads them over all 16.  The reader's e = j + 64 r has (e >> 4) & 7 = ((j >> 4) + 4 r) & 7: constant
+      // per 16 lanes, so its 32-lane groups still read 32 distinct slots.
 #pragma unroll
-      for (int r = 0; r < 8; ++r) xb[8 * lane + r] = v[r];
+      for (int r = 0; r < 8; ++r) xb[(8 * lane + r) ^ ((lane >> 1) & 7)] = v[r];
       __builtin_amdgcn_wave_barrier();
       // pass 1 (Ns = 8): in[j + 64 r] * exp(-2 pi i r k / 64), k = j & 7; out[(j>>3)*64 + k + 8 r]
       {
         const int k = lane & 7;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = cmul(xb[lane + 64 * r], tw[(r * k * 16) & (NFFT - 1)]);  // 1024/64 = 16
+        for (int r = 0; r < 8; ++r)  // ((lane >> 4) + 4 r) & 7 = (lane >> 4) ^ 4 (r & 1): two base addresses + immediate offsets
+          v[r] = cmul(xb[((lane ^ (lane >> 4)) ^ (4 * (r & 1))) + 64 * r], tw1[r * 8 + k]);
         dft8(v);
         __builtin_amdgcn_wave_barrier();
-        const int j0 = (lane >> 3) * 64 + k;
+        // Exchange 2: element e = 64 g + k + 8 r (g = j >> 3) is stored at e ^ (8 * (g & 1)): the two g of a 16-lane write group
+        // would share their 8 slots, bit 3 separates them.  The reader's e = j + 64 r sees the constant 8 * (r & 1).
+        const int j0 = (lane >> 3) * 64 + k, swz = lane & 8;  // 8 * (g & 1)
 #pragma unroll
-        for (int r = 0; r < 8; ++r) xb[j0 + 8 * r] = v[r];
+        for (int r = 0; r < 8; ++r) xb[(j0 + 8 * r) ^ swz] = v[r];
         __builtin_amdgcn_wave_barrier();
       }
       // pass 2 (Ns = 64): in[j + 64 r] * exp(-2 pi i r j / 512); result Z[j + 64 r] stays in lane j, register r
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = cmul(xb[lane + 64 * r], tw[(r * lane * 2) & (NFFT - 1)]);  // 1024/512 = 2
+      for (int r = 0; r < 8; ++r) v[r] = cmul(xb[(lane + 64 * r) ^ (8 * (r & 1))], tw2[r * 64 + lane]);
       dft8(v);
       __builtin_amdgcn_wave_barrier();
       // untangle: X[k] = (Z[k] + conj Z[512-k])/2 - i/2 * e^{-2 pi i k/1024} * (Z[k] - conj Z[512-k]),  k = lane + 64 r.
@@ -190,20 +217,33 @@ __global__ void __launch_bounds__(64 * NWAVE, 2) stft1024_kernel(const float* __
       }
     }
     __syncthreads();
-    // transposed write-out: the 16 frames of one bin row per 16 lanes
+    // transposed write-out: the 16 frames of one bin row per 8 lanes, two frames (16 bytes) per lane -- stores are issue-bound per
+    // instruction, so half as many twice as wide; a store instruction writes eight 128-byte runs along t
     {
-      const int f = tid & (FPB - 1);
-      const int t = t0 + f;
-      if (t < T) {
+      const int fp = tid & (FPB / 2 - 1);  // frame pair
+      const int t = t0 + 2 * fp;
+      if (out_im == nullptr && (T & 1) == 0) {  // interleaved complex output, rows 16-byte aligned
+        if (t < T) {  // T even: t + 1 < T too
 #pragma unroll 4
-        for (int k = tid / FPB; k < NB; k += 64 * NWAVE / FPB) {
-          const c2 o = xbuf[f * XSTR + k];
-          const size_t idx = (size_t)k * T + t;
-          if (out_im != nullptr) {
-            out_re[idx] = o.x;
-            out_im[idx] = o.y;
-          } else {
-            *reinterpret_cast<c2*>(out_re + 2 * idx) = o;
+          for (int k = tid / (FPB / 2); k < NB; k += 64 * NWAVE / (FPB / 2)) {
+            const c2 o0 = xbuf[(2 * fp) * XSTR + k], o1 = xbuf[(2 * fp + 1) * XSTR + k];
+            *reinterpret_cast<f32x4*>(out_re + 2 * ((size_t)k * T + t)) = f32x4{o0.x, o0.y, o1.x, o1.y};
+          }
+        }
+      } else {
+        const int f = tid & (FPB - 1);
+        const int tt = t0 + f;
+        if (tt < T) {
+#pragma unroll 4
+          for (int k = tid / FPB; k < NB; k += 64 * NWAVE / FPB) {
+            const c2 o = xbuf[f * XSTR + k];
+            const size_t idx = (size_t)k * T + tt;
+            if (out_im != nullptr) {
+              out_re[idx] = o.x;
+              out_im[idx] = o.y;
+            } else {
+              *reinterpret_cast<c2*>(out_re + 2 * idx) = o;
+            }
           }
         }
       }
