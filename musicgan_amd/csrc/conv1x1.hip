@@ -93,6 +93,53 @@ __global__ void __launch_bounds__(256) conv1x1_few_in(const C1Args a) {
   }
 }
 
+// few output channels on small maps (< 2^20 pixels: every thread of the streaming kernel below would walk all Cin channels of
+// one pixel -- 48..160 dependent-latency loads with too few threads to cover them): the 4 waves of a workgroup split the input
+// channels of 64 pixels (lane = pixel, so loads stay coalesced) and combine their partial sums through LDS in a fixed order.
+__global__ void __launch_bounds__(256) conv1x1_few_out_split(const C1Args a) {
+  __shared__ float red[3][FEW][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t total = (size_t)a.N * a.HW;
+  for (size_t base = (size_t)blockIdx.x * 64; base < total; base += (size_t)gridDim.x * 64) {
+    const size_t i = base + lane;
+    const bool ok = i < total;
+    const int n = ok ? (int)(i / a.HW) : 0;
+    const int p = ok ? (int)(i - (size_t)n * a.HW) : 0;
+    float acc[FEW];
+#pragma unroll
+    for (int o = 0; o < FEW; ++o) acc[o] = 0.f;
+    const float* xp = a.x + (size_t)n * a.Cin * a.HW + p;
+    if (ok) {
+#pragma unroll 4
+      for (int c = wave; c < a.Cin; c += 4) {
+        float xv = xp[(size_t)c * a.HW];
+        if (a.flags & MG_C1_MASK_AUX) xv *= mg_lrelu_mask(a.aux[((size_t)n * a.Cin + c) * a.HW + p], a.slope);
+#pragma unroll
+        for (int o = 0; o < FEW; ++o)
+          if (o < a.Cout) acc[o] = fmaf(a.w[o * a.so + c * a.sc], xv, acc[o]);
+      }
+    }
+    if (wave > 0) {
+#pragma unroll
+      for (int o = 0; o < FEW; ++o) red[wave - 1][o][lane] = acc[o];
+    }
+    __syncthreads();
+    if (wave == 0 && ok) {
+#pragma unroll
+      for (int o = 0; o < FEW; ++o) {
+        if (o < a.Cout) {
+          float r = ((acc[o] + red[0][o][lane]) + red[1][o][lane]) + red[2][o][lane];
+          r += a.bias ? a.bias[o] : 0.f;
+          if (a.flags & MG_C1_LRELU) r = mg_lrelu(r, a.slope);
+          if (a.flags & MG_C1_TANH) r = tanhf(r);
+          a.y[((size_t)n * a.Cout + o) * a.HW + p] = r;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // few output channels (Cout <= 4): out[o] = act(b[o] + sum_c w[o][c] x[c]),  x streamed once
 template <int V>
 __global__ void __launch_bounds__(256) conv1x1_few_out(const C1Args a) {
@@ -321,10 +368,15 @@ extern "C" int mg_conv1x1(const float* x, const float* w, const float* bias, con
     // few-out: MASK_AUX applies to the INPUT (aux has Cin channels).  Small maps: one pixel per thread (4x the threads).
     MG_CHECK_ARG(!(flags & MG_C1_TANH_BWD_IN), "mg_conv1x1: TANH_BWD_IN needs Cin<=4");
     a.co_per = Cout;
-    if (px < ((size_t)1 << 20)) vec = false;
-    const int grid = c1_grid(vec ? px / 4 : px);
-    if (vec) hipLaunchKernelGGL(conv1x1_few_out<4>, dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(conv1x1_few_out<1>, dim3(grid), dim3(256), 0, s, a);
+    if (px < ((size_t)1 << 20) && Cin >= 16) {
+      size_t b = (px + 63) / 64;
+      hipLaunchKernelGGL(conv1x1_few_out_split, dim3((unsigned)(b > 4096 ? 4096 : b)), dim3(256), 0, s, a);
+    } else {
+      if (px < ((size_t)1 << 20)) vec = false;
+      const int grid = c1_grid(vec ? px / 4 : px);
+      if (vec) hipLaunchKernelGGL(conv1x1_few_out<4>, dim3(grid), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(conv1x1_few_out<1>, dim3(grid), dim3(256), 0, s, a);
+    }
   }
   MG_CHECK_LAUNCH("mg_conv1x1");
   return MG_OK;

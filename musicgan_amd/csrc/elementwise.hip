@@ -383,20 +383,30 @@ __global__ void __launch_bounds__(256) linear1_bwd_k(const float* __restrict__ x
   // The classifier weight gradient is a cancellation: -mean(real features) + mean(fake features) + penalty term leaves
   // ~1e-6 from ~0.05-sized summands.  Summing the few hundred terms in fp64 costs nothing (K = 160 threads x N <= 600 fmas) and
   // removes the order-dependent fp32 round-off of the intermediate sums (each product is exact in fp64).
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+  // one wave per feature k (4 per workgroup), its 64 lanes stride over the samples; lane partials and the xor-tree are in fp64 and in
+  // a fixed order (deterministic).  (A single workgroup walking all N samples per thread took 35-95 us: 100+ dependent loads.)
+  const int lane = threadIdx.x & 63;
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k < K) {
     const float wk = w[k];
     double s = 0.0;
-    for (int n = 0; n < N; ++n) {
+    for (int n = lane; n < N; n += 64) {
       const float g = gy[n];
       if (gx) gx[(size_t)n * K + k] = g * wk;
       if (gw) s += (double)g * (double)x[(size_t)n * K + k];
     }
-    if (gw) gw[k] = accumulate ? (float)((double)gw[k] + s) : (float)s;
+    if (gw) {
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+      if (lane == 0) gw[k] = accumulate ? (float)((double)gw[k] + s) : (float)s;
+    }
   }
-  if (gb && threadIdx.x == 0) {
+  if (gb && blockIdx.x == 0 && threadIdx.x < 64) {
     double s = 0.0;
-    for (int n = 0; n < N; ++n) s += (double)gy[n];
-    gb[0] = accumulate ? (float)((double)gb[0] + s) : (float)s;
+    for (int n = lane; n < N; n += 64) s += (double)gy[n];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if (lane == 0) gb[0] = accumulate ? (float)((double)gb[0] + s) : (float)s;
   }
 }
 
@@ -543,7 +553,7 @@ extern "C" int mg_linear1_fwd(const float* x, const float* w, const float* b, fl
 extern "C" int mg_linear1_bwd(const float* x, const float* w, const float* gy, float* gx, float* gw, float* gb, int N,
                               int K, int accumulate, mg_stream_t stream) {
   MG_CHECK_ARG(w && gy && N > 0 && K > 0 && (!gw || x), "mg_linear1_bwd: bad arguments");
-  EW_LAUNCH(linear1_bwd_k, 1, 256, x, w, gy, gx, gw, gb, N, K, accumulate);
+  EW_LAUNCH(linear1_bwd_k, (K + 3) / 4, 256, x, w, gy, gx, gw, gb, N, K, accumulate);
   MG_CHECK_LAUNCH("mg_linear1_bwd");
   return MG_OK;
 }

@@ -19,6 +19,7 @@ Gradient penalty  P = 10 * mean_n (||g_0[n]|| - 1)^2,  g_0 = d D(x~) / d x~  (fi
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -58,6 +59,23 @@ class PackCache:
         if ops.wino3x3_supported(n, cout, h, wd, ups=kw.get("ups", False), pixnorm=kw.get("pixnorm", False), cin=cin):
             return ops.conv3x3(x, None, bias, cout, wino=self.get_wino(w, dgrad), **kw)
         return ops.conv3x3(x, self.get(w, dgrad), bias, cout, **kw)
+
+    def conv_lrelu_pixnorm(self, x: torch.Tensor, w: torch.Tensor, bias, cout: int, ups: bool = False):
+        """conv3x3 (+ nearest x2 up-sampling of its input) + LeakyReLU + PixelNorm -> (p, 1/norm).  The fused kernels keep all
+        output channels of a pixel in one wave, so the grid is output pixels / 64 workgroups; on the small maps at the start of the
+        generator that is 8 .. 128 workgroups for 256 CUs, each walking all of Cin x 9 taps x Cout alone (60-80 us for 0.1-1.4
+        GFLOP).  There the convolution runs sliced over out-channels (many short workgroups) and PixelNorm as its own pass over
+        the (tiny) result."""
+        n, cin, h, wd = x.shape
+        ho, wo = (2 * h, 2 * wd) if ups else (h, wd)
+        if n * ho * wo >= int(os.environ.get("MG_PN_FUSE_MIN_PIXELS", "16384")):
+            if ups and ops.upconv3x3_supported(cout, wd, x.numel()):  # sub-pixel form: 2.25x fewer MFMAs
+                _, p, rn = ops.upconv3x3(x, self.get_up(w), bias, cout, lrelu=True, pixnorm=True, want_y=False)
+            else:
+                _, p, rn = self.conv(x, w, False, bias, cout, ups=ups, lrelu=True, pixnorm=True, want_y=False)
+            return p, rn
+        y = self.conv(x, w, False, bias, cout, ups=ups, lrelu=True)
+        return ops.pixelnorm_fwd(y)
 
     def get_up(self, w: torch.Tensor) -> torch.Tensor:
         """Effective sub-pixel weights of Upsample(x2) -> Conv3x3 (ops.upconv3x3)."""
@@ -128,11 +146,8 @@ def gen_forward(W: GenWeights, z: torch.Tensor, alpha: float, cache: PackCache, 
     for (w1, b1, w2, b2) in W.blocks:
         ci, co = w1.shape[0], w2.shape[0]
         # only the normalised outputs p and the per-pixel 1/norm are kept: the backward derives mask and x_hat from p
-        _, p1, rn1 = cache.conv(x, w1, False, b1, ci, lrelu=True, pixnorm=True, want_y=False)
-        if ops.upconv3x3_supported(co, p1.shape[3], p1.numel()):  # sub-pixel form: 2.25x fewer MFMAs than conv over the upsampled map
-            _, p2, rn2 = ops.upconv3x3(p1, cache.get_up(w2), b2, co, lrelu=True, pixnorm=True, want_y=False)
-        else:
-            _, p2, rn2 = cache.conv(p1, w2, False, b2, co, ups=True, lrelu=True, pixnorm=True, want_y=False)
+        p1, rn1 = cache.conv_lrelu_pixnorm(x, w1, b1, ci)
+        p2, rn2 = cache.conv_lrelu_pixnorm(p1, w2, b2, co, ups=True)
         if save:
             saved.append((x, rn1, p1, rn2, p2))
         x_in_last, x = x, p2
