@@ -154,6 +154,18 @@ int mg_gp_finish(const float* sumsq, float* penalty, float* coef, int N, float f
 /* sum over (n, hw) of a per-channel tensor: out[c] (+)= sum x[n,c,hw] */
 int mg_channel_sum(const float* x, float* out, int N, int C, int HW, int accumulate, mg_stream_t stream);
 
+/* ------------------------------------------------------------------ multi-tensor weight re-packing
+ * All of mg_conv3x3_pack / mg_wino3x3_pack / mg_upconv3x3_pack / mg_upconv3x3_dgrad_pack for a list of weights in ONE launch (the
+ * reference has no counterpart: these layouts replace what MIOpen / oneDNN re-derive from nn.Conv2d.weight inside every call).
+ * descs is a HOST array; `out` buffers are sized by the matching *_packed_floats(). */
+enum { MG_PACK_CONV3X3 = 0, MG_PACK_WINO3X3 = 1, MG_PACK_UPCONV3X3 = 2, MG_PACK_UPCONV3X3_DGRAD = 3 };
+typedef struct {
+  const float* w; /* module weight [Co][Ci][3][3] */
+  float* out;
+  int32_t kind, Co, Ci, dgrad; /* dgrad: data-gradient variant (kinds 0 and 1 only) */
+} mg_pack_desc_t;
+int mg_pack_multi(const mg_pack_desc_t* descs, int n, mg_stream_t stream);
+
 /* ------------------------------------------------------------------ fused Adam [train.py:64-70,175,214]
  * Multi-tensor torch.optim.Adam step (amsgrad off, weight_decay 0).  desc is a HOST array of n_tensors records (device pointers
  * inside); the records are passed to the kernel by value, so the call neither copies nor synchronises. */
@@ -168,6 +180,19 @@ typedef struct {
 } mg_adam_tensor_t;
 int mg_adam_step(const mg_adam_tensor_t* desc, int n_tensors, float beta1, float beta2, float eps, float grad_scale,
                  mg_stream_t stream);
+/* Same update with the per-parameter step count in DEVICE memory (int32, count BEFORE this update; advanced by the call): the
+ * bias corrections are formed on the device, so the launch carries nothing that changes from step to step and can be captured
+ * in a HIP graph and replayed (torch.optim.Adam(capturable=True) semantics). */
+typedef struct {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t numel;
+  int32_t* step;
+} mg_adam_tensor_dev_t;
+int mg_adam_step_dev(const mg_adam_tensor_dev_t* desc, int n_tensors, float lr, float beta1, float beta2, float eps,
+                     float grad_scale, mg_stream_t stream);
 
 /* ------------------------------------------------------------------ STFT [audio/functions.py:38-62]
  * wav: mono fp32 [L]; out_re/out_im: [512][T] (freq-major, Nyquist row dropped), T = 1 + L/256.  Periodic Hann(1024),

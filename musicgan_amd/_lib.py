@@ -27,6 +27,17 @@ class AdamTensor(Structure):
                 ("numel", c_int64), ("step_size", c_float), ("bc2_sqrt", c_float)]
 
 
+class AdamTensorDev(Structure):
+    _fields_ = [("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p),
+                ("numel", c_int64), ("step", c_void_p)]
+
+
+class PackDesc(Structure):
+    _fields_ = [("w", c_void_p), ("out", c_void_p), ("kind", c_int), ("Co", c_int), ("Ci", c_int), ("dgrad", c_int)]
+
+
+MG_PACK_CONV3X3, MG_PACK_WINO3X3, MG_PACK_UPCONV3X3, MG_PACK_UPCONV3X3_DGRAD = 0, 1, 2, 3
+
 _P = c_void_p
 # name -> (restype, argtypes); every entry must be exported by the library (checked by tests/test_abi.py)
 SIGNATURES = {
@@ -69,6 +80,8 @@ SIGNATURES = {
     "mg_gp_finish": (c_int, [_P, _P, _P, c_int, c_float, c_float, _P]),
     "mg_channel_sum": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "mg_adam_step": (c_int, [_P, c_int, c_float, c_float, c_float, c_float, _P]),
+    "mg_pack_multi": (c_int, [_P, c_int, _P]),
+    "mg_adam_step_dev": (c_int, [_P, c_int, c_float, c_float, c_float, c_float, c_float, _P]),
     "mg_input_transform_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "mg_input_transform": (c_int, [_P, c_int, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_float, _P]),
     "mg_stft_1024": (c_int, [_P, _P, _P, c_int64, _P]),

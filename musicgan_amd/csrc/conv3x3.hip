@@ -16,6 +16,7 @@
 #include <type_traits>
 
 #include "mg_common.h"
+#include "pack_kernels.h"
 
 namespace {
 
@@ -388,23 +389,9 @@ __global__ void __launch_bounds__(256) conv3x3_tiny(const ConvArgs a) {
   a.y[idx] = acc;
 }
 
-__global__ void conv3x3_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int dgrad,
-                                    int cin_call, int cout_call, int OPF, size_t total) {
+__global__ void conv3x3_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int dgrad, size_t total) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
-  const int o = (int)(e % OPF);
-  size_t r = e / OPF;
-  const int cl = (int)(r % CC);
-  r /= CC;
-  const int t = (int)(r % 9);
-  const int ch = (int)(r / 9);
-  const int c = ch * CC + cl;
-  float v = 0.f;
-  if (c < cin_call && o < cout_call) {
-    // dgrad=0: conv Ci->Co, W'[o][c][t] = w[o][c][t];  dgrad=1: conv Co->Ci, W'[o][c][t] = w[c][o][8-t]
-    v = dgrad ? w[((size_t)c * Ci + o) * 9 + (8 - t)] : w[((size_t)o * Ci + c) * 9 + t];
-  }
-  wp[e] = v;
+  if (e < total) pack_conv3x3_elem(e, w, wp, Co, Ci, dgrad);
 }
 
 template <int NI, int MI, bool PF, int SUB = 1>
@@ -470,12 +457,9 @@ extern "C" size_t mg_conv3x3_packed_floats(int Cin, int Cout) {
 
 extern "C" int mg_conv3x3_pack(const float* w, float* wp, int Co, int Ci, int dgrad, mg_stream_t stream) {
   MG_CHECK_ARG(w && wp && Co > 0 && Ci > 0, "mg_conv3x3_pack: bad arguments");
-  const int cin_call = dgrad ? Co : Ci, cout_call = dgrad ? Ci : Co;
-  const int OPF = 16 * mg_cdiv(cout_call, 16);
-  const size_t total = mg_conv3x3_packed_floats(cin_call, cout_call);
+  const size_t total = pack_conv3x3_total(Co, Ci, dgrad);
   const int blocks = (int)((total + 255) / 256);
-  hipLaunchKernelGGL(conv3x3_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wp, Co, Ci, dgrad,
-                     cin_call, cout_call, OPF, total);
+  hipLaunchKernelGGL(conv3x3_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wp, Co, Ci, dgrad, total);
   MG_CHECK_LAUNCH("mg_conv3x3_pack");
   return MG_OK;
 }

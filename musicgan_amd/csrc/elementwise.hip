@@ -433,6 +433,36 @@ __global__ void __launch_bounds__(256) adam_k(const AdamChunk desc, float beta1,
   }
 }
 
+// Capturable variant (HIP graphs): the step count lives in device memory, the bias corrections are formed in the kernel, and a
+// second one-wave launch behind it advances the counters -- nothing step-dependent is baked into the launch arguments.
+constexpr int ADAM_DEV_CHUNK = 56;
+struct AdamDevChunk {
+  mg_adam_tensor_dev_t t[ADAM_DEV_CHUNK];
+};
+
+__global__ void __launch_bounds__(256) adam_dev_k(const AdamDevChunk desc, float lr, float beta1, float beta2, float eps,
+                                                  float grad_scale) {
+  const mg_adam_tensor_dev_t d = desc.t[blockIdx.y];
+  const float t = (float)(*d.step + 1);  // count AFTER this update
+  const float bc1 = 1.f - (beta1 > 0.f ? powf(beta1, t) : 0.f);
+  const float bc2s = sqrtf(1.f - powf(beta2, t));
+  const float step_size = lr / bc1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.numel; i += (int64_t)gridDim.x * blockDim.x) {
+    const float g = d.grad[i] * grad_scale;
+    float m = d.exp_avg[i], v = d.exp_avg_sq[i];
+    m = m + (g - m) * (1.f - beta1);
+    v = v * beta2 + (1.f - beta2) * g * g;
+    const float denom = sqrtf(v) / bc2s + eps;
+    d.param[i] = d.param[i] - step_size * (m / denom);
+    d.exp_avg[i] = m;
+    d.exp_avg_sq[i] = v;
+  }
+}
+
+__global__ void __launch_bounds__(64) adam_tick_k(const AdamDevChunk desc, int n) {
+  if ((int)threadIdx.x < n) *desc.t[threadIdx.x].step += 1;
+}
+
 }  // namespace
 
 #define EW_LAUNCH(kernel, grid, block, ...)                                                   \
@@ -539,6 +569,25 @@ extern "C" int mg_axpby(float a, const float* x, float b, const float* y, float*
   if ((n & 3) == 0) EW_LAUNCH(axpby_k<4>, ew_grid(n / 4), 256, a, x, b, y, out, n / 4);
   else EW_LAUNCH(axpby_k<1>, ew_grid(n), 256, a, x, b, y, out, n);
   MG_CHECK_LAUNCH("mg_axpby");
+  return MG_OK;
+}
+
+extern "C" int mg_adam_step_dev(const mg_adam_tensor_dev_t* desc, int n_tensors, float lr, float beta1, float beta2, float eps,
+                                float grad_scale, mg_stream_t stream) {
+  MG_CHECK_ARG(desc && n_tensors > 0, "mg_adam_step_dev: bad arguments");
+  for (int first = 0; first < n_tensors; first += ADAM_DEV_CHUNK) {
+    const int n = n_tensors - first < ADAM_DEV_CHUNK ? n_tensors - first : ADAM_DEV_CHUNK;
+    AdamDevChunk c;
+    for (int i = 0; i < n; ++i) {
+      c.t[i] = desc[first + i];
+      MG_CHECK_ARG(c.t[i].param && c.t[i].grad && c.t[i].exp_avg && c.t[i].exp_avg_sq && c.t[i].step && c.t[i].numel >= 0,
+                   "mg_adam_step_dev: record %d has a null pointer", first + i);
+    }
+    hipLaunchKernelGGL(adam_dev_k, dim3(64, n), dim3(256), 0, (hipStream_t)stream, c, lr, beta1, beta2, eps, grad_scale);
+    MG_CHECK_LAUNCH("mg_adam_step_dev");
+    hipLaunchKernelGGL(adam_tick_k, dim3(1), dim3(64), 0, (hipStream_t)stream, c, n);  // behind every reader of the counters
+    MG_CHECK_LAUNCH("mg_adam_step_dev(tick)");
+  }
   return MG_OK;
 }
 

@@ -53,7 +53,7 @@ static inline int mg_ilog2(int v) {
   return l;
 }
 static inline int mg_pow2_ceil(int v) { return 1 << mg_ilog2(v); }
-static inline int mg_cdiv(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int mg_cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // XCD-aware, bijective block-id remap: blocks b and b+8 share an XCD (observed round-robin dispatch), so give each of the
 // 8 residue classes a contiguous chunk of the logical grid => neighbouring tiles (shared halos / weights) hit one L2.

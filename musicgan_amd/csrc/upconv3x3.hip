@@ -14,6 +14,7 @@
 // channels (64 output pixels, PixelNorm reduction inside the wave), 8-channel chunks through LDS with issue-early/write-late
 // register prefetch, weights pre-packed as the LDS image [chunk][16 = phase*4 + a*2 + b][8][16*ceil(Cout/16)].
 #include "mg_common.h"
+#include "pack_kernels.h"
 
 namespace {
 
@@ -460,32 +461,9 @@ __global__ void __launch_bounds__(256) downconv4x4s2_mfma(const DownArgs a) {
 }
 
 // K4 weights of the data-gradient form, LDS image layout [Cg/8][16][8][OPF]; w is the module weight [Co][Ci][3][3], Cg = Co, Cx = Ci.
-__global__ void downconv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int OPF,
-                                     size_t total) {
+__global__ void downconv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, size_t total) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
-  const int c = (int)(e % OPF);  // forward input channel = output channel of this conv
-  size_t r = e / OPF;
-  const int cl = (int)(r % CC);
-  r /= CC;
-  const int t = (int)(r % 16);
-  const int ch = (int)(r / 16);
-  const int o = ch * CC + cl;  // gradient (forward output) channel
-  float v = 0.f;
-  if (o < Co && c < Ci) {
-    const int u = t >> 2, vv = t & 3;
-    // offset u-1: -1 -> (p 1, t 1), 0 -> (0, 1), +1 -> (1, 0), +2 -> (0, 0);  taps of (p, t): p=0: t=0 {0}, t=1 {1,2}; p=1: t=0 {0,1}, t=1 {2}
-    const int py = (u == 0 || u == 2) ? 1 : 0, ta = (u <= 1) ? 1 : 0;
-    const int px = (vv == 0 || vv == 2) ? 1 : 0, tb = (vv <= 1) ? 1 : 0;
-    const int ky0 = py == 0 ? (ta == 0 ? 0 : 1) : (ta == 0 ? 0 : 2);
-    const int ky1 = py == 0 ? (ta == 0 ? 0 : 2) : (ta == 0 ? 1 : 2);
-    const int kx0 = px == 0 ? (tb == 0 ? 0 : 1) : (tb == 0 ? 0 : 2);
-    const int kx1 = px == 0 ? (tb == 0 ? 0 : 2) : (tb == 0 ? 1 : 2);
-    const float* wk = w + ((size_t)o * Ci + c) * 9;
-    for (int ky = ky0; ky <= ky1; ++ky)
-      for (int kx = kx0; kx <= kx1; ++kx) v += wk[ky * 3 + kx];
-  }
-  wp[e] = v;
+  if (e < total) pack_downconv_elem(e, w, wp, Co, Ci);
 }
 
 template <int NI>
@@ -501,30 +479,9 @@ int launch_down(const DownArgs& a, dim3 grid, size_t lds, hipStream_t s) {
 }
 
 // Effective sub-pixel weights in the LDS image layout.  w is the module weight [Co][Ci][3][3].
-__global__ void upconv3x3_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int OPF,
-                                      size_t total) {
+__global__ void upconv3x3_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, size_t total) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
-  const int o = (int)(e % OPF);
-  size_t r = e / OPF;
-  const int cl = (int)(r % CC);
-  r /= CC;
-  const int q = (int)(r % 16);  // phase*4 + a*2 + b
-  const int ch = (int)(r / 16);
-  const int c = ch * CC + cl;
-  float v = 0.f;
-  if (c < Ci && o < Co) {
-    const int py = q >> 3, px = (q >> 2) & 1, ta = (q >> 1) & 1, tb = q & 1;
-    // original taps k in {0,1,2} landing on low-res offset t for phase p:  p=0: t=0 <- {0}, t=1 <- {1,2};  p=1: t=0 <- {0,1}, t=1 <- {2}
-    const int ky0 = py == 0 ? (ta == 0 ? 0 : 1) : (ta == 0 ? 0 : 2);
-    const int ky1 = py == 0 ? (ta == 0 ? 0 : 2) : (ta == 0 ? 1 : 2);
-    const int kx0 = px == 0 ? (tb == 0 ? 0 : 1) : (tb == 0 ? 0 : 2);
-    const int kx1 = px == 0 ? (tb == 0 ? 0 : 2) : (tb == 0 ? 1 : 2);
-    const float* wk = w + ((size_t)o * Ci + c) * 9;
-    for (int ky = ky0; ky <= ky1; ++ky)
-      for (int kx = kx0; kx <= kx1; ++kx) v += wk[ky * 3 + kx];
-  }
-  wp[e] = v;
+  if (e < total) pack_upconv3x3_elem(e, w, wp, Co, Ci);
 }
 
 template <int NI>
@@ -547,10 +504,9 @@ extern "C" size_t mg_upconv3x3_packed_floats(int Cin, int Cout) {
 
 extern "C" int mg_upconv3x3_pack(const float* w, float* wp, int Co, int Ci, mg_stream_t stream) {
   MG_CHECK_ARG(w && wp && Co > 0 && Ci > 0, "mg_upconv3x3_pack: bad arguments");
-  const int OPF = 16 * mg_cdiv(Co, 16);
   const size_t total = mg_upconv3x3_packed_floats(Ci, Co);
   hipLaunchKernelGGL(upconv3x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, wp,
-                     Co, Ci, OPF, total);
+                     Co, Ci, total);
   MG_CHECK_LAUNCH("mg_upconv3x3_pack");
   return MG_OK;
 }
@@ -608,10 +564,9 @@ extern "C" size_t mg_upconv3x3_dgrad_packed_floats(int Cin, int Cout) {
 
 extern "C" int mg_upconv3x3_dgrad_pack(const float* w, float* wp, int Co, int Ci, mg_stream_t stream) {
   MG_CHECK_ARG(w && wp && Co > 0 && Ci > 0, "mg_upconv3x3_dgrad_pack: bad arguments");
-  const int OPF = 16 * mg_cdiv(Ci, 16);
   const size_t total = mg_upconv3x3_dgrad_packed_floats(Ci, Co);
   hipLaunchKernelGGL(downconv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, wp,
-                     Co, Ci, OPF, total);
+                     Co, Ci, total);
   MG_CHECK_LAUNCH("mg_upconv3x3_dgrad_pack");
   return MG_OK;
 }

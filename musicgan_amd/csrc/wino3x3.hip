@@ -30,6 +30,7 @@
 #include <type_traits>
 
 #include "mg_common.h"
+#include "pack_kernels.h"
 
 namespace {
 
@@ -425,45 +426,14 @@ __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(co
   }
 }
 
-// U = G g G^T for every (out, in) channel pair, written in MFMA operand order:
+// U = G g G^T for every (out, in) channel pair, written in MFMA operand order (pack_kernels.h):
 //   up[(((ch*NT + ct)*8 + slot/2)*64 + lane)*4 + ks*2 + slot%2],   slot = 4*xi + {0, 2, 3, 1}[nu]  (pairs (nu0,nu3), (nu1,nu2):
 // the order in which the packed input transform produces them)
 // with  in-channel = ch*8 + 2*(lane>>4) + ks,  out-channel = ct*16 + (lane&15)
-__global__ void wino3x3_pack_kernel(const float* __restrict__ w, float* __restrict__ up, int Co, int Ci, int dgrad,
-                                    int cin_call, int cout_call, int NT, size_t total) {
+__global__ void wino3x3_pack_kernel(const float* __restrict__ w, float* __restrict__ up, int Co, int Ci, int dgrad, int NT,
+                                    size_t total) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
-  const int ks = (int)(e & 1);
-  const int lane = (int)((e >> 1) & 63);
-  const size_t r = e >> 7;
-  const int ct = (int)(r % NT);
-  const int ch = (int)(r / NT);
-  const int c = ch * WCC + 2 * (lane >> 4) + ks;
-  const int o = ct * 16 + (lane & 15);
-  float g[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t) g[t] = 0.f;
-  if (c < cin_call && o < cout_call) {
-    // dgrad=0: conv Ci->Co, g[t] = w[o][c][t];  dgrad=1: conv Co->Ci with the spatially flipped, transposed filter
-#pragma unroll
-    for (int t = 0; t < 9; ++t) g[t] = dgrad ? w[((size_t)c * Ci + o) * 9 + (8 - t)] : w[((size_t)o * Ci + c) * 9 + t];
-  }
-  float h[12];  // G g : 4x3
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const float g0 = g[j], g1 = g[3 + j], g2 = g[6 + j];
-    h[j] = g0;
-    h[3 + j] = 0.5f * ((g0 + g1) + g2);
-    h[6 + j] = 0.5f * ((g0 - g1) + g2);
-    h[9 + j] = g2;
-  }
-  float* dst = up + (((size_t)ch * NT + ct) * 8) * 256 + lane * 4 + ks * 2;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {  // (G g) G^T : row xi = i, columns nu0..nu3 -> pairs (nu0, nu3), (nu1, nu2)
-    const float h0 = h[3 * i], h1 = h[3 * i + 1], h2 = h[3 * i + 2];
-    *reinterpret_cast<float2*>(dst + (size_t)(2 * i) * 256) = make_float2(h0, h2);
-    *reinterpret_cast<float2*>(dst + (size_t)(2 * i + 1) * 256) = make_float2(0.5f * ((h0 + h1) + h2), 0.5f * ((h0 - h1) + h2));
-  }
+  if (e < total) pack_wino3x3_elem(e, w, up, Co, Ci, dgrad, NT);
 }
 
 template <int NIW, int WC, int WT>
@@ -480,11 +450,7 @@ int launch_wino(const WinoArgs& a, dim3 grid, hipStream_t s) {
   return MG_OK;
 }
 
-int wino_nt_padded(int Cout) {
-  const int nt = mg_cdiv(Cout, 16);
-  const int p4 = mg_cdiv(nt, 4) * 4, p3 = mg_cdiv(nt, 3) * 3;
-  return p4 > p3 ? p4 : p3;
-}
+int wino_nt_padded(int Cout) { return pack_wino_nt_padded(Cout); }
 
 }  // namespace
 
@@ -494,11 +460,10 @@ extern "C" size_t mg_wino3x3_packed_floats(int Cin, int Cout) {
 
 extern "C" int mg_wino3x3_pack(const float* w, float* up, int Co, int Ci, int dgrad, mg_stream_t stream) {
   MG_CHECK_ARG(w && up && Co > 0 && Ci > 0, "mg_wino3x3_pack: bad arguments");
-  const int cin_call = dgrad ? Co : Ci, cout_call = dgrad ? Ci : Co;
-  const int NT = wino_nt_padded(cout_call);
-  const size_t total = (size_t)mg_cdiv(cin_call, WCC) * NT * 128;  // one thread per (chunk, tile, lane, k-step)
+  const int NT = wino_nt_padded(dgrad ? Ci : Co);
+  const size_t total = pack_wino3x3_threads(Co, Ci, dgrad);  // one thread per (chunk, tile, lane, k-step)
   hipLaunchKernelGGL(wino3x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, up, Co,
-                     Ci, dgrad, cin_call, cout_call, NT, total);
+                     Ci, dgrad, NT, total);
   MG_CHECK_LAUNCH("mg_wino3x3_pack");
   return MG_OK;
 }

@@ -24,33 +24,46 @@ from typing import Dict, List, Optional
 
 import torch
 
-from .. import ops
+from .. import _lib, ops
 
 
 class PackCache:
-    """Packed (LDS-image) conv3x3 weights, refreshed when the parameter's storage or version changes."""
+    """Packed (LDS-image) conv3x3 weights.  A layout is packed when first asked for; afterwards its buffer is REFRESHED IN PLACE
+    whenever the parameter's storage or version has changed -- one by one on demand, or all stale ones of the cache in a single
+    launch through `refresh()` (the steppers call it at the top of every update: one launch instead of ~30 per network, and a
+    captured HIP graph of the update re-packs into the same buffers on every replay)."""
 
     def __init__(self):
-        self._c: Dict = {}
+        self._c: Dict = {}  # (id(w), kind, dgrad) -> [tag, packed, w]
+
+    @staticmethod
+    def _tag(w: torch.Tensor):
+        return (w.data_ptr(), w._version, w.device)
+
+    def _get(self, w: torch.Tensor, kind: int, dgrad: bool) -> torch.Tensor:
+        key = (id(w), kind, dgrad)
+        ent = self._c.get(key)
+        if ent is None:
+            out = torch.empty(ops.packed_floats(kind, w.shape[0], w.shape[1], dgrad), dtype=torch.float32, device=w.device)
+            ent = self._c[key] = [None, out, w]
+        if ent[0] != self._tag(w):
+            ops.pack_multi([(kind, w.detach(), dgrad, ent[1])])
+            ent[0] = self._tag(w)
+        return ent[1]
+
+    def refresh(self, force: bool = False) -> None:
+        """Re-pack every known layout whose weight has changed (`force`: all of them) in one launch."""
+        stale = [(key, ent) for key, ent in self._c.items() if force or ent[0] != self._tag(ent[2])]
+        ops.pack_multi([(key[1], ent[2].detach(), key[2], ent[1]) for key, ent in stale])
+        for _, ent in stale:
+            ent[0] = self._tag(ent[2])
 
     def get(self, w: torch.Tensor, dgrad: bool) -> torch.Tensor:
-        key = (id(w), dgrad)
-        tag = (w.data_ptr(), w._version, w.device)
-        ent = self._c.get(key)
-        if ent is None or ent[0] != tag:
-            ent = (tag, ops.pack_conv3x3(w.detach(), dgrad))
-            self._c[key] = ent
-        return ent[1]
+        return self._get(w, _lib.MG_PACK_CONV3X3, dgrad)
 
     def get_wino(self, w: torch.Tensor, dgrad: bool) -> torch.Tensor:
-        """Winograd-domain filters U = G g G^T (ops.pack_wino3x3)."""
-        key = (id(w), "wino", dgrad)
-        tag = (w.data_ptr(), w._version, w.device)
-        ent = self._c.get(key)
-        if ent is None or ent[0] != tag:
-            ent = (tag, ops.pack_wino3x3(w.detach(), dgrad))
-            self._c[key] = ent
-        return ent[1]
+        """Winograd-domain filters U = G g G^T."""
+        return self._get(w, _lib.MG_PACK_WINO3X3, dgrad)
 
     def conv(self, x: torch.Tensor, w: torch.Tensor, dgrad: bool, bias, cout: int, **kw):
         """ops.conv3x3 with the kernel chosen per shape: Winograd F(2x2,3x3) where it is supported and pays (large maps, no
@@ -79,23 +92,11 @@ class PackCache:
 
     def get_up(self, w: torch.Tensor) -> torch.Tensor:
         """Effective sub-pixel weights of Upsample(x2) -> Conv3x3 (ops.upconv3x3)."""
-        key = (id(w), "up")
-        tag = (w.data_ptr(), w._version, w.device)
-        ent = self._c.get(key)
-        if ent is None or ent[0] != tag:
-            ent = (tag, ops.pack_upconv3x3(w.detach()))
-            self._c[key] = ent
-        return ent[1]
+        return self._get(w, _lib.MG_PACK_UPCONV3X3, False)
 
     def get_up_dgrad(self, w: torch.Tensor) -> torch.Tensor:
         """4x4 stride-2 effective kernel of the upsample-conv data gradient (ops.upconv3x3_dgrad)."""
-        key = (id(w), "updg")
-        tag = (w.data_ptr(), w._version, w.device)
-        ent = self._c.get(key)
-        if ent is None or ent[0] != tag:
-            ent = (tag, ops.pack_upconv3x3_dgrad(w.detach()))
-            self._c[key] = ent
-        return ent[1]
+        return self._get(w, _lib.MG_PACK_UPCONV3X3_DGRAD, False)
 
     def clear(self):
         self._c.clear()
@@ -428,3 +429,20 @@ def disc_step_fused(W: DiscWeights, x_real: torch.Tensor, x_fake: torch.Tensor, 
     ops.linear1_bwd(flat[lo], W.clf[0], g_out[lo], gw=None, gb=gbc, need_gx=False, accumulate=acc)
     disc_loss = -(out[:n].mean() - out[n:2 * n].mean())
     return disc_loss, grad_pen, out
+
+
+# =====================================================================================================================
+# Generator step without autograd
+# =====================================================================================================================
+def gen_step_fused(Wg: GenWeights, Wd: DiscWeights, z: torch.Tensor, alpha: float, cache_g: PackCache, cache_d: PackCache,
+                   sink: GradSink):
+    """Gradient of  -mean D(G(z))  (criterion.py:17-18, train.py:191-213) w.r.t. every live generator parameter, written into
+    `sink`; returns (gen_loss, out_fake).  The critic's weight gradients are not evaluated (the reference computes and discards
+    them, train.py:209-214): its backward pass only carries the data gradient down to the generated images."""
+    n = z.shape[0]
+    x_fake, gctx = gen_forward(Wg, z.contiguous(), alpha, cache_g, save=True)
+    out, dctx = disc_forward(Wd, x_fake, alpha, cache_d, save=True)
+    g_out = torch.full((n, 1), -1.0 / n, dtype=torch.float32, device=z.device)
+    gx, _ = disc_backward(Wd, dctx, g_out, cache_d, None, need_gx=True)
+    gen_backward(Wg, gctx, gx, cache_g, sink)
+    return -out.mean(), out

@@ -68,6 +68,32 @@ def pack_wino3x3(w: torch.Tensor, dgrad: bool) -> torch.Tensor:
     return up
 
 
+def packed_floats(kind: int, co: int, ci: int, dgrad: bool) -> int:
+    """Size of the packed layout `kind` (_lib.MG_PACK_*) of a weight [co][ci][3][3]."""
+    lib = _lib.load()
+    cin_call, cout_call = (co, ci) if dgrad else (ci, co)
+    if kind == _lib.MG_PACK_CONV3X3:
+        return lib.mg_conv3x3_packed_floats(cin_call, cout_call)
+    if kind == _lib.MG_PACK_WINO3X3:
+        return lib.mg_wino3x3_packed_floats(cin_call, cout_call)
+    if kind == _lib.MG_PACK_UPCONV3X3:
+        return lib.mg_upconv3x3_packed_floats(ci, co)
+    return lib.mg_upconv3x3_dgrad_packed_floats(ci, co)
+
+
+def pack_multi(requests) -> None:
+    """requests: iterable of (kind, weight [co][ci][3][3], dgrad, out) -- every layout written in ONE launch (mg_pack_multi)."""
+    recs = []
+    for kind, w, dgrad, out in requests:
+        _chk(w, out)
+        assert out.numel() == packed_floats(kind, w.shape[0], w.shape[1], dgrad)
+        recs.append(_lib.PackDesc(w.data_ptr(), out.data_ptr(), kind, w.shape[0], w.shape[1], int(dgrad)))
+    if not recs:
+        return
+    arr = (_lib.PackDesc * len(recs))(*recs)
+    check(_lib.load().mg_pack_multi(ctypes.cast(arr, ctypes.c_void_p), len(recs), _s()), "mg_pack_multi")
+
+
 def wino3x3_supported(n: int, cout: int, h: int, w: int, *, ups=False, pixnorm=False, cin: int = 0) -> bool:
     """Whether conv3x3(..., wino=) may be used: even sizes, enough 2x2 tiles to fill the chip, for the fused PixelNorm all
     channels of a pixel inside one workgroup, and a tile block's input and output planes within the kernel's 32-bit offsets (the long

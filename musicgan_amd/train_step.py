@@ -7,12 +7,19 @@
     weight gradients, train.py:209-214);
   * no .item() host syncs: losses come back as device tensors.
 
+Single-process runs replay each update as a HIP graph: after two eager calls with the same (level, batch, alpha) the update --
+forward, backward, weight re-packing and the fused Adam with its device-side step counter -- is captured once and replayed, so
+the ~150 launches of an update cost the host one call (the small maps at the ends of both networks are otherwise launch-bound:
+15 us of Python + ctypes per launch against 5-20 us of GPU time).  During a fade-in alpha changes every iteration and the
+updates run eagerly.  `MG_GRAPHS=0` disables it.
+
 With torch.distributed initialised (one process per GPU, backend "nccl" = RCCL) the per-rank gradients are summed with one
 flat all-reduce per network on a side stream, the fused Adam runs behind it on that stream, and the main stream meanwhile
 runs the next forward pass that does not depend on the updated weights (G forward of the G step; D(x_real) of the next D step).
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -32,6 +39,8 @@ class ProGANStepper:
         self.rand_channels, self.h, self.w = rand_channels, height, width
         self.fused_d_step = fused_d_step
         self.dp = is_distributed()
+        self.use_graphs = (not self.dp) and fused_d_step and os.environ.get("MG_GRAPHS", "1") != "0"
+        self._graphs: Dict[tuple, dict] = {}
         self.bucket_d = GradBucket()
         self.bucket_g = GradBucket()
         if hasattr(optim_gen, "grad_scale"):
@@ -56,6 +65,10 @@ class ProGANStepper:
         if z is None:
             z = self._latent(n, x_real.device)
         if self.fused_d_step:
+            if eps is None:
+                eps = torch.rand(n, 1, 1, 1, device=x_real.device, generator=self.noise)
+            if self.use_graphs:
+                return self._graphed("D", (x_real, z, eps), alpha)
             return self._d_step_fused(x_real, alpha, z, eps)
         if self.dp:
             self.bucket_d.wait()  # D weights final (Adam of the previous D step)
@@ -92,6 +105,7 @@ class ProGANStepper:
             self.bucket_g.wait()
         xcat = torch.empty((3 * n,) + tuple(x_real.shape[1:]), dtype=torch.float32, device=dev)
         xcat[:n].copy_(x_real)
+        self._refresh_packs()
         with torch.no_grad():
             engine.gen_forward(self.gen._weights(), z.contiguous(), alpha, self.gen._pack_cache, save=False,
                                out=xcat[n:2 * n])
@@ -110,6 +124,10 @@ class ProGANStepper:
     def g_step(self, batch_size: int, alpha: float, device, z: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         if z is None:
             z = self._latent(batch_size, device)
+        if self.use_graphs:
+            return self._graphed("G", (z,), alpha)
+        if self.fused_d_step and not self.dp:
+            return self._g_step_fused(z, alpha)
         if self.dp:
             self.bucket_g.wait()
         x_fake = self.gen(z, alpha)  # overlaps D's gradient exchange + Adam on the side stream
@@ -129,6 +147,73 @@ class ProGANStepper:
                 p.requires_grad_(True)
         self._update(self.bucket_g, self.gen, self.optim_gen)
         return {"gen_loss": gen_loss.detach(), "out_fake_mean": out_fake.detach().mean()}
+
+    def _g_step_fused(self, z, alpha) -> Dict[str, torch.Tensor]:
+        """The generator update through `engine.gen_step_fused` (no autograd graph, no critic weight gradients)."""
+        from .networks import engine
+        self._refresh_packs()
+        with torch.no_grad():
+            Wg, Wd = self.gen._weights(), self.disc._weights()
+            sink = engine.GradSink()
+            gen_loss, out = engine.gen_step_fused(Wg, Wd, z, alpha, self.gen._pack_cache, self.disc._pack_cache, sink)
+        self.gen.zero_grad()
+        self.disc.zero_grad()
+        for p in Wg.tensors():
+            p.grad = sink.get(p)
+        self._update(self.bucket_g, self.gen, self.optim_gen)
+        return {"gen_loss": gen_loss, "out_fake_mean": out.mean()}
+
+    def _refresh_packs(self) -> None:
+        """Every packed weight layout either network has used so far, re-packed in one launch per network if its weight changed
+        (all of them while a graph is being captured: a replay must not depend on what was fresh at capture time)."""
+        force = torch.cuda.is_current_stream_capturing()
+        self.gen._pack_cache.refresh(force)
+        self.disc._pack_cache.refresh(force)
+
+    # ------------------------------------------------------------------ HIP-graph replay of whole updates
+    _WARM_CALLS = 2
+
+    def _graphed(self, kind: str, inputs, alpha: float) -> Dict[str, torch.Tensor]:
+        net, other = (self.disc, self.gen) if kind == "D" else (self.gen, self.disc)
+        key = (kind, self.gen.curr_layer, float(alpha), tuple(tuple(t.shape) for t in inputs),
+               tuple(id(p) for p in net.parameters()))
+        run = (lambda *a: self._d_step_fused(a[0], alpha, a[1], a[2])) if kind == "D" else (lambda *a: self._g_step_fused(a[0], alpha))
+        ent = self._graphs.get(key)
+        if ent is None:
+            if len(self._graphs) > 8:  # growth / new batch shapes: drop graphs (and their private memory pools) of the past
+                self._graphs.clear()
+            ent = self._graphs[key] = {"calls": 0}
+        if "graph" not in ent:
+            ent["calls"] += 1
+            if ent["calls"] <= self._WARM_CALLS:
+                return run(*inputs)
+            # capture: static copies of the inputs, every weight form re-packed inside the graph (caches emptied first), the
+            # gradients and the four scalars the caller reads live in the graph's pool
+            ent["inputs"] = [t.detach().clone().contiguous() for t in inputs]
+            net.zero_grad()
+            other.zero_grad()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                m = run(*ent["inputs"])
+                ent["names"] = list(m.keys())
+                ent["out"] = torch.stack([m[k].reshape(()) for k in ent["names"]])
+            ent["graph"] = graph
+            ent["grads"] = [(p, p.grad) for p in net.parameters() if p.grad is not None]
+            opt = self.optim_disc if kind == "D" else self.optim_gen
+            for p, _ in ent["grads"]:  # the captured optimizer step advanced the host mirrors, but nothing ran yet
+                opt.state[p]["step"] -= 1
+            # the captured run itself did not execute: fall through to the first replay with the caller's inputs
+        for dst, src in zip(ent["inputs"], inputs):
+            dst.copy_(src)
+        ent["graph"].replay()
+        self.gen.zero_grad()
+        self.disc.zero_grad()
+        for p, g in ent["grads"]:
+            p.grad = g
+        (self.optim_disc if kind == "D" else self.optim_gen).note_replay([p for p, _ in ent["grads"]])
+        out = ent["out"].clone()
+        return {k: out[i] for i, k in enumerate(ent["names"])}
 
     def finish(self) -> None:
         """Join the side streams (call before reading weights / checkpointing)."""

@@ -528,3 +528,28 @@ def test_input_transform_matches_reference_fixture():
     for level, side in ((0, 4), (3, 32), (5, 128)):
         y = ops.input_transform(big, side)
         assert float((y.cpu() - torch.from_numpy(g[f"scaled_l{level}"])).abs().max()) <= 3e-6, level
+
+
+def test_pack_multi_equals_single_tensor_packs():
+    """mg_pack_multi (all layouts of a list of weights in one launch) writes bit for bit what the four single-tensor pack entry points
+    write, for forward and data-gradient variants, odd channel counts and more records than one launch carries by value (64)."""
+    ops = _ops()
+    from musicgan_amd import _lib
+    g = torch.Generator().manual_seed(71)
+    reqs, refs = [], []
+    shapes = [(48, 64), (64, 48), (80, 96), (144, 160), (32, 8), (16, 16), (112, 128)]
+    for rep in range(4):
+        for co, ci in shapes:
+            w = torch.randn(co, ci, 3, 3, generator=g).to(DEV)
+            singles = [(_lib.MG_PACK_CONV3X3, False, ops.pack_conv3x3(w, False)), (_lib.MG_PACK_CONV3X3, True, ops.pack_conv3x3(w, True)),
+                       (_lib.MG_PACK_WINO3X3, False, ops.pack_wino3x3(w, False)), (_lib.MG_PACK_WINO3X3, True, ops.pack_wino3x3(w, True)),
+                       (_lib.MG_PACK_UPCONV3X3, False, ops.pack_upconv3x3(w)), (_lib.MG_PACK_UPCONV3X3_DGRAD, False, ops.pack_upconv3x3_dgrad(w))]
+            for kind, dgrad, ref in singles[rep::2]:
+                out = torch.full((ops.packed_floats(kind, co, ci, dgrad),), float("nan"), device=DEV)
+                assert out.numel() == ref.numel()
+                reqs.append((kind, w, dgrad, out))
+                refs.append(ref)
+    assert len(reqs) > 64
+    ops.pack_multi(reqs)
+    for (kind, w, dgrad, out), ref in zip(reqs, refs):
+        assert torch.equal(out, ref), (kind, tuple(w.shape), dgrad)

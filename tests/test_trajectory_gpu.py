@@ -103,10 +103,12 @@ def _sync_from_oracle(tr, gen, disc, og, od):
             p.data.copy_(src.to(torch.float32))
             torch.autograd.graph.increment_version(p)
             ast = opt_o.of(src)
-            if ast is not None:
-                opt_p.state[p] = {"step": torch.tensor(float(ast["step"])),
-                                  "exp_avg": ast["exp_avg"].to(torch.float32).to(DEV),
-                                  "exp_avg_sq": ast["exp_avg_sq"].to(torch.float32).to(DEV)}
+            if ast is not None:  # in place: a captured graph of the update holds the addresses of these tensors
+                pst = opt_p._init_state(p)
+                pst["step"].fill_(float(ast["step"]))
+                pst["step_dev"].fill_(int(ast["step"]))
+                pst["exp_avg"].copy_(ast["exp_avg"].to(torch.float32))
+                pst["exp_avg_sq"].copy_(ast["exp_avg_sq"].to(torch.float32))
 
 
 def test_training_loop_in_lock_step_with_fp64_oracle():
