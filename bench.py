@@ -88,7 +88,7 @@ def executed_flops_per_image(level: int, rand_channels: int, batch: int) -> floa
             f += 18.0 * ci * co * 4 * s * s * n * (W if sub else 1.0)
             if backward:
                 f += wgrad(n, ci, co, 2 * s, 2 * s, ups=True) + wgrad(n, ci, ci, s, s)
-                f += 18.0 * ci * co * 4 * s * s * n * (W if ops.upconv3x3_dgrad_supported(s, s, n * co * 4 * s * s) else 1.0)
+                f += 18.0 * ci * co * 4 * s * s * n * (W if ops.upconv3x3_dgrad_supported(s, s, n * co * 4 * s * s, n) else 1.0)
                 if i > 0:
                     f += conv(n, ci, ci, s, s)
             s *= 2

@@ -71,6 +71,42 @@ __global__ void __launch_bounds__(256) pixelnorm_fwd_k(const float* __restrict__
   }
 }
 
+// Small maps (the first generator blocks: 2x2 .. 16x16, 32-160 channels): one thread per pixel walking all channels twice is a
+// 2 x 160-deep chain of dependent-latency loads in 1-8 workgroups (33-54 us measured for 4-130 KB of data).  Here a workgroup
+// takes 64 pixels (lane = pixel: coalesced), its 4 waves split the channels and keep their values in registers (<= 40 each),
+// the partial sums of squares meet in LDS, and each wave scales and writes what it holds: one pass, 4x the threads, no chain.
+constexpr int PN_SMALL_MAXC = 160;
+__global__ void __launch_bounds__(256) pixelnorm_fwd_small_k(const float* __restrict__ y, float* __restrict__ p,
+                                                             float* __restrict__ rn, int N, int C, int HW) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t i = (size_t)blockIdx.x * 64 + lane;
+  const bool ok = i < (size_t)N * HW;
+  const int n = ok ? (int)(i / HW) : 0;
+  const int px = ok ? (int)(i - (size_t)n * HW) : 0;
+  const float* yp = y + (size_t)n * C * HW + px;
+  float v[PN_SMALL_MAXC / 4];
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < PN_SMALL_MAXC / 4; ++k) {
+    const int c = wave + 4 * k;
+    v[k] = (ok && c < C) ? yp[(size_t)c * HW] : 0.f;
+    ss = fmaf(v[k], v[k], ss);
+  }
+  part[wave][lane] = ss;
+  __syncthreads();
+  const float r = 1.0f / sqrtf((((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]) / (float)C + PN_EPS);
+  if (ok) {
+    if (rn && wave == 0) rn[(size_t)n * HW + px] = r;
+    float* pp = p + (size_t)n * C * HW + px;
+#pragma unroll
+    for (int k = 0; k < PN_SMALL_MAXC / 4; ++k) {
+      const int c = wave + 4 * k;
+      if (c < C) pp[(size_t)c * HW] = v[k] * r;
+    }
+  }
+}
+
 // Backward through PixelNorm and the LeakyReLU in front of it.  from_p == 0: `y` is the post-LeakyReLU activation, p = y*rn.
 // from_p != 0: `y` IS the normalised output p (the pre-norm activation is never stored: sign(p) == sign(y) since rn > 0).
 template <int V>
@@ -470,7 +506,9 @@ __global__ void __launch_bounds__(64) adam_tick_k(const AdamDevChunk desc, int n
 
 extern "C" int mg_pixelnorm_fwd(const float* y, float* p, float* rn, int N, int C, int HW, mg_stream_t stream) {
   MG_CHECK_ARG(y && p && N > 0 && C > 0 && HW > 0, "mg_pixelnorm_fwd: bad arguments");
-  if ((HW & 3) == 0) EW_LAUNCH(pixelnorm_fwd_k<4>, ew_grid((size_t)N * HW / 4), 256, y, p, rn, N, C, HW);
+  if ((size_t)N * HW <= (1u << 17) && C <= PN_SMALL_MAXC)
+    EW_LAUNCH(pixelnorm_fwd_small_k, (unsigned)(((size_t)N * HW + 63) / 64), 256, y, p, rn, N, C, HW);
+  else if ((HW & 3) == 0) EW_LAUNCH(pixelnorm_fwd_k<4>, ew_grid((size_t)N * HW / 4), 256, y, p, rn, N, C, HW);
   else EW_LAUNCH(pixelnorm_fwd_k<1>, ew_grid((size_t)N * HW), 256, y, p, rn, N, C, HW);
   MG_CHECK_LAUNCH("mg_pixelnorm_fwd");
   return MG_OK;

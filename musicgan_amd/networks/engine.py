@@ -186,7 +186,7 @@ def gen_backward(W: GenWeights, ctx, g_out: torch.Tensor, cache: PackCache, sink
         gw2, acc = sink.slot(w2)
         gb2, _ = sink.slot(b2)
         ops.conv3x3_wgrad(p1, gpre2, gw2, gb2, ups=True, accumulate=acc)
-        if ops.upconv3x3_dgrad_supported(p1.shape[2], p1.shape[3], gpre2.numel()):
+        if ops.upconv3x3_dgrad_supported(p1.shape[2], p1.shape[3], gpre2.numel(), p1.shape[0]):
             gp1 = ops.upconv3x3_dgrad(gpre2, cache.get_up_dgrad(w2), ci)  # stride-2 4x4 form: no high-res intermediate
         else:
             gp1 = ops.upsample2x_bwd(cache.conv(gpre2, w2, True, None, ci))

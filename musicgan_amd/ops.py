@@ -184,13 +184,17 @@ def pack_upconv3x3_dgrad(w: torch.Tensor) -> torch.Tensor:
     return wp
 
 
-def upconv3x3_dgrad_supported(hin: int, win: int, gy_numel: int = 0) -> bool:
+def upconv3x3_dgrad_supported(hin: int, win: int, gy_numel: int = 0, n: int = 0) -> bool:
     """Mirrors the tile choice of mg_upconv3x3_dgrad: 128 low-res pixels per workgroup, the high-res halo tile of one
     8-channel chunk must fit the 24-register prefetch (images below 8x8 do not; they take the plain dgrad + block-sum path).
     `gy_numel` (elements of the output gradient): the kernel indexes with 31 bits -- larger tensors take that path too."""
     if os.environ.get("MG_UPCONV_DGRAD", "1") == "0":  # A/B switch for measurements
         return False
     if gy_numel >= (1 << 31):
+        return False
+    if n and n * hin * win < int(os.environ.get("MG_UPCONV_DGRAD_MIN_PIXELS", "16384")):
+        # 128 low-res pixels per workgroup: fewer than ~128 workgroups leave most of the chip idle behind one long K loop (16 / 64
+        # workgroups: 114 / 84 us at level 4); the plain data gradient + 2x2 block sum is sliced over out-channels and faster there
         return False
     p2 = lambda v: 1 << max(0, (v - 1).bit_length())
     tw = min(32, p2(win))

@@ -418,9 +418,9 @@ def test_full_size_step_is_algorithm_independent(monkeypatch, level, batch):
         gmax = max(float(v.abs().max()) for k, v in gb.items() if k.startswith(net))
         for k in gb:
             if k.startswith(net):
-                # per tensor: 2e-4 of its own max-norm, or (cancellation residues, see grad_atol) 2e-5 of the network's scale
-                # or of the tensor's un-cancelled term
-                tol = max(2e-4 * float(gb[k].abs().max()), 2e-5 * gmax)
+                # per tensor: 1e-3 of its own max-norm (the SURVEY 8(c) gradient gate: two fp32 algorithms each within it of fp64),
+                # or (cancellation residues, see grad_atol) 2e-5 of the network's scale or of the tensor's un-cancelled term
+                tol = max(1e-3 * float(gb[k].abs().max()), 2e-5 * gmax)
                 if k in terms["direct"]:
                     tol = max(tol, 2e-5 * float(terms["direct"][k].abs().max()))
                 assert maxabs_err(ga[k], gb[k]) <= tol, f"{k}: {maxabs_err(ga[k], gb[k]):.3e} > {tol:.3e}"
