@@ -3,7 +3,7 @@ waveform-level helpers the drivers use (`stft_from_waveform`, `magn_phase_to_wav
 from . import constant as _constant
 from . import functions as _functions
 from .constant import N_FFT, N_VEC, SAMPLE_RATE, STFT_STRIDE
-from .dataset import AudioDataset
+from .dataset import AudioDataset, PackedAudioDataset, PackedLoader, has_packed, write_packed
 from .transforms import ChangeRange, ChannelMinMaxNorm
 
 for _name in ("wav_to_stft", "stft_to_phase_magn", "magn_phase_to_wav", "bark_magn_scale", "stft_from_waveform",
@@ -12,4 +12,4 @@ for _name in ("wav_to_stft", "stft_to_phase_magn", "magn_phase_to_wav", "bark_ma
 del _name
 
 __all__ = ["wav_to_stft", "stft_to_phase_magn", "magn_phase_to_wav", "bark_magn_scale", "stft_from_waveform",
-           "magn_phase_to_waveform", "AudioDataset", "ChannelMinMaxNorm", "ChangeRange", *_constant.__all__]
+           "magn_phase_to_waveform", "AudioDataset", "PackedAudioDataset", "PackedLoader", "has_packed", "write_packed", "ChannelMinMaxNorm", "ChangeRange", *_constant.__all__]

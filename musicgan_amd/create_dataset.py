@@ -18,7 +18,9 @@ def _nb_samples(nb_frames_wav: int, nb_vec: int) -> int:
     return 0 if t < nb_vec else (t - 1) // nb_vec
 
 
-def create_dataset(audio_path: str, dataset_output_dir: str) -> None:
+def create_dataset(audio_path: str, dataset_output_dir: str, *, packed: bool = True) -> None:
+    """`packed` (extension, single-process runs): also write the float32 memory-mapped side-car the fast loader reads
+    (audio/dataset.py); the reference-format `magn_phase_{idx}.pt` files are written either way."""
     w_p = glob.glob(audio_path)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if not exists(dataset_output_dir):
@@ -46,3 +48,5 @@ def create_dataset(audio_path: str, dataset_output_dir: str) -> None:
         for s_idx in range(both.size()[0]):
             th.save(both[s_idx].clone(), join(dataset_output_dir, f"magn_phase_{idx}.pt"))
             idx += 1
+    if packed and world == 1:
+        audio.write_packed(dataset_output_dir)

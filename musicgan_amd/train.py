@@ -107,7 +107,8 @@ def _latest_state(resume_from: str) -> str:
 
 def train(run_name: str, input_dataset_path: str, output_dir: str, *, nb_epoch: int = 1000, batch_size: int = 6,
           num_workers: int = 6, metric_every: int = 20, max_iters: int = 0, save_every: int = 1000,
-          resume_from: str = None, fadein_lengths=None, train_lengths=None, rand_channels: int = 32) -> None:
+          resume_from: str = None, fadein_lengths=None, train_lengths=None, rand_channels: int = 32,
+          use_packed_loader: bool = True) -> None:
     """Reference signature plus keyword-only extensions (all defaulting to the reference's literals).  `resume_from`: a
     directory written by a previous run; its newest `train_state_k.pt` / `gen_k.pt` / `disc_k.pt` / `optim_*_k.pt` set is
     loaded (growth level, Grower counters, weights, Adam state, noise stream, position in the epoch, checkpoint numbering), after
@@ -177,10 +178,16 @@ def train(run_name: str, input_dataset_path: str, output_dir: str, *, nb_epoch: 
         noise.set_state(resume_state["noise_rng"][rank])
     stepper = ProGANStepper(gen, disc, optim_gen, optim_disc, rand_channels, height, width, noise=noise)
 
-    audio_dataset = audio.AudioDataset(input_dataset_path)
+    # the float32 memory-mapped side-car when the dataset has one (one gather + one asynchronous upload per batch on a background
+    # thread), the reference's per-sample th.load through DataLoader workers otherwise; same samples in the same order either way
+    use_packed = use_packed_loader and audio.has_packed(input_dataset_path)
+    audio_dataset = audio.PackedAudioDataset(input_dataset_path) if use_packed else audio.AudioDataset(input_dataset_path)
     sampler = ShardedShuffle(len(audio_dataset), base_seed, rank, world)
-    data_loader = DataLoader(audio_dataset, batch_size=batch_size, sampler=sampler, num_workers=num_workers,
-                             drop_last=True, pin_memory=True)
+    if use_packed:
+        data_loader = audio.PackedLoader(audio_dataset, batch_size, sampler, device)
+    else:
+        data_loader = DataLoader(audio_dataset, batch_size=batch_size, sampler=sampler, num_workers=num_workers,
+                                 drop_last=True, pin_memory=True)
 
     if mlflow is not None and rank == 0:
         mlflow.log_params({"input_dataset": input_dataset_path, "nb_sample": len(audio_dataset),

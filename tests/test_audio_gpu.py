@@ -91,8 +91,9 @@ def test_drivers_end_to_end_tiny_corpus(tmp_path):
         wavio.save(str(wav_dir / f"s{i}.wav"), torch.rand(2, 256 * 1030, generator=rng) - 0.5, 44100)
     wavio.save(str(wav_dir / "short.wav"), torch.rand(1, 256 * 100, generator=rng) - 0.5, 44100)  # < 512 frames: skipped
     musicgan_amd.create_dataset(str(wav_dir / "*.wav"), str(data_dir))
-    files = sorted(os.listdir(data_dir))
-    assert files == [f"magn_phase_{i}.pt" for i in range(4)]  # 2 files x 2 samples
+    assert sorted(os.listdir(data_dir)) == sorted([f"magn_phase_{i}.pt" for i in range(4)] +  # 2 files x 2 samples
+                                                  ["magn_phase_f32.bin", "magn_phase_f32.json"])  # + the loader's side-car
+    files = sorted(f for f in os.listdir(data_dir) if f.endswith(".pt"))
     sample = torch.load(str(data_dir / files[0]))
     assert sample.dtype == torch.float64 and tuple(sample.shape) == (2, 512, 512)
     assert float(sample.min()) >= -1.0 and float(sample.max()) <= 1.0
@@ -131,7 +132,7 @@ def _tiny_dataset(tmp_path, n=6):
     data.mkdir()
     rng = torch.Generator().manual_seed(17)
     for i in range(n):
-        x = torch.rand(2, 512, 512, generator=rng, dtype=torch.float64) * 2 - 1
+        x = (torch.rand(2, 512, 512, generator=rng) * 2 - 1).double()  # float32 values widened, as create_dataset stores them
         torch.save(x, str(data / f"magn_phase_{i}.pt"))
     return data
 
@@ -251,9 +252,46 @@ def test_create_dataset_sharded_equals_single_process(tmp_path, monkeypatch):
         monkeypatch.setenv("LOCAL_RANK", "0")
         musicgan_amd.create_dataset(str(wav_dir / "*.wav"), str(sharded))
         if rank == 1:
-            part = sorted(os.listdir(sharded))
+            part = sorted(f for f in os.listdir(sharded) if f.endswith(".pt"))
             assert 0 < len(part) < 7  # rank 1 alone wrote only its files' samples
-    names = sorted(os.listdir(single))
-    assert names == sorted(os.listdir(sharded)) == sorted(f"magn_phase_{i}.pt" for i in range(7))
+    pts = lambda d: sorted(f for f in os.listdir(d) if f.endswith(".pt"))  # (the single-process run also wrote the side-car)
+    names = pts(single)
+    assert names == pts(sharded) == sorted(f"magn_phase_{i}.pt" for i in range(7))
     for n in names:
         assert torch.equal(torch.load(str(single / n)), torch.load(str(sharded / n))), n
+
+
+def test_packed_loader_serves_the_same_batches_and_the_same_training_run(tmp_path):
+    """SURVEY 8(f) rank 1, second half (audio/dataset.py:14-44 + train.py:77-84,139): the float32 memory-mapped side-car and its
+    double-buffered loader deliver exactly the samples `AudioDataset` + DataLoader deliver, in the same order, and a training run
+    fed by it ends in bit-identical checkpoints."""
+    from musicgan_amd import audio
+    from musicgan_amd.train import ShardedShuffle, train
+    data = _tiny_dataset(tmp_path, n=7)
+    assert not audio.has_packed(str(data))
+    assert audio.write_packed(str(data)) == 7 and audio.has_packed(str(data))
+    ref_ds, ds = audio.AudioDataset(str(data)), audio.PackedAudioDataset(str(data))
+    assert len(ds) == len(ref_ds) == 7
+    for i in (0, 3, 6):
+        assert ds[i].dtype == torch.float32 and torch.equal(ds[i].double(), ref_ds[i])
+    sampler = ShardedShuffle(7, seed=5)
+    sampler.set_epoch(2)
+    order = list(iter(sampler))
+    batches = [b.clone() for b in audio.PackedLoader(ds, 2, sampler, DEV)]
+    assert len(batches) == 3  # drop_last
+    for k, b in enumerate(batches):
+        assert b.is_cuda and b.dtype == torch.float32
+        want = torch.stack([ref_ds[i] for i in order[2 * k:2 * k + 2]])
+        assert torch.equal(b.cpu().double(), want)
+    # a sample file added behind the side-car's back invalidates it (the loader must never serve a stale index)
+    torch.save(ref_ds[0], str(data / "magn_phase_7.pt"))
+    assert not audio.has_packed(str(data))
+    os.remove(str(data / "magn_phase_7.pt"))
+    kw = dict(nb_epoch=4, batch_size=2, num_workers=0, save_every=5, rand_channels=8, max_iters=5)
+    torch.manual_seed(321)
+    train("p", str(data), str(tmp_path / "packed"), **kw)
+    torch.manual_seed(321)
+    train("r", str(data), str(tmp_path / "plain"), use_packed_loader=False, **kw)
+    for f in ("gen_0.pt", "disc_0.pt"):
+        a, b = torch.load(str(tmp_path / "packed" / f)), torch.load(str(tmp_path / "plain" / f))
+        assert all(torch.equal(a[k], b[k]) for k in a), f
