@@ -40,6 +40,7 @@ struct ConvArgs {
   int OPF;  // row stride of the packed weights (floats) = 16*ceil(Cout/16)
   int nchunk;
   int sub;  // 8-channel chunks per barrier interval (1 or 4)
+  int ksplit;  // 4: the workgroup's waves split those chunks over one shared 16-pixel tile (small maps)
 };
 
 // PF: software-pipelined variant -- the next chunk's global loads are issued into registers right after the barrier that
@@ -50,8 +51,13 @@ constexpr int PF_NIN = 12;  // halo positions per thread held in flight (covers 
 // SUB: 8-channel chunks staged and consumed per barrier interval.  The small maps at the ends of both networks (<= 8x8, 112-160
 // channels) are latency-bound -- 14-20 chunks of 18 MFMAs, each behind two barriers and a global-load round trip -- so their
 // variants take 4 chunks at a time.
-template <int NI, int MI, bool PF, int SUB = 1>
+// KS = 4 (split-K, with SUB = 4): the four waves share ONE 16*MI-pixel tile and each consumes one of the four chunks of a barrier
+// interval; their partial accumulators meet in LDS and wave 0 runs the epilogue.  On <= 8x8 maps a launch is a chain of Cin/8
+// chunk phases that no width shortens (4 us + 0.113 us per input channel whatever Cout and batch, tools/bench_smallconv.py: every
+// MFMA of the 16x16 tile waits for its own two LDS operands); split four ways the chain is a quarter as long.
+template <int NI, int MI, bool PF, int SUB = 1, int KS = 1>
 __global__ void __launch_bounds__(256) conv3x3_mfma(const ConvArgs a) {
+  static_assert(KS == 1 || (KS == 4 && SUB == 4 && MI == 1), "split-K variant: 4 waves x 4 chunks per interval");
   constexpr int OPL = (NI & 1) ? NI * 16 : NI * 16 + 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int* tab = reinterpret_cast<int*>(smem);
@@ -88,7 +94,7 @@ __global__ void __launch_bounds__(256) conv3x3_mfma(const ConvArgs a) {
   int pix_off[MI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
-    const int p = (wave * MI + mi) * 16 + col;
+    const int p = ((KS > 1 ? 0 : wave) * MI + mi) * 16 + col;
     const int c = p & (a.TW - 1);
     const int r = (p >> a.lgTW) & (a.TH - 1);
     const int n_l = p >> (a.lgTW + a.lgTH);
@@ -111,6 +117,7 @@ __global__ void __launch_bounds__(256) conv3x3_mfma(const ConvArgs a) {
 #pragma unroll
     for (int sub = 0; sub < SUB; ++sub) {
       if (SUB > 1 && ch * SUB + sub >= a.nchunk) break;
+      if (KS > 1 && sub != wave) continue;
       const float* in_s = in_t + sub * CC * a.ch_stride;
       const float* w_s = w_t + sub * 9 * CC * OPL;
 #pragma unroll
@@ -224,6 +231,25 @@ __global__ void __launch_bounds__(256) conv3x3_mfma(const ConvArgs a) {
       __syncthreads();
       compute_chunk(ch);
     }
+  }
+
+  if constexpr (KS > 1) {  // partial sums of waves 1..3 -> LDS (over the staging area), summed by wave 0 in a fixed order
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(in_t);
+    if (wave > 0) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) red[(((wave - 1) * MI + mi) * NI + ni) * 64 + lane] = acc[mi][ni];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        acc[mi][ni] = ((acc[mi][ni] + red[((0 * MI + mi) * NI + ni) * 64 + lane]) + red[((1 * MI + mi) * NI + ni) * 64 + lane]) +
+                      red[((2 * MI + mi) * NI + ni) * 64 + lane];
   }
 
   // ---------------------------------------------------------------- epilogue
@@ -394,14 +420,14 @@ __global__ void conv3x3_pack_kernel(const float* __restrict__ w, float* __restri
   if (e < total) pack_conv3x3_elem(e, w, wp, Co, Ci, dgrad);
 }
 
-template <int NI, int MI, bool PF, int SUB = 1>
+template <int NI, int MI, bool PF, int SUB = 1, int KS = 1>
 int launch_conv_pf(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   static MgPerDevice once;  // the LDS limit is a per-device function attribute
   if (mg_first_use_on_device(once)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma<NI, MI, PF, SUB>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma<NI, MI, PF, SUB, KS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  hipLaunchKernelGGL((conv3x3_mfma<NI, MI, PF, SUB>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv3x3_mfma<NI, MI, PF, SUB, KS>), grid, dim3(256), lds, s, a);
   MG_CHECK_LAUNCH("mg_conv3x3");
   return MG_OK;
 }
@@ -418,8 +444,10 @@ bool pf_enabled() {
 template <int NI, int MI>
 int launch_conv(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   // small maps with many channels: 4 chunks per barrier interval (the host sized `lds` for it)
-  if constexpr (MI == 1 && NI <= 2)
+  if constexpr (MI == 1 && NI <= 2) {
+    if (a.sub == 4 && a.ksplit == 4) return launch_conv_pf<NI, MI, true, 4, 4>(a, grid, lds, s);
     if (a.sub == 4) return launch_conv_pf<NI, MI, true, 4>(a, grid, lds, s);
+  }
   // the pipelined variant needs the halo tile to fit its in-flight registers and more than one chunk to overlap
   if (pf_enabled() && a.plane <= 32 * PF_NIN && a.nchunk > 1) return launch_conv_pf<NI, MI, true>(a, grid, lds, s);
   return launch_conv_pf<NI, MI, false>(a, grid, lds, s);
@@ -507,7 +535,12 @@ extern "C" int mg_conv3x3(const float* x, const float* wp, const float* bias, co
     else if (nwg <= 256 && (NIfull % 2 == 0)) NI = 2;
     if (NI > NIfull) NI = NIfull;
   }
-  const int P = 64 * MI;
+  // the smallest maps, long K: split-K variant -- 16 pixels per workgroup, its 4 waves share them and split each interval's 4
+  // chunks.  Measured (tools/bench_smallconv.py, Cin 128): 96 x 2x2 21.9 -> 13.4 us, 32 x 4x4 18.4 -> 12.9, 96 x 4x4 18.5 -> 16.4; at
+  // 96 x 8x8 the 4x larger grid re-stages the weights 4x as often and loses (27.7 -> 58 us), hence the pixel bound.
+  a.ksplit = (MI == 1 && NI <= 2 && !pn && H * W <= 64 && px <= 1536 && a.nchunk >= 8 && pf_enabled() &&
+              getenv("MG_CONV_NOSUB") == nullptr && getenv("MG_CONV_NOKSPLIT") == nullptr) ? 4 : 1;
+  const int P = a.ksplit == 4 ? 16 : 64 * MI;
   a.TW = mg_pow2_ceil(W) < 32 ? mg_pow2_ceil(W) : 32;
   if (a.TW > P) a.TW = P;
   a.TH = mg_pow2_ceil(H) < P / a.TW ? mg_pow2_ceil(H) : P / a.TW;
@@ -522,6 +555,7 @@ extern "C" int mg_conv3x3(const float* x, const float* wp, const float* bias, co
   const int OPL = (NI & 1) ? NI * 16 : NI * 16 + 16;
   a.sub = 1;
   if (MI == 1 && NI <= 2 && pf_enabled() && a.plane <= 256 && a.nchunk >= 8 && getenv("MG_CONV_NOSUB") == nullptr) a.sub = 4;
+  MG_CHECK_ARG(a.ksplit == 1 || a.sub == 4, "mg_conv3x3: internal error (split-K without 4-chunk intervals)");
   const size_t lds = (size_t)(a.tab_floats + a.sub * (CC * a.ch_stride + 9 * CC * OPL)) * sizeof(float);
   MG_CHECK_ARG(lds <= 160 * 1024, "mg_conv3x3: LDS tile %zu B too large", lds);
   dim3 grid(a.tiles_x * a.tiles_y * a.tiles_n, NIfull / NI);
