@@ -138,6 +138,13 @@ int mg_axpby(float a, const float* x, float b, const float* y, float* out, size_
 /* out[n,c,h,w] = a*x[n,c,h,w] + b*up2(y)[n,c,h,w], y is (NC, H/2, W/2) */
 int mg_blend_up(float a, const float* x, float b, const float* y, float* out, int NC, int H, int W,
                 mg_stream_t stream);
+/* The three fade-in kernels with their coefficients (a, b) = coef[0], coef[1] read from DEVICE memory (y == NULL: coef[0] only):
+ * alpha changes every iteration of a fade-in (utils.py:62-68); as launch arguments it would be baked into a captured HIP graph
+ * of the update.  Same values, same results as the scalar forms. */
+int mg_axpby_dev(const float* coef, const float* x, const float* y, float* out, size_t n, mg_stream_t stream);
+int mg_blend_up_dev(const float* coef, const float* x, const float* y, float* out, int NC, int H, int W, mg_stream_t stream);
+int mg_blend_lrelu_bwd_dev(const float* g, const float* act_a, const float* act_o, const float* coef, float* out_a, float* out_o,
+                           size_t n, float slope, mg_stream_t stream);
 /* Linear(K -> 1) [discriminator.py:103-105]: y[n] = b + sum_k w[k] x[n,k] */
 int mg_linear1_fwd(const float* x, const float* w, const float* b, float* y, int N, int K, mg_stream_t stream);
 /* gx[n,k] = gy[n]*w[k]; gw[k] (+)= sum_n gy[n] x[n,k]; gb (+)= sum_n gy[n]   (gx/gw/gb may be NULL) */

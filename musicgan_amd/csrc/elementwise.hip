@@ -248,9 +248,12 @@ __global__ void __launch_bounds__(256) avgpool2_bwd_k(const float* __restrict__ 
   }
 }
 
+// `coef` (optional, all three fade-in kernels): the two coefficients in DEVICE memory instead of launch arguments, so that a
+// captured HIP graph of an update stays valid while alpha moves through the fade-in (the values, hence the results, are the same)
 __global__ void __launch_bounds__(256) blend_up_k(float a, const float* __restrict__ x, float b,
                                                   const float* __restrict__ ylow, float* __restrict__ out, size_t total,
-                                                  int Ho, int Wo) {
+                                                  int Ho, int Wo, const float* __restrict__ coef) {
+  if (coef) { a = coef[0]; b = coef[1]; }
   // one thread per LOW-res element: out 2x2 block = a*x + b*ylow
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int w = (int)(i % Wo);
@@ -285,7 +288,8 @@ template <int V>
 __global__ void __launch_bounds__(256) blend_lrelu_bwd_k(const float* __restrict__ g, const float* __restrict__ act_a,
                                                          const float* __restrict__ act_o, float ca, float co,
                                                          float* __restrict__ out_a, float* __restrict__ out_o, size_t nq,
-                                                         float slope) {
+                                                         float slope, const float* __restrict__ coef) {
+  if (coef) { ca = coef[0]; co = coef[1]; }
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (size_t)gridDim.x * blockDim.x) {
     float gv[V], a[V], o[V];
     ld<V>(g + i * V, gv);
@@ -303,7 +307,9 @@ __global__ void __launch_bounds__(256) blend_lrelu_bwd_k(const float* __restrict
 
 template <int V>
 __global__ void __launch_bounds__(256) axpby_k(float a, const float* __restrict__ x, float b,
-                                               const float* __restrict__ y, float* __restrict__ out, size_t nq) {
+                                               const float* __restrict__ y, float* __restrict__ out, size_t nq,
+                                               const float* __restrict__ coef) {
+  if (coef) { a = coef[0]; if (y) b = coef[1]; }
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (size_t)gridDim.x * blockDim.x) {
     float xv[V], yv[V];
     ld<V>(x + i * V, xv);
@@ -576,13 +582,22 @@ extern "C" int mg_avgpool2_bwd(const float* gy, const float* act, float* gx, int
   return MG_OK;
 }
 
-extern "C" int mg_blend_up(float a, const float* x, float b, const float* y, float* out, int NC, int H, int W,
-                           mg_stream_t stream) {
+static int blend_up_impl(float a, const float* x, float b, const float* y, float* out, int NC, int H, int W, const float* coef,
+                         mg_stream_t stream) {
   MG_CHECK_ARG(x && y && out && NC > 0 && H > 0 && W > 0 && (H % 2 == 0) && (W % 2 == 0), "mg_blend_up: bad arguments");
   const size_t total = (size_t)NC * (H / 2) * (W / 2);
-  EW_LAUNCH(blend_up_k, ew_grid(total), 256, a, x, b, y, out, total, H / 2, W / 2);
+  EW_LAUNCH(blend_up_k, ew_grid(total), 256, a, x, b, y, out, total, H / 2, W / 2, coef);
   MG_CHECK_LAUNCH("mg_blend_up");
   return MG_OK;
+}
+extern "C" int mg_blend_up(float a, const float* x, float b, const float* y, float* out, int NC, int H, int W,
+                           mg_stream_t stream) {
+  return blend_up_impl(a, x, b, y, out, NC, H, W, nullptr, stream);
+}
+extern "C" int mg_blend_up_dev(const float* coef, const float* x, const float* y, float* out, int NC, int H, int W,
+                               mg_stream_t stream) {
+  MG_CHECK_ARG(coef, "mg_blend_up_dev: coef is NULL");
+  return blend_up_impl(0.f, x, 0.f, y, out, NC, H, W, coef, stream);
 }
 
 extern "C" int mg_lrelu_bwd(const float* g, const float* act, float* out, size_t n, float slope, mg_stream_t stream) {
@@ -593,21 +608,39 @@ extern "C" int mg_lrelu_bwd(const float* g, const float* act, float* out, size_t
   return MG_OK;
 }
 
-extern "C" int mg_blend_lrelu_bwd(const float* g, const float* act_a, const float* act_o, float ca, float co, float* out_a,
-                                  float* out_o, size_t n, float slope, mg_stream_t stream) {
+static int blend_lrelu_bwd_impl(const float* g, const float* act_a, const float* act_o, float ca, float co, float* out_a,
+                                float* out_o, size_t n, float slope, const float* coef, mg_stream_t stream) {
   MG_CHECK_ARG(g && act_a && act_o && out_a && out_o && n > 0, "mg_blend_lrelu_bwd: bad arguments");
-  if ((n & 3) == 0) EW_LAUNCH(blend_lrelu_bwd_k<4>, ew_grid(n / 4), 256, g, act_a, act_o, ca, co, out_a, out_o, n / 4, slope);
-  else EW_LAUNCH(blend_lrelu_bwd_k<1>, ew_grid(n), 256, g, act_a, act_o, ca, co, out_a, out_o, n, slope);
+  if ((n & 3) == 0)
+    EW_LAUNCH(blend_lrelu_bwd_k<4>, ew_grid(n / 4), 256, g, act_a, act_o, ca, co, out_a, out_o, n / 4, slope, coef);
+  else EW_LAUNCH(blend_lrelu_bwd_k<1>, ew_grid(n), 256, g, act_a, act_o, ca, co, out_a, out_o, n, slope, coef);
   MG_CHECK_LAUNCH("mg_blend_lrelu_bwd");
   return MG_OK;
 }
+extern "C" int mg_blend_lrelu_bwd(const float* g, const float* act_a, const float* act_o, float ca, float co, float* out_a,
+                                  float* out_o, size_t n, float slope, mg_stream_t stream) {
+  return blend_lrelu_bwd_impl(g, act_a, act_o, ca, co, out_a, out_o, n, slope, nullptr, stream);
+}
+extern "C" int mg_blend_lrelu_bwd_dev(const float* g, const float* act_a, const float* act_o, const float* coef, float* out_a,
+                                      float* out_o, size_t n, float slope, mg_stream_t stream) {
+  MG_CHECK_ARG(coef, "mg_blend_lrelu_bwd_dev: coef is NULL");
+  return blend_lrelu_bwd_impl(g, act_a, act_o, 0.f, 0.f, out_a, out_o, n, slope, coef, stream);
+}
 
-extern "C" int mg_axpby(float a, const float* x, float b, const float* y, float* out, size_t n, mg_stream_t stream) {
+static int axpby_impl(float a, const float* x, float b, const float* y, float* out, size_t n, const float* coef,
+                      mg_stream_t stream) {
   MG_CHECK_ARG(x && out && n > 0, "mg_axpby: bad arguments");
-  if ((n & 3) == 0) EW_LAUNCH(axpby_k<4>, ew_grid(n / 4), 256, a, x, b, y, out, n / 4);
-  else EW_LAUNCH(axpby_k<1>, ew_grid(n), 256, a, x, b, y, out, n);
+  if ((n & 3) == 0) EW_LAUNCH(axpby_k<4>, ew_grid(n / 4), 256, a, x, b, y, out, n / 4, coef);
+  else EW_LAUNCH(axpby_k<1>, ew_grid(n), 256, a, x, b, y, out, n, coef);
   MG_CHECK_LAUNCH("mg_axpby");
   return MG_OK;
+}
+extern "C" int mg_axpby(float a, const float* x, float b, const float* y, float* out, size_t n, mg_stream_t stream) {
+  return axpby_impl(a, x, b, y, out, n, nullptr, stream);
+}
+extern "C" int mg_axpby_dev(const float* coef, const float* x, const float* y, float* out, size_t n, mg_stream_t stream) {
+  MG_CHECK_ARG(coef, "mg_axpby_dev: coef is NULL");
+  return axpby_impl(0.f, x, 0.f, y, out, n, coef, stream);
 }
 
 extern "C" int mg_adam_step_dev(const mg_adam_tensor_dev_t* desc, int n_tensors, float lr, float beta1, float beta2, float eps,

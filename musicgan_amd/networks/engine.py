@@ -102,6 +102,22 @@ class PackCache:
         self._c.clear()
 
 
+class FadeIn:
+    """The fade-in coefficients (alpha, 1 - alpha) of generator.py:124 / discriminator.py:113 as launch scalars -- or, `dev` given
+    (float32 device tensor [alpha, 1 - alpha]), read by the kernels from device memory, which keeps a captured HIP graph of an
+    update valid while alpha moves.  Every engine function accepts a plain float or a FadeIn for `alpha`."""
+
+    def __init__(self, alpha, dev: Optional[torch.Tensor] = None):
+        self.a = float(alpha)
+        self.b = 1.0 - float(alpha)
+        self.dev = dev                                   # coefficients (a, b)
+        self.dev_b = dev[1:] if dev is not None else None  # coefficient b alone (single-coefficient scalings)
+
+    @staticmethod
+    def of(alpha) -> "FadeIn":
+        return alpha if isinstance(alpha, FadeIn) else FadeIn(alpha)
+
+
 class GradSink:
     """Collects parameter gradients keyed by the parameter object; a second write to the same key accumulates."""
 
@@ -156,7 +172,8 @@ def gen_forward(W: GenWeights, z: torch.Tensor, alpha: float, cache: PackCache, 
     if W.old_head is not None:
         mp = ops.conv1x1(x, W.head[0], W.head[1], 2, tanh=True)
         old = ops.conv1x1(x_in_last, W.old_head[0], W.old_head[1], 2, tanh=True)
-        out = ops.blend_up(alpha, mp, 1.0 - alpha, old, out=out)
+        F = FadeIn.of(alpha)
+        out = ops.blend_up(F.a, mp, F.b, old, out=out, coef=F.dev)
     else:
         out = mp = ops.conv1x1(x, W.head[0], W.head[1], 2, tanh=True, out=out)
     ctx = (saved, x, mp, old, alpha) if save else None
@@ -165,11 +182,12 @@ def gen_forward(W: GenWeights, z: torch.Tensor, alpha: float, cache: PackCache, 
 
 def gen_backward(W: GenWeights, ctx, g_out: torch.Tensor, cache: PackCache, sink: GradSink, need_gz: bool = False):
     saved, x_last, mp, old, alpha = ctx
+    F = FadeIn.of(alpha)
     g_out = g_out.contiguous()
     if W.old_head is not None:
-        g_mp = ops.axpby(alpha, g_out)
+        g_mp = ops.axpby(F.a, g_out, coef=F.dev)
         g_old = ops.upsample2x_bwd(g_out)
-        g_old = ops.axpby(1.0 - alpha, g_old, out=g_old)
+        g_old = ops.axpby(F.b, g_old, out=g_old, coef=F.dev_b)
     else:
         g_mp, g_old = g_out, None
     gw, acc = sink.slot(W.head[0])
@@ -245,7 +263,8 @@ def disc_forward(W: DiscWeights, x: torch.Tensor, alpha: float, cache: PackCache
         if i == 0 and W.old_stem is not None:
             xp = ops.avgpool2_fwd(x)
             o = ops.conv1x1(xp, W.old_stem[0], W.old_stem[1], c1, lrelu=True)
-            inp = ops.axpby(alpha, a2, 1.0 - alpha, o)
+            F = FadeIn.of(alpha)
+            inp = ops.axpby(F.a, a2, F.b, o, coef=F.dev)
     assert inp.shape[2] == 1 and inp.shape[3] == 1, \
         f"discriminator input must be square with side 2**(9-curr_layer); final map is {tuple(inp.shape)}"
     flat = inp.reshape(n, -1)
@@ -259,6 +278,7 @@ def disc_backward(W: DiscWeights, ctx, g_out: torch.Tensor, cache: PackCache, si
     """Back-propagate g_out (N,1).  sink=None skips all parameter gradients (first-order pass of the penalty).
     keep_h returns the masked per-layer gradients h_l needed by disc_gp_param_grads()."""
     x, h0, saved, xp, o, flat, alpha = ctx
+    F = FadeIn.of(alpha)
     g_out = g_out.contiguous()
     n = x.shape[0]
     if sink is not None:
@@ -272,7 +292,7 @@ def disc_backward(W: DiscWeights, ctx, g_out: torch.Tensor, cache: PackCache, si
     a2_last = saved[nb - 1][3]
     g = g.reshape(a2_last.shape)
     if nb == 1 and W.old_stem is not None:  # the blend is the classifier input
-        gpre2, gpre_o = ops.blend_lrelu_bwd(g, a2_last, o, alpha, 1.0 - alpha)
+        gpre2, gpre_o = ops.blend_lrelu_bwd(g, a2_last, o, F.a, F.b, coef=F.dev)
     else:
         gpre2 = ops.lrelu_bwd(g, a2_last)
         gpre_o = None
@@ -297,7 +317,7 @@ def disc_backward(W: DiscWeights, ctx, g_out: torch.Tensor, cache: PackCache, si
             a2_prev = saved[i - 1][3]
             if i == 1 and W.old_stem is not None:  # inp is the fade-in blend of a2_prev and the old stem path
                 gblend = cache.conv(gpre1, w1, True, None, cin)
-                gpre2, gpre_o = ops.blend_lrelu_bwd(gblend, a2_prev, o, alpha, 1.0 - alpha)
+                gpre2, gpre_o = ops.blend_lrelu_bwd(gblend, a2_prev, o, F.a, F.b, coef=F.dev)
             else:
                 gpre2 = cache.conv(gpre1, w1, True, None, cin, mask_aux=a2_prev)
         else:
@@ -347,7 +367,8 @@ def disc_gp_param_grads(W: DiscWeights, ctx, hs, u0: torch.Tensor, cache: PackCa
         ops.conv3x3_wgrad(tq, gpre2, gw2, None, accumulate=acc)
         t = cache.conv(tq, w2, False, None, c1, mask_aux=a2)
         if i == 0 and to is not None:
-            t = ops.axpby(alpha, t, 1.0 - alpha, to, out=t)
+            F = FadeIn.of(alpha)
+            t = ops.axpby(F.a, t, F.b, to, out=t, coef=F.dev)
     ones = torch.ones((n, 1), dtype=torch.float32, device=x.device)
     gwc, acc = sink.slot(W.clf[0])
     ops.linear1_bwd(t.reshape(n, -1), W.clf[0], ones, gw=gwc, gb=None, need_gx=False, accumulate=acc)
@@ -402,7 +423,8 @@ def disc_step_fused(W: DiscWeights, x_real: torch.Tensor, x_fake: torch.Tensor, 
         cache.conv(q1[sl], w2, False, None, c1, mask_aux=a2[sl], out=a2[sl])
         if i == 0 and W.old_stem is not None:
             target = saved[1][0][sl] if nb > 1 else flat[sl].reshape(a2[sl].shape)
-            ops.axpby(alpha, a2[sl], 1.0 - alpha, o[sl], out=target)
+            F = FadeIn.of(alpha)
+            ops.axpby(F.a, a2[sl], F.b, o[sl], out=target, coef=F.dev)
     # ---- one weight-gradient sweep over the 3N samples
     for i, (w1, b1, w2, b2) in enumerate(W.blocks):
         inp, a1, q1, a2 = saved[i]

@@ -330,12 +330,17 @@ def avgpool2_bwd(gy, act=None):
     return gx
 
 
-def blend_lrelu_bwd(g, act_a, act_o, ca: float, co: float):
-    """(ca*g*lrelu'(act_a), co*g*lrelu'(act_o)): backward of the fade-in blend and the two LeakyReLUs in one pass."""
-    _chk(g, act_a, act_o)
+def blend_lrelu_bwd(g, act_a, act_o, ca: float, co: float, coef=None):
+    """(ca*g*lrelu'(act_a), co*g*lrelu'(act_o)): backward of the fade-in blend and the two LeakyReLUs in one pass.
+    `coef` (all three fade-in ops): a device tensor whose first two floats replace the scalar coefficients (graph replay)."""
+    _chk(g, act_a, act_o, coef)
     out_a, out_o = torch.empty_like(g), torch.empty_like(g)
-    check(_lib.load().mg_blend_lrelu_bwd(_p(g), _p(act_a), _p(act_o), ca, co, _p(out_a), _p(out_o), g.numel(), SLOPE, _s()),
-          "mg_blend_lrelu_bwd")
+    if coef is not None:
+        check(_lib.load().mg_blend_lrelu_bwd_dev(_p(g), _p(act_a), _p(act_o), _p(coef), _p(out_a), _p(out_o), g.numel(), SLOPE,
+                                                 _s()), "mg_blend_lrelu_bwd_dev")
+    else:
+        check(_lib.load().mg_blend_lrelu_bwd(_p(g), _p(act_a), _p(act_o), ca, co, _p(out_a), _p(out_o), g.numel(), SLOPE,
+                                             _s()), "mg_blend_lrelu_bwd")
     return out_a, out_o
 
 
@@ -346,18 +351,24 @@ def lrelu_bwd(g, act, out=None):
     return out
 
 
-def axpby(a: float, x, b: float = 0.0, y=None, out=None):
-    _chk(x, y, out)
+def axpby(a: float, x, b: float = 0.0, y=None, out=None, coef=None):
+    _chk(x, y, out, coef)
     out = torch.empty_like(x) if out is None else out
-    check(_lib.load().mg_axpby(float(a), _p(x), float(b), _p(y), _p(out), x.numel(), _s()), "mg_axpby")
+    if coef is not None:
+        check(_lib.load().mg_axpby_dev(_p(coef), _p(x), _p(y), _p(out), x.numel(), _s()), "mg_axpby_dev")
+    else:
+        check(_lib.load().mg_axpby(float(a), _p(x), float(b), _p(y), _p(out), x.numel(), _s()), "mg_axpby")
     return out
 
 
-def blend_up(a: float, x, b: float, ylow, out=None):
-    _chk(x, ylow, out)
+def blend_up(a: float, x, b: float, ylow, out=None, coef=None):
+    _chk(x, ylow, out, coef)
     n, c, h, w = x.shape
     out = torch.empty_like(x) if out is None else out
-    check(_lib.load().mg_blend_up(float(a), _p(x), float(b), _p(ylow), _p(out), n * c, h, w, _s()), "mg_blend_up")
+    if coef is not None:
+        check(_lib.load().mg_blend_up_dev(_p(coef), _p(x), _p(ylow), _p(out), n * c, h, w, _s()), "mg_blend_up_dev")
+    else:
+        check(_lib.load().mg_blend_up(float(a), _p(x), float(b), _p(ylow), _p(out), n * c, h, w, _s()), "mg_blend_up")
     return out
 
 

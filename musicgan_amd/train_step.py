@@ -10,8 +10,9 @@
 Single-process runs replay each update as a HIP graph: after two eager calls with the same (level, batch, alpha) the update --
 forward, backward, weight re-packing and the fused Adam with its device-side step counter -- is captured once and replayed, so
 the ~150 launches of an update cost the host one call (the small maps at the ends of both networks are otherwise launch-bound:
-15 us of Python + ctypes per launch against 5-20 us of GPU time).  During a fade-in alpha changes every iteration and the
-updates run eagerly.  `MG_GRAPHS=0` disables it.
+15 us of Python + ctypes per launch against 5-20 us of GPU time).  The fade-in coefficient alpha, which changes every iteration
+of a fade-in, is read by the captured kernels from device memory, so one graph per (level, batch) serves the whole level.
+`MG_GRAPHS=0` disables it.
 
 With torch.distributed initialised (one process per GPU, backend "nccl" = RCCL) the per-rank gradients are summed with one
 flat all-reduce per network on a side stream, the fused Adam runs behind it on that stream, and the main stream meanwhile
@@ -41,6 +42,8 @@ class ProGANStepper:
         self.dp = is_distributed()
         self.use_graphs = (not self.dp) and fused_d_step and os.environ.get("MG_GRAPHS", "1") != "0"
         self._graphs: Dict[tuple, dict] = {}
+        self._fade: Optional[torch.Tensor] = None   # [alpha, 1 - alpha] read by the captured fade-in kernels
+        self._fade_value: Optional[float] = None
         self.bucket_d = GradBucket()
         self.bucket_g = GradBucket()
         if hasattr(optim_gen, "grad_scale"):
@@ -175,9 +178,10 @@ class ProGANStepper:
 
     def _graphed(self, kind: str, inputs, alpha: float) -> Dict[str, torch.Tensor]:
         net, other = (self.disc, self.gen) if kind == "D" else (self.gen, self.disc)
-        key = (kind, self.gen.curr_layer, float(alpha), tuple(tuple(t.shape) for t in inputs),
-               tuple(id(p) for p in net.parameters()))
-        run = (lambda *a: self._d_step_fused(a[0], alpha, a[1], a[2])) if kind == "D" else (lambda *a: self._g_step_fused(a[0], alpha))
+        key = (kind, self.gen.curr_layer, tuple(tuple(t.shape) for t in inputs), tuple(id(p) for p in net.parameters()))
+
+        def run(fade, *a):
+            return self._d_step_fused(a[0], fade, a[1], a[2]) if kind == "D" else self._g_step_fused(a[0], fade)
         ent = self._graphs.get(key)
         if ent is None:
             if len(self._graphs) > 8:  # growth / new batch shapes: drop graphs (and their private memory pools) of the past
@@ -186,16 +190,20 @@ class ProGANStepper:
         if "graph" not in ent:
             ent["calls"] += 1
             if ent["calls"] <= self._WARM_CALLS:
-                return run(*inputs)
+                return run(alpha, *inputs)
             # capture: static copies of the inputs, every weight form re-packed inside the graph (caches emptied first), the
             # gradients and the four scalars the caller reads live in the graph's pool
             ent["inputs"] = [t.detach().clone().contiguous() for t in inputs]
             net.zero_grad()
             other.zero_grad()
             torch.cuda.synchronize()
+            # the fade-in coefficients live in device memory inside the graph: alpha changes every iteration of a fade-in
+            if self._fade is None:
+                self._fade = torch.zeros(2, dtype=torch.float32, device=inputs[0].device)
+            from .networks.engine import FadeIn
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                m = run(*ent["inputs"])
+                m = run(FadeIn(alpha, dev=self._fade), *ent["inputs"])
                 ent["names"] = list(m.keys())
                 ent["out"] = torch.stack([m[k].reshape(()) for k in ent["names"]])
             ent["graph"] = graph
@@ -206,6 +214,10 @@ class ProGANStepper:
             # the captured run itself did not execute: fall through to the first replay with the caller's inputs
         for dst, src in zip(ent["inputs"], inputs):
             dst.copy_(src)
+        if self._fade_value != float(alpha):
+            self._fade[0:1].fill_(float(alpha))
+            self._fade[1:2].fill_(1.0 - float(alpha))
+            self._fade_value = float(alpha)
         ent["graph"].replay()
         self.gen.zero_grad()
         self.disc.zero_grad()

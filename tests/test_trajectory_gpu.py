@@ -232,3 +232,50 @@ def test_fused_adam_multi_step_matches_torch_adam(grad_scale):
     chk = torch.optim.Adam([p.detach().clone().requires_grad_(True) for p in dev[:-1]], lr=LR, betas=BETAS)
     chk.add_param_group({"params": [dev[-1].detach().clone().requires_grad_(True)], "lr": LR, "betas": BETAS})
     chk.load_state_dict(sd)
+
+
+def test_graph_replay_is_bit_identical_to_eager_updates(monkeypatch):
+    """The HIP-graph path of ProGANStepper (updates captured after two eager calls, then replayed: device-side Adam step counters,
+    in-graph weight re-packing, fade-in coefficients read from device memory) against the same stepper with MG_GRAPHS=0: eight
+    iterations with alpha moving every iteration and the 5:1 cadence -- every loss and every weight, Adam moment and step count
+    bit for bit."""
+    import bench
+    from musicgan_amd.optim import FusedAdam
+    from musicgan_amd.train_step import ProGANStepper
+
+    def run(graphs: bool):
+        monkeypatch.setenv("MG_GRAPHS", "1" if graphs else "0")
+        gen, disc = bench.build_nets(3, 32, DEV)
+        og = FusedAdam(gen.parameters(), lr=LR, betas=BETAS)
+        od = FusedAdam(disc.parameters(), lr=LR, betas=BETAS)
+        st = ProGANStepper(gen, disc, og, od, 32)
+        assert st.use_graphs == graphs
+        rng = torch.Generator(device=DEV).manual_seed(9)
+        losses = []
+        for it in range(8):
+            alpha = min(1.0, (1 + 4 * it) / 24.0)
+            x = torch.rand(4, 2, 32, 32, device=DEV, generator=rng) * 2 - 1
+            z = torch.randn(4, 32, 2, 2, device=DEV, generator=rng)
+            eps = torch.rand(4, 1, 1, 1, device=DEV, generator=rng)
+            m = st.d_step(x, alpha, z=z, eps=eps)
+            losses += [float(m["disc_loss"]), float(m["grad_pen"])]
+            if it % 5 == 0 or it >= 5:
+                losses.append(float(st.g_step(4, alpha, DEV, z=z)["gen_loss"]))
+        st.finish()
+        if graphs:
+            assert sum("graph" in e for e in st._graphs.values()) == 2  # one critic graph, one generator graph for the level
+        state = {}
+        for name, net, opt in (("G", gen, og), ("D", disc, od)):
+            for k, p in net.named_parameters():
+                state[f"{name}.{k}"] = p.detach().clone()
+                if p in opt.state:
+                    state[f"{name}.{k}.v"] = opt.state[p]["exp_avg_sq"].clone()
+                    state[f"{name}.{k}.t"] = torch.tensor([float(opt.state[p]["step"]), float(opt.state[p]["step_dev"])])
+        return losses, state
+
+    l_graph, s_graph = run(True)
+    l_eager, s_eager = run(False)
+    assert l_graph == l_eager
+    assert s_graph.keys() == s_eager.keys()
+    for k in s_graph:
+        assert torch.equal(s_graph[k], s_eager[k]), k
