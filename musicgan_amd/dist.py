@@ -34,6 +34,8 @@ class GradBucket:
         self.group = group
         self.world = dist.get_world_size(group) if is_distributed() else 1
         self._flat: Optional[torch.Tensor] = None
+        self._own: Optional[torch.Tensor] = None   # flat buffer handed out by flat_sink()
+        self._own_key = None
         self._work = None
         self._stream: Optional[torch.cuda.Stream] = None
         self._done: Optional[torch.cuda.Event] = None
@@ -47,6 +49,25 @@ class GradBucket:
         if self._stream is None:
             self._stream = torch.cuda.Stream(device=device)
         return self._stream
+
+    def flat_sink(self, tensors: List[torch.Tensor]):
+        """(flat, layout) for engine.GradSink: one buffer the gradients of `tensors` (unique, in this order) are written into
+        directly, reused from step to step (the caller waits for the previous exchange before it writes again)."""
+        uniq, seen = [], set()
+        for p in tensors:
+            if id(p) not in seen:
+                seen.add(id(p))
+                uniq.append(p)
+        total = sum(p.numel() for p in uniq)
+        key = tuple(id(p) for p in uniq)
+        if self._own is None or self._own_key != key:
+            self._own = torch.empty(total, dtype=torch.float32, device=uniq[0].device)
+            self._own_key = key
+        layout, off = {}, 0
+        for p in uniq:
+            layout[id(p)] = (off, p.numel())
+            off += p.numel()
+        return self._own, layout
 
     def launch(self, params: Iterable[torch.nn.Parameter]) -> None:
         """Start the exchange of every non-None .grad.  On GPU it runs on a side stream ordered after the current stream's
@@ -66,7 +87,9 @@ class GradBucket:
                     # the gradients were allocated on the main stream and are dropped (re-pointed) below while the side
                     # stream may not have read them yet: tell the caching allocator they are in use there
                     p.grad.record_stream(side)
-                flat = torch.cat([p.grad.reshape(-1) for p in plist])
+                flat = self._as_own_flat(plist)
+                if flat is None:
+                    flat = torch.cat([p.grad.reshape(-1) for p in plist])
                 if is_distributed():
                     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
                 self._done = torch.cuda.Event()
@@ -81,6 +104,17 @@ class GradBucket:
             p.grad = flat[off:off + n].view_as(p)
             off += n
         self._flat = flat
+
+    def _as_own_flat(self, plist) -> Optional[torch.Tensor]:
+        """The flat_sink() buffer if the gradients of `plist` are exactly its consecutive slices (then nothing is copied)."""
+        if self._own is None:
+            return None
+        off, base = 0, self._own.data_ptr()
+        for p in plist:
+            if p.grad.data_ptr() != base + 4 * off or not p.grad.is_contiguous():
+                return None
+            off += p.numel()
+        return self._own if off == self._own.numel() else None
 
     def stream(self) -> Optional[torch.cuda.Stream]:
         return self._stream

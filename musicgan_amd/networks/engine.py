@@ -119,16 +119,23 @@ class FadeIn:
 
 
 class GradSink:
-    """Collects parameter gradients keyed by the parameter object; a second write to the same key accumulates."""
+    """Collects parameter gradients keyed by the parameter object; a second write to the same key accumulates.
+    `flat` (optional, with `layout` = {id(param): (offset, numel)}): the gradients are carved out of ONE buffer, which is what the
+    data-parallel path all-reduces -- no flatten / un-flatten copies around the exchange."""
 
-    def __init__(self):
+    def __init__(self, flat: Optional[torch.Tensor] = None, layout: Optional[Dict[int, tuple]] = None):
         self.g: Dict[int, torch.Tensor] = {}
+        self.flat, self.layout = flat, layout
 
     def slot(self, param: torch.Tensor):
         k = id(param)
         if k in self.g:
             return self.g[k], True
-        t = torch.empty_like(param, memory_format=torch.contiguous_format)
+        if self.flat is not None and k in self.layout:
+            off, n = self.layout[k]
+            t = self.flat[off:off + n].view(param.shape)
+        else:
+            t = torch.empty_like(param, memory_format=torch.contiguous_format)
         self.g[k] = t
         return t, False
 
@@ -457,12 +464,15 @@ def disc_step_fused(W: DiscWeights, x_real: torch.Tensor, x_fake: torch.Tensor, 
 # Generator step without autograd
 # =====================================================================================================================
 def gen_step_fused(Wg: GenWeights, Wd: DiscWeights, z: torch.Tensor, alpha: float, cache_g: PackCache, cache_d: PackCache,
-                   sink: GradSink):
+                   sink: GradSink, before_disc=None):
     """Gradient of  -mean D(G(z))  (criterion.py:17-18, train.py:191-213) w.r.t. every live generator parameter, written into
     `sink`; returns (gen_loss, out_fake).  The critic's weight gradients are not evaluated (the reference computes and discards
-    them, train.py:209-214): its backward pass only carries the data gradient down to the generated images."""
+    them, train.py:209-214): its backward pass only carries the data gradient down to the generated images.
+    `before_disc` (optional callable) runs between the generator's forward pass and the critic's."""
     n = z.shape[0]
     x_fake, gctx = gen_forward(Wg, z.contiguous(), alpha, cache_g, save=True)
+    if before_disc is not None:  # data-parallel: the critic's weights may still be in flight on the side stream until here
+        before_disc()
     out, dctx = disc_forward(Wd, x_fake, alpha, cache_d, save=True)
     g_out = torch.full((n, 1), -1.0 / n, dtype=torch.float32, device=z.device)
     gx, _ = disc_backward(Wd, dctx, g_out, cache_d, None, need_gx=True)

@@ -113,7 +113,7 @@ class ProGANStepper:
             engine.gen_forward(self.gen._weights(), z.contiguous(), alpha, self.gen._pack_cache, save=False,
                                out=xcat[n:2 * n])
             W = self.disc._weights()
-            sink = engine.GradSink()
+            sink = engine.GradSink(*self.bucket_d.flat_sink(W.tensors())) if self.dp else engine.GradSink()
             disc_loss, grad_pen, out = engine.disc_step_fused(W, xcat[:n], xcat[n:2 * n], eps, alpha,
                                                               self.disc._pack_cache, sink, xcat=xcat)
         self.gen.zero_grad()
@@ -129,7 +129,7 @@ class ProGANStepper:
             z = self._latent(batch_size, device)
         if self.use_graphs:
             return self._graphed("G", (z,), alpha)
-        if self.fused_d_step and not self.dp:
+        if self.fused_d_step:
             return self._g_step_fused(z, alpha)
         if self.dp:
             self.bucket_g.wait()
@@ -154,11 +154,23 @@ class ProGANStepper:
     def _g_step_fused(self, z, alpha) -> Dict[str, torch.Tensor]:
         """The generator update through `engine.gen_step_fused` (no autograd graph, no critic weight gradients)."""
         from .networks import engine
-        self._refresh_packs()
+        before_disc = None
+        if self.dp:
+            # G's forward runs while the critic's gradient exchange + Adam are still on the side stream; the critic's weights
+            # (and their packed layouts) are only touched behind bucket_d.wait()
+            self.bucket_g.wait()
+            self.gen._pack_cache.refresh()
+
+            def before_disc():
+                self.bucket_d.wait()
+                self.disc._pack_cache.refresh()
+        else:
+            self._refresh_packs()
         with torch.no_grad():
             Wg, Wd = self.gen._weights(), self.disc._weights()
-            sink = engine.GradSink()
-            gen_loss, out = engine.gen_step_fused(Wg, Wd, z, alpha, self.gen._pack_cache, self.disc._pack_cache, sink)
+            sink = engine.GradSink(*self.bucket_g.flat_sink(Wg.tensors())) if self.dp else engine.GradSink()
+            gen_loss, out = engine.gen_step_fused(Wg, Wd, z, alpha, self.gen._pack_cache, self.disc._pack_cache, sink,
+                                                  before_disc=before_disc)
         self.gen.zero_grad()
         self.disc.zero_grad()
         for p in Wg.tensors():

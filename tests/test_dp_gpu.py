@@ -65,3 +65,25 @@ def test_data_parallel_path_is_bit_identical_to_single_process(one_rank_nccl, mo
     live = [p for p in st_dp.gen.parameters() if p.grad is not None]
     assert flat is not None and sum(p.numel() for p in live) == flat.numel()
     assert all(flat.data_ptr() <= p.grad.data_ptr() < flat.data_ptr() + 4 * flat.numel() for p in live)
+
+
+def test_bench_runs_under_torchrun_as_the_driver_launches_it(tmp_path):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N` (the driver's N > 1 command) with
+    N = 1 and MG_FORCE_DP=1: a 1-rank RCCL group, the data-parallel stepper, one JSON line with the contract's keys."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MG_FORCE_DP="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(29800 + os.getpid() % 100), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3",
+           "--warmup", "2", "--level", "3", "--batch", "8", "--no-cpu-baseline", "--no-extra"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["parallelism"] == "dp1" and "workload" in d["config"]
