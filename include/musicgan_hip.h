@@ -161,6 +161,11 @@ int mg_gp_finish(const float* sumsq, float* penalty, float* coef, int N, float f
 /* sum over (n, hw) of a per-channel tensor: out[c] (+)= sum x[n,c,hw] */
 int mg_channel_sum(const float* x, float* out, int N, int C, int HW, int accumulate, mg_stream_t stream);
 
+/* Wasserstein losses [criterion.py:12-18] and the score means train.py:180-186 logs, one launch: out[g] = mean of the g-th group of
+ * n consecutive critic scores (g < groups <= 8), out[groups] = groups >= 2 ? out[1] - out[0] (= wasserstein_discriminator_loss
+ * with group 0 = real, 1 = fake) : -out[0] (= wasserstein_generator_loss).  out has groups + 1 floats. */
+int mg_group_means(const float* x, int groups, int n, float* out, mg_stream_t stream);
+
 /* ------------------------------------------------------------------ multi-tensor weight re-packing
  * All of mg_conv3x3_pack / mg_wino3x3_pack / mg_upconv3x3_pack / mg_upconv3x3_dgrad_pack for a list of weights in ONE launch (the
  * reference has no counterpart: these layouts replace what MIOpen / oneDNN re-derive from nn.Conv2d.weight inside every call).

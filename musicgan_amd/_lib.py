@@ -83,6 +83,7 @@ SIGNATURES = {
     "mg_gp_finish": (c_int, [_P, _P, _P, c_int, c_float, c_float, _P]),
     "mg_channel_sum": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "mg_adam_step": (c_int, [_P, c_int, c_float, c_float, c_float, c_float, _P]),
+    "mg_group_means": (c_int, [_P, c_int, c_int, _P, _P]),
     "mg_pack_multi": (c_int, [_P, c_int, _P]),
     "mg_adam_step_dev": (c_int, [_P, c_int, c_float, c_float, c_float, c_float, c_float, _P]),
     "mg_input_transform_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),

@@ -394,6 +394,29 @@ __global__ void gp_finish_k(const float* __restrict__ sumsq, float* __restrict__
   if (threadIdx.x == 0 && penalty) penalty[0] = factor * s / (float)N;
 }
 
+// Means of consecutive groups of n critic scores + the Wasserstein loss built from them, one launch (criterion.py:12-18):
+//   out[g] = mean(x[g*n .. g*n+n)),  out[groups] = groups >= 2 ? out[1] - out[0]  (= -(mean D(real) - mean D(fake)))  :  -out[0]
+__global__ void __launch_bounds__(256) group_means_k(const float* __restrict__ x, int groups, int n, float* __restrict__ out) {
+  __shared__ double part[4];
+  __shared__ float means[8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int g = 0; g < groups; ++g) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)x[(size_t)g * n + i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if (lane == 0) part[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float m = (float)((((part[0] + part[1]) + part[2]) + part[3]) / (double)n);
+      means[g] = m;
+      out[g] = m;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[groups] = groups >= 2 ? means[1] - means[0] : -means[0];
+}
+
 __global__ void __launch_bounds__(1024) channel_sum_k(const float* __restrict__ x, float* __restrict__ out, int N, int C,
                                                       int HW, int accumulate) {
   __shared__ float red[16];
@@ -708,6 +731,13 @@ extern "C" int mg_gp_finish(const float* sumsq, float* penalty, float* coef, int
   MG_CHECK_ARG(sumsq && N > 0, "mg_gp_finish: bad arguments");
   EW_LAUNCH(gp_finish_k, 1, 256, sumsq, penalty, coef, N, factor, upstream);
   MG_CHECK_LAUNCH("mg_gp_finish");
+  return MG_OK;
+}
+
+extern "C" int mg_group_means(const float* x, int groups, int n, float* out, mg_stream_t stream) {
+  MG_CHECK_ARG(x && out && groups >= 1 && groups <= 8 && n > 0, "mg_group_means: bad arguments");
+  EW_LAUNCH(group_means_k, 1, 256, x, groups, n, out);
+  MG_CHECK_LAUNCH("mg_group_means");
   return MG_OK;
 }
 

@@ -102,6 +102,23 @@ class PackCache:
         self._c.clear()
 
 
+_UPSTREAM: Dict[tuple, torch.Tensor] = {}
+
+
+def upstream_scores_grad(kind: str, n: int, device) -> torch.Tensor:
+    """d loss / d critic scores, a constant of the batch size: "critic": [-1/n]*n + [+1/n]*n + [1]*n for the fused critic step's
+    [real | fake | interpolated] batch; "gen": [-1/n]*n.  Built once per (kind, n, device) and only ever read."""
+    key = (kind, n, str(device))
+    t = _UPSTREAM.get(key)
+    if t is None:
+        if kind == "critic":
+            t = torch.cat([torch.full((n, 1), -1.0 / n), torch.full((n, 1), 1.0 / n), torch.ones(n, 1)]).to(device)
+        else:
+            t = torch.full((n, 1), -1.0 / n).to(device)
+        _UPSTREAM[key] = t
+    return t
+
+
 class FadeIn:
     """The fade-in coefficients (alpha, 1 - alpha) of generator.py:124 / discriminator.py:113 as launch scalars -- or, `dev` given
     (float32 device tensor [alpha, 1 - alpha]), read by the kernels from device memory, which keeps a captured HIP graph of an
@@ -389,7 +406,8 @@ def disc_gp_param_grads(W: DiscWeights, ctx, hs, u0: torch.Tensor, cache: PackCa
 def disc_step_fused(W: DiscWeights, x_real: torch.Tensor, x_fake: torch.Tensor, eps: torch.Tensor, alpha: float,
                     cache: PackCache, sink: GradSink, gp_factor: float = 10.0, xcat: Optional[torch.Tensor] = None):
     """Gradient of  -(mean D(x_real) - mean D(x_fake)) + gp_factor * mean((||grad D(x~)|| - 1)^2)  w.r.t. every live critic
-    parameter, written into `sink`; returns (disc_loss, grad_pen, out) with out = D([x_real; x_fake; x~]).
+    parameter, written into `sink`; returns (disc_loss, grad_pen, out, stats) with out = D([x_real; x_fake; x~]) and stats =
+    [mean D(real), mean D(fake), mean D(x~), disc_loss].
 
     Same arithmetic as three `disc_forward` + two `disc_backward` + `disc_gp_param_grads`, organised as ONE forward and ONE
     data-gradient chain over the concatenated batch [real | fake | interpolated] (per-sample upstream -1/N, +1/N, 1), the
@@ -405,10 +423,7 @@ def disc_step_fused(W: DiscWeights, x_real: torch.Tensor, x_fake: torch.Tensor, 
         xcat[n:2 * n].copy_(x_fake)
     ops.gp_interp(xcat[:n], xcat[n:2 * n], eps.contiguous(), out=xcat[2 * n:])
     out, ctx = disc_forward(W, xcat, alpha, cache, save=True)
-    g_out = torch.empty((3 * n, 1), dtype=torch.float32, device=xcat.device)
-    g_out[:n] = -1.0 / n
-    g_out[n:2 * n] = 1.0 / n
-    g_out[2 * n:] = 1.0
+    g_out = upstream_scores_grad("critic", n, xcat.device)
     gx, hs = disc_backward(W, ctx, g_out, cache, None, need_gx=True, keep_h=True, gx_from=2 * n)  # input gradient: x~ only
     # penalty value and u_0 = dP/dg_0, written over the interpolated inputs (they are not needed any more)
     ss = ops.sumsq_per_sample(gx)
@@ -456,8 +471,8 @@ def disc_step_fused(W: DiscWeights, x_real: torch.Tensor, x_fake: torch.Tensor, 
     gbc, _ = sink.slot(W.clf[1])
     ops.linear1_bwd(flat, W.clf[0], g_out, gw=gwc, gb=None, need_gx=False, accumulate=acc)
     ops.linear1_bwd(flat[lo], W.clf[0], g_out[lo], gw=None, gb=gbc, need_gx=False, accumulate=acc)
-    disc_loss = -(out[:n].mean() - out[n:2 * n].mean())
-    return disc_loss, grad_pen, out
+    stats = ops.group_means(out, 3)  # [mean D(real), mean D(fake), mean D(x~), -(mean D(real) - mean D(fake))]
+    return stats[3], grad_pen, out, stats
 
 
 # =====================================================================================================================
@@ -466,7 +481,7 @@ def disc_step_fused(W: DiscWeights, x_real: torch.Tensor, x_fake: torch.Tensor, 
 def gen_step_fused(Wg: GenWeights, Wd: DiscWeights, z: torch.Tensor, alpha: float, cache_g: PackCache, cache_d: PackCache,
                    sink: GradSink, before_disc=None):
     """Gradient of  -mean D(G(z))  (criterion.py:17-18, train.py:191-213) w.r.t. every live generator parameter, written into
-    `sink`; returns (gen_loss, out_fake).  The critic's weight gradients are not evaluated (the reference computes and discards
+    `sink`; returns (gen_loss, out_fake, stats = [mean D(G(z)), gen_loss]).  The critic's weight gradients are not evaluated (the reference computes and discards
     them, train.py:209-214): its backward pass only carries the data gradient down to the generated images.
     `before_disc` (optional callable) runs between the generator's forward pass and the critic's."""
     n = z.shape[0]
@@ -474,7 +489,8 @@ def gen_step_fused(Wg: GenWeights, Wd: DiscWeights, z: torch.Tensor, alpha: floa
     if before_disc is not None:  # data-parallel: the critic's weights may still be in flight on the side stream until here
         before_disc()
     out, dctx = disc_forward(Wd, x_fake, alpha, cache_d, save=True)
-    g_out = torch.full((n, 1), -1.0 / n, dtype=torch.float32, device=z.device)
+    g_out = upstream_scores_grad("gen", n, z.device)
     gx, _ = disc_backward(Wd, dctx, g_out, cache_d, None, need_gx=True)
     gen_backward(Wg, gctx, gx, cache_g, sink)
-    return -out.mean(), out
+    stats = ops.group_means(out, 1)  # [mean D(G(z)), -mean D(G(z))]
+    return stats[1], out, stats

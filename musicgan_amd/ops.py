@@ -425,6 +425,17 @@ def gp_finish(sumsq, factor: float, upstream: float = 1.0, want_penalty=True, wa
     return pen, coef
 
 
+def group_means(scores, groups: int):
+    """scores (groups*n, 1) -> float32 tensor [mean_0 .. mean_{groups-1}, loss] with loss = mean_1 - mean_0 (groups >= 2: the
+    critic's Wasserstein loss for groups real | fake | ...) or -mean_0 (groups == 1: the generator's)."""
+    _chk(scores)
+    n = scores.numel() // groups
+    assert n * groups == scores.numel()
+    out = torch.empty((groups + 1,), dtype=torch.float32, device=scores.device)
+    check(_lib.load().mg_group_means(_p(scores), groups, n, _p(out), _s()), "mg_group_means")
+    return out
+
+
 def channel_sum(x, out=None, accumulate=False):
     _chk(x, out)
     n, c, h, w = x.shape

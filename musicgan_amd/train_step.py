@@ -114,15 +114,14 @@ class ProGANStepper:
                                out=xcat[n:2 * n])
             W = self.disc._weights()
             sink = engine.GradSink(*self.bucket_d.flat_sink(W.tensors())) if self.dp else engine.GradSink()
-            disc_loss, grad_pen, out = engine.disc_step_fused(W, xcat[:n], xcat[n:2 * n], eps, alpha,
-                                                              self.disc._pack_cache, sink, xcat=xcat)
+            disc_loss, grad_pen, out, stats = engine.disc_step_fused(W, xcat[:n], xcat[n:2 * n], eps, alpha,
+                                                                     self.disc._pack_cache, sink, xcat=xcat)
         self.gen.zero_grad()
         self.disc.zero_grad()
         for p in W.tensors():
             p.grad = sink.get(p)
         self._update(self.bucket_d, self.disc, self.optim_disc)
-        return {"disc_loss": disc_loss, "grad_pen": grad_pen, "out_real_mean": out[:n].mean(),
-                "out_fake_mean": out[n:2 * n].mean()}
+        return {"disc_loss": disc_loss, "grad_pen": grad_pen, "out_real_mean": stats[0], "out_fake_mean": stats[1]}
 
     def g_step(self, batch_size: int, alpha: float, device, z: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         if z is None:
@@ -169,14 +168,14 @@ class ProGANStepper:
         with torch.no_grad():
             Wg, Wd = self.gen._weights(), self.disc._weights()
             sink = engine.GradSink(*self.bucket_g.flat_sink(Wg.tensors())) if self.dp else engine.GradSink()
-            gen_loss, out = engine.gen_step_fused(Wg, Wd, z, alpha, self.gen._pack_cache, self.disc._pack_cache, sink,
-                                                  before_disc=before_disc)
+            gen_loss, out, stats = engine.gen_step_fused(Wg, Wd, z, alpha, self.gen._pack_cache, self.disc._pack_cache, sink,
+                                                         before_disc=before_disc)
         self.gen.zero_grad()
         self.disc.zero_grad()
         for p in Wg.tensors():
             p.grad = sink.get(p)
         self._update(self.bucket_g, self.gen, self.optim_gen)
-        return {"gen_loss": gen_loss, "out_fake_mean": out.mean()}
+        return {"gen_loss": gen_loss, "out_fake_mean": stats[0]}
 
     def _refresh_packs(self) -> None:
         """Every packed weight layout either network has used so far, re-packed in one launch per network if its weight changed
