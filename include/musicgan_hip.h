@@ -77,6 +77,20 @@ int mg_wino3x3(const float* x, const float* up, const float* bias, const float* 
 size_t mg_wino3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W);
 int mg_wino3x3_wgrad(const float* x, const float* gy, float* gw, float* gb, void* ws, size_t ws_bytes, int N, int Cin, int Cout,
                      int H, int W, int flags, int accumulate, int bias_n, mg_stream_t stream);
+/* The same in two halves, so that the slab reductions of several layers run in ONE launch at the end of an update's weight-gradient
+ * sweep (each is a ~20 us latency-bound kernel): _partial runs the matrix kernel into `ws` (one workspace PER LAYER, alive until
+ * the reduce) and fills `job`; _reduce sums the slabs of n jobs in a fixed order, applies G^T . G and writes gw / gb. */
+typedef struct {
+  const float* slab;
+  const float* slab_b;
+  float* gw;
+  float* gb;
+  int32_t nsplit, Cout, Cin, CoutP, CinP, accumulate;
+} mg_wgrad_job_t;
+int mg_wino3x3_wgrad_partial(const float* x, const float* gy, float* gw, float* gb, void* ws, size_t ws_bytes, int N, int Cin,
+                             int Cout, int H, int W, int flags, int accumulate, int bias_n, mg_wgrad_job_t* job,
+                             mg_stream_t stream);
+int mg_wino3x3_wgrad_reduce(const mg_wgrad_job_t* jobs, int n, mg_stream_t stream);
 
 /* Data gradient of Upsample(x2) -> Conv3x3 w.r.t. the LOW-resolution input: one stride-2 convolution with the 4x4 effective
  * kernel over gy (N,Cout,2Hin,2Win) -> gx (N,Cin,Hin,Win); replaces conv-dgrad at 2Hx2W + the 2x2 block sums of Upsample's

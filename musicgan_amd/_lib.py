@@ -32,6 +32,11 @@ class AdamTensorDev(Structure):
                 ("numel", c_int64), ("step", c_void_p)]
 
 
+class WgradJob(Structure):
+    _fields_ = [("slab", c_void_p), ("slab_b", c_void_p), ("gw", c_void_p), ("gb", c_void_p), ("nsplit", c_int), ("Cout", c_int),
+                ("Cin", c_int), ("CoutP", c_int), ("CinP", c_int), ("accumulate", c_int)]
+
+
 class PackDesc(Structure):
     _fields_ = [("w", c_void_p), ("out", c_void_p), ("kind", c_int), ("Co", c_int), ("Ci", c_int), ("dgrad", c_int)]
 
@@ -54,6 +59,9 @@ SIGNATURES = {
     "mg_wino3x3": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "mg_wino3x3_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "mg_wino3x3_wgrad": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "mg_wino3x3_wgrad_partial": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
+                                         _P]),
+    "mg_wino3x3_wgrad_reduce": (c_int, [_P, c_int, _P]),
     "mg_upconv3x3_dgrad_packed_floats": (c_size_t, [c_int, c_int]),
     "mg_upconv3x3_dgrad_pack": (c_int, [_P, _P, c_int, c_int, _P]),
     "mg_upconv3x3_dgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),

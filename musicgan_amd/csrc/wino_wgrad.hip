@@ -257,12 +257,12 @@ __global__ void __launch_bounds__(512) wino_wgrad_mfma(const WwArgs a) {
 // Sum the split-K slabs in a fixed order and apply  dW = G^T M G.  Block = 64 consecutive (c, o) pairs x 4 split-lanes x 4
 // component groups (a thread sums every 4th split of 4 components: 1024 threads keep enough loads in flight for what is a pure
 // latency problem), LDS-combined as ((l0 + l1) + (l2 + l3)) => deterministic.  Component slots per row: [nu0, nu3, nu1, nu2].
-__global__ void __launch_bounds__(1024) wino_wgrad_reduce(const float* __restrict__ slab, const float* __restrict__ slab_b, int nsplit,
-                                                          float* __restrict__ gw, float* __restrict__ gb, int Cout, int Cin,
-                                                          int CoutP, int CinP, int accumulate) {
+__device__ __forceinline__ void wino_wgrad_reduce_body(const float* __restrict__ slab, const float* __restrict__ slab_b, int nsplit,
+                                                       float* __restrict__ gw, float* __restrict__ gb, int Cout, int Cin,
+                                                       int CoutP, int CinP, int accumulate, int block) {
   __shared__ float red[4][16][64];
   const int el = threadIdx.x & 63, kl = (threadIdx.x >> 6) & 3, cg = threadIdx.x >> 8;
-  const int e = blockIdx.x * 64 + el;  // e = c * CoutP + o over the padded block
+  const int e = block * 64 + el;  // e = c * CoutP + o over the padded block
   const int total = CinP * CoutP;
   float m[4] = {0.f, 0.f, 0.f, 0.f};
   if (e < total) {
@@ -322,6 +322,18 @@ __global__ void __launch_bounds__(1024) wino_wgrad_reduce(const float* __restric
   }
 }
 
+// One launch for the reduce of SEVERAL layers (the weight-gradient sweep of an update ends with one of these per layer: 8 launches of
+// ~20 us each, latency-bound, at level 5): jobs travel by value, blockIdx.y selects the job, blocks past a job's extent return.
+constexpr int WW_JOBS = 40;
+struct WwJobs {
+  mg_wgrad_job_t j[WW_JOBS];
+};
+__global__ void __launch_bounds__(1024) wino_wgrad_reduce_multi(const WwJobs jobs) {
+  const mg_wgrad_job_t j = jobs.j[blockIdx.y];
+  if ((int)blockIdx.x * 64 >= j.CinP * j.CoutP) return;
+  wino_wgrad_reduce_body(j.slab, j.slab_b, j.nsplit, j.gw, j.gb, j.Cout, j.Cin, j.CoutP, j.CinP, j.accumulate, blockIdx.x);
+}
+
 struct WwPlan {
   WwArgs a;
   int CT, OT, ncb, nsplit;
@@ -378,9 +390,10 @@ extern "C" size_t mg_wino3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int
   return pl.ws_floats * sizeof(float);
 }
 
-extern "C" int mg_wino3x3_wgrad(const float* x, const float* gy, float* gw, float* gb, void* ws, size_t ws_bytes, int N, int Cin,
-                                int Cout, int H, int W, int flags, int accumulate, int bias_n, mg_stream_t stream) {
-  MG_CHECK_ARG(x && gy && gw && ws && N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "mg_wino3x3_wgrad: bad arguments");
+extern "C" int mg_wino3x3_wgrad_partial(const float* x, const float* gy, float* gw, float* gb, void* ws, size_t ws_bytes, int N,
+                                        int Cin, int Cout, int H, int W, int flags, int accumulate, int bias_n,
+                                        mg_wgrad_job_t* job, mg_stream_t stream) {
+  MG_CHECK_ARG(x && gy && gw && ws && job && N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "mg_wino3x3_wgrad: bad arguments");
   MG_CHECK_ARG((H % 2 == 0) && (W % 2 == 0), "mg_wino3x3_wgrad: H=%d W=%d must be even", H, W);
   MG_CHECK_ARG(!(flags & ~MG_CONV_UPS_IN), "mg_wino3x3_wgrad: unknown flag");
   const bool ups = (flags & MG_CONV_UPS_IN) != 0;
@@ -414,9 +427,33 @@ extern "C" int mg_wino3x3_wgrad(const float* x, const float* gy, float* gw, floa
     else rc = launch_ww<4, 4, false>(a, grid, s);
   }
   if (rc != MG_OK) return rc;
-  const int total = a.CinP * a.CoutP;
-  hipLaunchKernelGGL(wino_wgrad_reduce, dim3(mg_cdiv(total, 64)), dim3(1024), 0, s, a.slab, a.slab_b, pl.nsplit, gw, gb, Cout, Cin,
-                     a.CoutP, a.CinP, accumulate);
-  MG_CHECK_LAUNCH("mg_wino3x3_wgrad(reduce)");
+  job->slab = a.slab; job->slab_b = a.slab_b; job->gw = gw; job->gb = gb;
+  job->nsplit = pl.nsplit; job->Cout = Cout; job->Cin = Cin; job->CoutP = a.CoutP; job->CinP = a.CinP; job->accumulate = accumulate;
   return MG_OK;
+}
+
+extern "C" int mg_wino3x3_wgrad_reduce(const mg_wgrad_job_t* jobs, int n, mg_stream_t stream) {
+  MG_CHECK_ARG(jobs && n > 0, "mg_wino3x3_wgrad_reduce: bad arguments");
+  for (int first = 0; first < n; first += WW_JOBS) {
+    const int m = n - first < WW_JOBS ? n - first : WW_JOBS;
+    WwJobs c;
+    int most = 0;
+    for (int i = 0; i < m; ++i) {
+      c.j[i] = jobs[first + i];
+      MG_CHECK_ARG(c.j[i].slab && c.j[i].gw && c.j[i].nsplit > 0 && c.j[i].CinP > 0 && c.j[i].CoutP > 0,
+                   "mg_wino3x3_wgrad_reduce: bad job %d", first + i);
+      const int blocks = mg_cdiv(c.j[i].CinP * c.j[i].CoutP, 64);
+      if (blocks > most) most = blocks;
+    }
+    hipLaunchKernelGGL(wino_wgrad_reduce_multi, dim3(most, m), dim3(1024), 0, (hipStream_t)stream, c);
+    MG_CHECK_LAUNCH("mg_wino3x3_wgrad_reduce");
+  }
+  return MG_OK;
+}
+
+extern "C" int mg_wino3x3_wgrad(const float* x, const float* gy, float* gw, float* gb, void* ws, size_t ws_bytes, int N, int Cin,
+                                int Cout, int H, int W, int flags, int accumulate, int bias_n, mg_stream_t stream) {
+  mg_wgrad_job_t job;
+  const int rc = mg_wino3x3_wgrad_partial(x, gy, gw, gb, ws, ws_bytes, N, Cin, Cout, H, W, flags, accumulate, bias_n, &job, stream);
+  return rc != MG_OK ? rc : mg_wino3x3_wgrad_reduce(&job, 1, stream);
 }

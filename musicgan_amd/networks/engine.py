@@ -204,7 +204,9 @@ def gen_forward(W: GenWeights, z: torch.Tensor, alpha: float, cache: PackCache, 
     return out, ctx
 
 
-def gen_backward(W: GenWeights, ctx, g_out: torch.Tensor, cache: PackCache, sink: GradSink, need_gz: bool = False):
+def gen_backward(W: GenWeights, ctx, g_out: torch.Tensor, cache: PackCache, sink: GradSink, need_gz: bool = False,
+                 defer: Optional["ops.WgradDefer"] = None):
+    """`defer`: the Winograd weight-gradient reductions are collected there; the caller flushes it (one launch for all layers)."""
     saved, x_last, mp, old, alpha = ctx
     F = FadeIn.of(alpha)
     g_out = g_out.contiguous()
@@ -227,7 +229,7 @@ def gen_backward(W: GenWeights, ctx, g_out: torch.Tensor, cache: PackCache, sink
         gpre2 = ops.pixelnorm_lrelu_bwd(g, p2, rn2, from_p=True)
         gw2, acc = sink.slot(w2)
         gb2, _ = sink.slot(b2)
-        ops.conv3x3_wgrad(p1, gpre2, gw2, gb2, ups=True, accumulate=acc)
+        ops.conv3x3_wgrad(p1, gpre2, gw2, gb2, ups=True, accumulate=acc, defer=defer)
         if ops.upconv3x3_dgrad_supported(p1.shape[2], p1.shape[3], gpre2.numel(), p1.shape[0]):
             gp1 = ops.upconv3x3_dgrad(gpre2, cache.get_up_dgrad(w2), ci)  # stride-2 4x4 form: no high-res intermediate
         else:
@@ -235,7 +237,7 @@ def gen_backward(W: GenWeights, ctx, g_out: torch.Tensor, cache: PackCache, sink
         gpre1 = ops.pixelnorm_lrelu_bwd(gp1, p1, rn1, from_p=True)
         gw1, acc = sink.slot(w1)
         gb1, _ = sink.slot(b1)
-        ops.conv3x3_wgrad(xin, gpre1, gw1, gb1, accumulate=acc)
+        ops.conv3x3_wgrad(xin, gpre1, gw1, gb1, accumulate=acc, defer=defer)
         if i > 0:
             g = cache.conv(gpre1, w1, True, None, ci)
             if g_old is not None and i == last:
@@ -404,7 +406,8 @@ def disc_gp_param_grads(W: DiscWeights, ctx, hs, u0: torch.Tensor, cache: PackCa
 # Fused discriminator step (one batched pass instead of three)
 # =====================================================================================================================
 def disc_step_fused(W: DiscWeights, x_real: torch.Tensor, x_fake: torch.Tensor, eps: torch.Tensor, alpha: float,
-                    cache: PackCache, sink: GradSink, gp_factor: float = 10.0, xcat: Optional[torch.Tensor] = None):
+                    cache: PackCache, sink: GradSink, gp_factor: float = 10.0, xcat: Optional[torch.Tensor] = None,
+                    defer: Optional["ops.WgradDefer"] = None):
     """Gradient of  -(mean D(x_real) - mean D(x_fake)) + gp_factor * mean((||grad D(x~)|| - 1)^2)  w.r.t. every live critic
     parameter, written into `sink`; returns (disc_loss, grad_pen, out, stats) with out = D([x_real; x_fake; x~]) and stats =
     [mean D(real), mean D(fake), mean D(x~), disc_loss].
@@ -453,10 +456,10 @@ def disc_step_fused(W: DiscWeights, x_real: torch.Tensor, x_fake: torch.Tensor, 
         gpre1, gpre2 = hs["blocks"][i]
         gw1, acc = sink.slot(w1)
         gb1, _ = sink.slot(b1)
-        ops.conv3x3_wgrad(inp, gpre1, gw1, gb1, accumulate=acc, bias_n=2 * n)
+        ops.conv3x3_wgrad(inp, gpre1, gw1, gb1, accumulate=acc, bias_n=2 * n, defer=defer)
         gw2, acc = sink.slot(w2)
         gb2, _ = sink.slot(b2)
-        ops.conv3x3_wgrad(q1, gpre2, gw2, gb2, accumulate=acc, bias_n=2 * n)
+        ops.conv3x3_wgrad(q1, gpre2, gw2, gb2, accumulate=acc, bias_n=2 * n, defer=defer)
     lo = slice(0, 2 * n)
     gws, acc = sink.slot(W.stem[0])
     gbs, _ = sink.slot(W.stem[1])
@@ -471,6 +474,8 @@ def disc_step_fused(W: DiscWeights, x_real: torch.Tensor, x_fake: torch.Tensor, 
     gbc, _ = sink.slot(W.clf[1])
     ops.linear1_bwd(flat, W.clf[0], g_out, gw=gwc, gb=None, need_gx=False, accumulate=acc)
     ops.linear1_bwd(flat[lo], W.clf[0], g_out[lo], gw=None, gb=gbc, need_gx=False, accumulate=acc)
+    if defer is not None:
+        defer.flush()  # the slab reductions of every Winograd weight gradient of the sweep, one launch
     stats = ops.group_means(out, 3)  # [mean D(real), mean D(fake), mean D(x~), -(mean D(real) - mean D(fake))]
     return stats[3], grad_pen, out, stats
 
@@ -479,7 +484,7 @@ def disc_step_fused(W: DiscWeights, x_real: torch.Tensor, x_fake: torch.Tensor, 
 # Generator step without autograd
 # =====================================================================================================================
 def gen_step_fused(Wg: GenWeights, Wd: DiscWeights, z: torch.Tensor, alpha: float, cache_g: PackCache, cache_d: PackCache,
-                   sink: GradSink, before_disc=None):
+                   sink: GradSink, before_disc=None, defer: Optional["ops.WgradDefer"] = None):
     """Gradient of  -mean D(G(z))  (criterion.py:17-18, train.py:191-213) w.r.t. every live generator parameter, written into
     `sink`; returns (gen_loss, out_fake, stats = [mean D(G(z)), gen_loss]).  The critic's weight gradients are not evaluated (the reference computes and discards
     them, train.py:209-214): its backward pass only carries the data gradient down to the generated images.
@@ -491,6 +496,8 @@ def gen_step_fused(Wg: GenWeights, Wd: DiscWeights, z: torch.Tensor, alpha: floa
     out, dctx = disc_forward(Wd, x_fake, alpha, cache_d, save=True)
     g_out = upstream_scores_grad("gen", n, z.device)
     gx, _ = disc_backward(Wd, dctx, g_out, cache_d, None, need_gx=True)
-    gen_backward(Wg, gctx, gx, cache_g, sink)
+    gen_backward(Wg, gctx, gx, cache_g, sink, defer=defer)
+    if defer is not None:
+        defer.flush()
     stats = ops.group_means(out, 1)  # [mean D(G(z)), -mean D(G(z))]
     return stats[1], out, stats

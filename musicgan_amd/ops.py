@@ -223,12 +223,48 @@ def wino_wgrad_supported(n: int, cin: int, cout: int, h: int, w: int, *, ups=Fal
     return n * h * w >= int(os.environ.get("MG_WINO_WGRAD_MIN_PIXELS", "8192"))
 
 
-def conv3x3_wgrad(x, gy, gw, gb, *, ups=False, accumulate=False, bias_n: int = 0):
-    """gw[Cout,Cin,3,3] (+)= wgrad(x, gy); gb[Cout] (+)= sum gy over samples n < bias_n (0: all; gb may be None)."""
+class WgradDefer:
+    """Collects the slab reductions of the Winograd weight gradients of one sweep (conv3x3_wgrad(..., defer=this)) and runs them
+    in ONE launch (`flush`).  Each deferred layer keeps its own workspace alive until then; the i-th layer of a sweep reuses the
+    i-th buffer of the previous sweep."""
+
+    def __init__(self):
+        self._bufs = []
+        self._jobs = []
+
+    def workspace(self, nbytes: int, device) -> torch.Tensor:
+        i = len(self._jobs)
+        if i == len(self._bufs):
+            self._bufs.append(torch.empty(nbytes, dtype=torch.uint8, device=device))
+        elif self._bufs[i].numel() < nbytes or self._bufs[i].device != device:
+            self._bufs[i] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self._bufs[i]
+
+    def add(self, job) -> None:
+        self._jobs.append(job)
+
+    def flush(self) -> None:
+        if self._jobs:
+            arr = (_lib.WgradJob * len(self._jobs))(*self._jobs)
+            self._jobs = []
+            check(_lib.load().mg_wino3x3_wgrad_reduce(ctypes.cast(arr, ctypes.c_void_p), len(arr), _s()), "mg_wino3x3_wgrad_reduce")
+
+
+def conv3x3_wgrad(x, gy, gw, gb, *, ups=False, accumulate=False, bias_n: int = 0, defer: Optional[WgradDefer] = None):
+    """gw[Cout,Cin,3,3] (+)= wgrad(x, gy); gb[Cout] (+)= sum gy over samples n < bias_n (0: all; gb may be None).
+    `defer`: leave the Winograd kernel's slab reduction to defer.flush() (gw / gb are not valid before it)."""
     _chk(x, gy, gw, gb)
     n, cout, h, w = gy.shape
     cin = x.shape[1]
     lib = _lib.load()
+    if defer is not None and not accumulate and wino_wgrad_supported(n, cin, cout, h, w, ups=ups):
+        ws = defer.workspace(lib.mg_wino3x3_wgrad_ws_bytes(n, cin, cout, h, w), x.device)
+        job = _lib.WgradJob()
+        check(lib.mg_wino3x3_wgrad_partial(_p(x), _p(gy), _p(gw), _p(gb), _p(ws), ws.numel(), n, cin, cout, h, w,
+                                           MG_CONV_UPS_IN if ups else 0, 0, int(bias_n), ctypes.byref(job), _s()),
+              "mg_wino3x3_wgrad_partial")
+        defer.add(job)
+        return
     if wino_wgrad_supported(n, cin, cout, h, w, ups=ups):
         ws = workspace(lib.mg_wino3x3_wgrad_ws_bytes(n, cin, cout, h, w), x.device)
         check(lib.mg_wino3x3_wgrad(_p(x), _p(gy), _p(gw), _p(gb), _p(ws), ws.numel(), n, cin, cout, h, w,

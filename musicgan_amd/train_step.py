@@ -42,6 +42,8 @@ class ProGANStepper:
         self.dp = is_distributed()
         self.use_graphs = (not self.dp) and fused_d_step and os.environ.get("MG_GRAPHS", "1") != "0"
         self._graphs: Dict[tuple, dict] = {}
+        from . import ops
+        self._defer_d, self._defer_g = ops.WgradDefer(), ops.WgradDefer()  # one-launch weight-gradient reductions per sweep
         self._fade: Optional[torch.Tensor] = None   # [alpha, 1 - alpha] read by the captured fade-in kernels
         self._fade_value: Optional[float] = None
         self.bucket_d = GradBucket()
@@ -115,7 +117,8 @@ class ProGANStepper:
             W = self.disc._weights()
             sink = engine.GradSink(*self.bucket_d.flat_sink(W.tensors())) if self.dp else engine.GradSink()
             disc_loss, grad_pen, out, stats = engine.disc_step_fused(W, xcat[:n], xcat[n:2 * n], eps, alpha,
-                                                                     self.disc._pack_cache, sink, xcat=xcat)
+                                                                     self.disc._pack_cache, sink, xcat=xcat,
+                                                                     defer=self._defer_d)
         self.gen.zero_grad()
         self.disc.zero_grad()
         for p in W.tensors():
@@ -169,7 +172,7 @@ class ProGANStepper:
             Wg, Wd = self.gen._weights(), self.disc._weights()
             sink = engine.GradSink(*self.bucket_g.flat_sink(Wg.tensors())) if self.dp else engine.GradSink()
             gen_loss, out, stats = engine.gen_step_fused(Wg, Wd, z, alpha, self.gen._pack_cache, self.disc._pack_cache, sink,
-                                                         before_disc=before_disc)
+                                                         before_disc=before_disc, defer=self._defer_g)
         self.gen.zero_grad()
         self.disc.zero_grad()
         for p in Wg.tensors():
