@@ -386,6 +386,37 @@ def main():
         cadence = {"cadence": "5 critic updates : 1 generator update (reference train.py:189)", "cycles": ncyc,
                    "ms_per_cycle": 1e3 * tc / ncyc, "images_per_s": 5 * args.batch * ncyc / tc}
 
+    # BASELINE.json configs[4], the N-GPU half: STFT + codec preprocessing sharded by file (create_dataset.py: independent
+    # units, no collective on the data path) -- every rank transforms its own synthetic 10-minute file between two barriers;
+    # the whole-job figure is all ranks' frames over the slowest rank's time.
+    stft_sharded = None
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+    if dist_on and (world > 1 or os.environ.get("MG_FORCE_DP") == "1") and not args.no_extra:  # (1 rank: rehearsal only)
+        from musicgan_amd import audio, ops
+        wav = torch.rand(44100 * 600, device=device, generator=torch.Generator(device=device).manual_seed(7 + rank)) - 0.5
+        frames = 1 + wav.numel() // 256
+        for _ in range(4):
+            audio.stft_to_phase_magn(ops.stft_1024(wav))
+        torch.cuda.synchronize()
+        barrier()
+        reps = 10
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t1 = time.perf_counter()
+        s0.record(torch.cuda.current_stream())
+        for _ in range(reps):
+            audio.stft_to_phase_magn(ops.stft_1024(wav))
+        s1.record(torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t1
+        if rank == 0:
+            print(f"stft_sharded rank 0: {1e3 * wall / reps:.3f} ms/file wall, {s0.elapsed_time(s1) / reps:.3f} ms/file on the stream",
+                  file=sys.stderr, flush=True)
+        dt = torch.tensor([wall], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
+        stft_sharded = {"workload": "one 10-minute 44.1 kHz file per rank through mg_stft_1024 + mg_codec_fwd, sharded by file",
+                        "n_gpus": world, "frames_per_s": world * reps * frames / float(dt.item()),
+                        "samples_per_s": world * reps * ((frames - 1) // 512) / float(dt.item()), "scaling": "weak"}
+
     if os.environ.get("MG_BENCH_CHECKSUM") and rank == 0:
         cs = sum(float(p.detach().double().abs().sum()) for p in list(gen.parameters()) + list(disc.parameters()))
         print(f"weights_abs_sum {cs:.10e}", file=sys.stderr, flush=True)
@@ -415,6 +446,8 @@ def main():
         }
         if cadence is not None:
             line["secondary"] = cadence
+        if stft_sharded is not None:
+            line["stft_sharded"] = stft_sharded
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.level, args.rand_channels, args.cpu_batch, iters=2)
         if world == 1 and not args.no_extra and args.level == 5:
