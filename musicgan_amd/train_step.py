@@ -198,7 +198,11 @@ class ProGANStepper:
             return self._d_step_fused(a[0], fade, a[1], a[2]) if kind == "D" else self._g_step_fused(a[0], fade)
         ent = self._graphs.get(key)
         if ent is None:
-            if len(self._graphs) > 8:  # growth / new batch shapes: drop graphs (and their private memory pools) of the past
+            # growth or a new batch shape: graphs of other levels (and their private memory pools, GBs at the large levels)
+            # are never replayed again
+            for k in [k for k in self._graphs if k[1] != key[1]]:
+                del self._graphs[k]
+            if len(self._graphs) > 8:
                 self._graphs.clear()
             ent = self._graphs[key] = {"calls": 0}
         if "graph" not in ent:
@@ -216,7 +220,8 @@ class ProGANStepper:
                 self._fade = torch.zeros(2, dtype=torch.float32, device=inputs[0].device)
             from .networks.engine import FadeIn
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: loader threads (pinned-memory staging, uploads on their own stream) keep working during the capture
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 m = run(FadeIn(alpha, dev=self._fade), *ent["inputs"])
                 ent["names"] = list(m.keys())
                 ent["out"] = torch.stack([m[k].reshape(()) for k in ent["names"]])
