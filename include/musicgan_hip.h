@@ -91,6 +91,11 @@ int mg_wino3x3_wgrad_partial(const float* x, const float* gy, float* gw, float* 
                              int Cout, int H, int W, int flags, int accumulate, int bias_n, mg_wgrad_job_t* job,
                              mg_stream_t stream);
 int mg_wino3x3_wgrad_reduce(const mg_wgrad_job_t* jobs, int n, mg_stream_t stream);
+/* the same split of mg_conv3x3_wgrad (the direct form's jobs carry CoutP = CinP = 0 and go to their own reduce) */
+int mg_conv3x3_wgrad_partial(const float* x, const float* gy, float* gw, float* gb, void* ws, size_t ws_bytes, int N, int Cin,
+                             int Cout, int H, int W, int flags, int accumulate, int bias_n, mg_wgrad_job_t* job,
+                             mg_stream_t stream);
+int mg_conv3x3_wgrad_reduce(const mg_wgrad_job_t* jobs, int n, mg_stream_t stream);
 
 /* Data gradient of Upsample(x2) -> Conv3x3 w.r.t. the LOW-resolution input: one stride-2 convolution with the 4x4 effective
  * kernel over gy (N,Cout,2Hin,2Win) -> gx (N,Cin,Hin,Win); replaces conv-dgrad at 2Hx2W + the 2x2 block sums of Upsample's

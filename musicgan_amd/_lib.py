@@ -62,6 +62,9 @@ SIGNATURES = {
     "mg_wino3x3_wgrad_partial": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
                                          _P]),
     "mg_wino3x3_wgrad_reduce": (c_int, [_P, c_int, _P]),
+    "mg_conv3x3_wgrad_partial": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
+                                         _P]),
+    "mg_conv3x3_wgrad_reduce": (c_int, [_P, c_int, _P]),
     "mg_upconv3x3_dgrad_packed_floats": (c_size_t, [c_int, c_int]),
     "mg_upconv3x3_dgrad_pack": (c_int, [_P, _P, c_int, c_int, _P]),
     "mg_upconv3x3_dgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),

@@ -322,14 +322,14 @@ __global__ void __launch_bounds__(WO == 1 ? 768 : 512) wgrad3x3_mfma(const Wgrad
 
 // Sum the split-K slabs in a fixed order.  Block = 64 consecutive slab elements x 4 split-lanes (each lane sums every 4th
 // split, 4 loads in flight), LDS-combined as ((l0 + l1) + (l2 + l3)) => deterministic.
-__global__ void __launch_bounds__(256) wgrad3x3_reduce(const float* __restrict__ slab, const float* __restrict__ slab_b,
-                                                       int nsplit, float* __restrict__ gw, float* __restrict__ gb,
-                                                       int Cout, int Cin, int accumulate) {
+__device__ __forceinline__ void wgrad3x3_reduce_body(const float* __restrict__ slab, const float* __restrict__ slab_b,
+                                                     int nsplit, float* __restrict__ gw, float* __restrict__ gb,
+                                                     int Cout, int Cin, int accumulate, int block) {
   __shared__ float red[4][64];
   const int total = 9 * Cout * Cin;
   const int all = total + (gb != nullptr ? Cout : 0);
   const int el = threadIdx.x & 63, kl = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + el;
+  const int e = block * 64 + el;
   float s = 0.f;
   if (e < all) {
     const float* src = e < total ? slab + e : slab_b + (e - total);
@@ -361,6 +361,17 @@ __global__ void __launch_bounds__(256) wgrad3x3_reduce(const float* __restrict__
       gb[o] = accumulate ? gb[o] + s : s;
     }
   }
+}
+
+// The reductions of several layers in one launch (jobs by value, blockIdx.y = job; blocks past a job's extent return).
+constexpr int WG_JOBS = 40;
+struct WgJobs {
+  mg_wgrad_job_t j[WG_JOBS];
+};
+__global__ void __launch_bounds__(256) wgrad3x3_reduce_multi(const WgJobs jobs) {
+  const mg_wgrad_job_t j = jobs.j[blockIdx.y];
+  if ((int)blockIdx.x * 64 >= 9 * j.Cout * j.Cin + j.Cout) return;
+  wgrad3x3_reduce_body(j.slab, j.slab_b, j.nsplit, j.gw, j.gb, j.Cout, j.Cin, j.accumulate, blockIdx.x);
 }
 
 struct WgradPlan {
@@ -490,10 +501,10 @@ extern "C" size_t mg_conv3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int
   return pl.ws_floats * sizeof(float);
 }
 
-extern "C" int mg_conv3x3_wgrad(const float* x, const float* gy, float* gw, float* gb, void* ws, size_t ws_bytes, int N,
-                                int Cin, int Cout, int H, int W, int flags, int accumulate, int bias_n,
-                                mg_stream_t stream) {
-  MG_CHECK_ARG(x && gy && gw && ws && N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "mg_conv3x3_wgrad: bad arguments");
+extern "C" int mg_conv3x3_wgrad_partial(const float* x, const float* gy, float* gw, float* gb, void* ws, size_t ws_bytes, int N,
+                                        int Cin, int Cout, int H, int W, int flags, int accumulate, int bias_n,
+                                        mg_wgrad_job_t* job, mg_stream_t stream) {
+  MG_CHECK_ARG(x && gy && gw && ws && job && N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "mg_conv3x3_wgrad: bad arguments");
   const bool ups = flags & MG_CONV_UPS_IN;
   MG_CHECK_ARG(!ups || ((H % 2 == 0) && (W % 2 == 0)), "mg_conv3x3_wgrad: upsampled input needs even H,W");
   const long long in_elems = (long long)N * Cin * (ups ? (H / 2) * (W / 2) : H * W);
@@ -514,9 +525,34 @@ extern "C" int mg_conv3x3_wgrad(const float* x, const float* gy, float* gw, floa
   a.bias_n = (bias_n <= 0 || bias_n > N) ? N : bias_n;
   const int rc = dispatch_wgrad(pl, s);
   if (rc != MG_OK) return rc;
-  const int total = 9 * Cout * Cin + Cout;
-  hipLaunchKernelGGL(wgrad3x3_reduce, dim3(mg_cdiv(total, 64)), dim3(256), 0, s, a.slab, a.slab_b, pl.nsplit, gw, gb,
-                     Cout, Cin, accumulate);
-  MG_CHECK_LAUNCH("mg_conv3x3_wgrad(reduce)");
+  job->slab = a.slab; job->slab_b = a.slab_b; job->gw = gw; job->gb = gb;
+  job->nsplit = pl.nsplit; job->Cout = Cout; job->Cin = Cin; job->CoutP = 0; job->CinP = 0; job->accumulate = accumulate;
   return MG_OK;
+}
+
+extern "C" int mg_conv3x3_wgrad_reduce(const mg_wgrad_job_t* jobs, int n, mg_stream_t stream) {
+  MG_CHECK_ARG(jobs && n > 0, "mg_conv3x3_wgrad_reduce: bad arguments");
+  for (int first = 0; first < n; first += WG_JOBS) {
+    const int m = n - first < WG_JOBS ? n - first : WG_JOBS;
+    WgJobs c;
+    int most = 0;
+    for (int i = 0; i < m; ++i) {
+      c.j[i] = jobs[first + i];
+      MG_CHECK_ARG(c.j[i].slab && c.j[i].gw && c.j[i].nsplit > 0 && c.j[i].Cout > 0 && c.j[i].Cin > 0,
+                   "mg_conv3x3_wgrad_reduce: bad job %d", first + i);
+      const int blocks = mg_cdiv(9 * c.j[i].Cout * c.j[i].Cin + c.j[i].Cout, 64);
+      if (blocks > most) most = blocks;
+    }
+    hipLaunchKernelGGL(wgrad3x3_reduce_multi, dim3(most, m), dim3(256), 0, (hipStream_t)stream, c);
+    MG_CHECK_LAUNCH("mg_conv3x3_wgrad_reduce");
+  }
+  return MG_OK;
+}
+
+extern "C" int mg_conv3x3_wgrad(const float* x, const float* gy, float* gw, float* gb, void* ws, size_t ws_bytes, int N,
+                                int Cin, int Cout, int H, int W, int flags, int accumulate, int bias_n,
+                                mg_stream_t stream) {
+  mg_wgrad_job_t job;
+  const int rc = mg_conv3x3_wgrad_partial(x, gy, gw, gb, ws, ws_bytes, N, Cin, Cout, H, W, flags, accumulate, bias_n, &job, stream);
+  return rc != MG_OK ? rc : mg_conv3x3_wgrad_reduce(&job, 1, stream);
 }

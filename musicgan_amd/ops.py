@@ -230,24 +230,28 @@ class WgradDefer:
 
     def __init__(self):
         self._bufs = []
-        self._jobs = []
+        self._jobs = []      # Winograd form
+        self._jobs_d = []    # direct form
 
     def workspace(self, nbytes: int, device) -> torch.Tensor:
-        i = len(self._jobs)
+        i = len(self._jobs) + len(self._jobs_d)
         if i == len(self._bufs):
             self._bufs.append(torch.empty(nbytes, dtype=torch.uint8, device=device))
         elif self._bufs[i].numel() < nbytes or self._bufs[i].device != device:
             self._bufs[i] = torch.empty(nbytes, dtype=torch.uint8, device=device)
         return self._bufs[i]
 
-    def add(self, job) -> None:
-        self._jobs.append(job)
+    def add(self, job, direct: bool = False) -> None:
+        (self._jobs_d if direct else self._jobs).append(job)
 
     def flush(self) -> None:
-        if self._jobs:
-            arr = (_lib.WgradJob * len(self._jobs))(*self._jobs)
-            self._jobs = []
-            check(_lib.load().mg_wino3x3_wgrad_reduce(ctypes.cast(arr, ctypes.c_void_p), len(arr), _s()), "mg_wino3x3_wgrad_reduce")
+        lib = _lib.load()
+        for jobs, fn, what in ((self._jobs, lib.mg_wino3x3_wgrad_reduce, "mg_wino3x3_wgrad_reduce"),
+                               (self._jobs_d, lib.mg_conv3x3_wgrad_reduce, "mg_conv3x3_wgrad_reduce")):
+            if jobs:
+                arr = (_lib.WgradJob * len(jobs))(*jobs)
+                check(fn(ctypes.cast(arr, ctypes.c_void_p), len(arr), _s()), what)
+        self._jobs, self._jobs_d = [], []
 
 
 def conv3x3_wgrad(x, gy, gw, gb, *, ups=False, accumulate=False, bias_n: int = 0, defer: Optional[WgradDefer] = None):
@@ -264,6 +268,14 @@ def conv3x3_wgrad(x, gy, gw, gb, *, ups=False, accumulate=False, bias_n: int = 0
                                            MG_CONV_UPS_IN if ups else 0, 0, int(bias_n), ctypes.byref(job), _s()),
               "mg_wino3x3_wgrad_partial")
         defer.add(job)
+        return
+    if defer is not None and not accumulate:
+        ws = defer.workspace(lib.mg_conv3x3_wgrad_ws_bytes(n, cin, cout, h, w), x.device)
+        job = _lib.WgradJob()
+        check(lib.mg_conv3x3_wgrad_partial(_p(x), _p(gy), _p(gw), _p(gb), _p(ws), ws.numel(), n, cin, cout, h, w,
+                                           MG_CONV_UPS_IN if ups else 0, 0, int(bias_n), ctypes.byref(job), _s()),
+              "mg_conv3x3_wgrad_partial")
+        defer.add(job, direct=True)
         return
     if wino_wgrad_supported(n, cin, cout, h, w, ups=ups):
         ws = workspace(lib.mg_wino3x3_wgrad_ws_bytes(n, cin, cout, h, w), x.device)
