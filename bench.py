@@ -3,7 +3,7 @@
 generator update, Adam on both -- /root/reference/music_gan/train.py:143-175,191-214) on synthetic 2x128x128 STFT tensors,
 batch 64 per GPU, level 5 with the fade-in branch live (alpha = 0.5).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -296,8 +296,8 @@ def cpu_baseline(level: int, rand_channels: int, batch: int, iters: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)    # >= 10 warm-up, >= 50 timed iterations
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--level", type=int, default=5, choices=[3, 4, 5, 6, 7])
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--rand-channels", type=int, default=32)
