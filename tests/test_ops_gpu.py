@@ -553,3 +553,89 @@ def test_pack_multi_equals_single_tensor_packs():
     ops.pack_multi(reqs)
     for (kind, w, dgrad, out), ref in zip(reqs, refs):
         assert torch.equal(out, ref), (kind, tuple(w.shape), dgrad)
+
+
+# ------------------------------------------------------------------ round-2 kernels on ragged shapes
+@pytest.mark.parametrize("shape", [(3, 100, 40, 4, 4), (5, 72, 24, 2, 2), (96, 128, 128, 4, 4), (7, 136, 150, 3, 5), (2, 64, 16, 8, 8)])
+def test_conv3x3_split_k_small_maps(shape, monkeypatch):
+    """The split-K variant of the direct conv (maps <= 8x8, <= 1536 pixels, >= 8 chunks): ragged last chunk, ragged out-channel tile,
+    odd map sizes -- against F.conv2d in fp64, bit-identical layout paths with bias + LeakyReLU and with the mask epilogue."""
+    ops = _ops()
+    n, ci, co, h, w = shape
+    g = torch.Generator().manual_seed(81)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(9 * ci)
+    b = torch.randn(co, generator=g)
+    wp = ops.pack_conv3x3(wt.to(DEV), dgrad=False)
+    ref = F.leaky_relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1), 0.2)
+    report("split-K conv + bias + lrelu", ops.conv3x3(x.to(DEV), wp, b.to(DEV), co, lrelu=True), ref, 1e-5)
+    aux = torch.randn(n, co, h, w, generator=g)
+    ref = F.conv2d(x.double(), wt.double(), None, padding=1) * torch.where(aux > 0, 1.0, 0.2).double()
+    report("split-K conv + mask", ops.conv3x3(x.to(DEV), wp, None, co, mask_aux=aux.to(DEV)), ref, 1e-5)
+    monkeypatch.setenv("MG_CONV_NOKSPLIT", "1")
+    a = ops.conv3x3(x.to(DEV), wp, b.to(DEV), co, lrelu=True)
+    monkeypatch.delenv("MG_CONV_NOKSPLIT")
+    report("split-K vs plain direct conv", ops.conv3x3(x.to(DEV), wp, b.to(DEV), co, lrelu=True), a.double(), 2e-6)
+
+
+@pytest.mark.parametrize("shape", [(3, 37, 5, 7), (32, 128, 4, 4), (1, 160, 2, 2), (64, 112, 8, 8), (2, 33, 16, 16)])
+def test_pixelnorm_fwd_small_maps(shape):
+    """The split-channel PixelNorm kernel (<= 2^17 pixels): pixel counts that do not fill a 64-pixel workgroup, channel counts that
+    are no multiple of 4."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(82)
+    y = torch.randn(*shape, generator=g) * 3
+    p, rn = ops.pixelnorm_fwd(y.to(DEV))
+    ref_rn = 1.0 / torch.sqrt(y.double().pow(2).mean(dim=1, keepdim=True) + 1e-8)
+    report("pixelnorm p", p, y.double() * ref_rn, 2e-6)
+    report("pixelnorm rn", rn, ref_rn, 2e-6)
+
+
+@pytest.mark.parametrize("case", [(3, 37, 2, 5, 9), (32, 64, 2, 64, 64), (2, 160, 1, 7, 7), (4, 16, 4, 33, 3)])
+def test_conv1x1_few_out_split_channels(case):
+    """The few-out 1x1 conv on < 2^20-pixel maps (4 waves split the input channels): odd pixel counts, Cin not a multiple of 4,
+    with tanh (the generator head) and with the input-side mask (the critic's input gradient)."""
+    ops = _ops()
+    n, ci, co, h, w = case
+    g = torch.Generator().manual_seed(83)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 1, 1, generator=g) / math.sqrt(ci)
+    b = torch.randn(co, generator=g)
+    ref = torch.tanh(F.conv2d(x.double(), wt.double(), b.double()))
+    report("few-out + tanh", ops.conv1x1(x.to(DEV), wt.to(DEV), b.to(DEV), co, tanh=True), ref, 2e-6)
+    aux = torch.randn(n, ci, h, w, generator=g)
+    wt_t = torch.randn(ci, co, 1, 1, generator=g) / math.sqrt(ci)  # module weight of a co -> ci conv, applied transposed
+    ref = F.conv2d(x.double() * torch.where(aux > 0, 1.0, 0.2).double(), wt_t.double().permute(1, 0, 2, 3))
+    report("few-out transposed + input mask", ops.conv1x1(x.to(DEV), wt_t.to(DEV), None, co, transposed=True, mask_aux=aux.to(DEV)),
+           ref, 2e-6)
+
+
+def test_group_means_and_deferred_wgrad_reduce():
+    """mg_group_means (score means + Wasserstein losses, one launch) against torch, and the deferred one-launch weight-gradient
+    reduction (Winograd and direct jobs mixed in one sweep) bit-identical to the immediate form."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(84)
+    for groups, n in ((3, 5), (3, 64), (1, 300), (2, 1000)):
+        s = torch.randn(groups * n, 1, generator=g) * 7
+        out = ops.group_means(s.to(DEV), groups).cpu().double()
+        m = s.double().reshape(groups, n).mean(dim=1)
+        assert float((out[:groups] - m).abs().max()) <= 1e-6 * float(m.abs().max() + 1)
+        want = float(m[1] - m[0]) if groups >= 2 else float(-m[0])
+        assert abs(float(out[groups]) - want) <= 2e-6 * (abs(want) + 1)
+    defer = ops.WgradDefer()
+    layers = [(6, 48, 64, 64, 64, False), (6, 16, 32, 4, 4, False), (6, 64, 48, 64, 64, True), (6, 96, 112, 16, 16, False),
+              (6, 144, 160, 2, 2, False)]
+    want, got = [], []
+    for n, ci, co, h, w, ups in layers:
+        x = torch.randn(n, ci, h // 2 if ups else h, w // 2 if ups else w, generator=g).to(DEV)
+        gy = torch.randn(n, co, h, w, generator=g).to(DEV)
+        gw0, gb0 = torch.empty(co, ci, 3, 3, device=DEV), torch.empty(co, device=DEV)
+        ops.conv3x3_wgrad(x, gy, gw0, gb0, ups=ups, bias_n=4)
+        gw1, gb1 = torch.full((co, ci, 3, 3), float("nan"), device=DEV), torch.full((co,), float("nan"), device=DEV)
+        ops.conv3x3_wgrad(x, gy, gw1, gb1, ups=ups, bias_n=4, defer=defer)
+        want.append((gw0, gb0))
+        got.append((gw1, gb1))
+    assert len(defer._jobs) >= 2 and len(defer._jobs_d) >= 2  # both kernel families took part
+    defer.flush()
+    for (a, b), (c, d) in zip(want, got):
+        assert torch.equal(a, c) and torch.equal(b, d)
