@@ -44,6 +44,14 @@ const char* mg_last_error(void);
 #define MG_CONV_MASK_AUX 4 /* y = acc * (aux > 0 ? 1 : slope): LeakyReLU backward fused on the output (aux: N,Cout,H,W) */
 #define MG_CONV_PIXNORM 8  /* also emit p = y * rn and rn = 1/sqrt(mean_c(y^2)+1e-8) (needs MG_CONV_LRELU) */
 #define MG_CONV_POOL_OUT 16 /* also emit p = AvgPool2d(2,2)(y) (N,Cout,H/2,W/2) [discriminator.py:24]; excludes PIXNORM */
+/* Tile masks (mg_wino3x3 only): what the backward pass of conv -> LeakyReLU -> AvgPool2d [discriminator.py:15-24] needs of the
+ * full-resolution activation is its sign, so the forward pass can keep one BYTE per 2x2 tile and out-channel instead of four
+ * floats: bit 2i+j set <=> y[2Y+i][2X+j] > 0, tensor (N,Cout,H/2,W/2) of uint8. */
+#define MG_CONV_MASK_OUT 32   /* with POOL_OUT|LRELU: y (cast to uint8_t*) receives the tile mask; the fp32 y is not written */
+#define MG_CONV_MASK_BYTES 64 /* with MASK_AUX|POOL_OUT: aux (cast to const uint8_t*) is the tile mask of THIS conv's output; only p is written */
+#define MG_CONV_UNPOOL 128    /* alone: aux = tile mask with one byte per OUTPUT PIXEL (N,Cout,H,W) of this conv; y is (N,Cout,2H,2W): \
+                                 y[2Y+i][2X+j] = 0.25 * acc[Y][X] * (bit 2i+j ? 1 : slope), i.e. AvgPool2d backward and the LeakyReLU \
+                                 backward of the layer below fused on the data-gradient conv that feeds them */
 
 /* number of floats of the packed (LDS-image) weight layout for a Cin->Cout conv */
 size_t mg_conv3x3_packed_floats(int Cin, int Cout);
@@ -146,6 +154,10 @@ int mg_upsample2x_bwd(const float* gy, float* gx, int NC, int Hin, int Win, mg_s
 int mg_avgpool2_fwd(const float* x, float* y, int NC, int H, int W, mg_stream_t stream);
 int mg_avgpool2_bwd(const float* gy, const float* act, float* gx, int NC, int H, int W, float slope,
                     mg_stream_t stream);
+/* the same with the mask given as tile bytes (MG_CONV_MASK_OUT above: (NC,H/2,W/4*2) uint8, bit 2i+j <-> act[2h+i][2w+j] > 0);
+ * W must be a multiple of 4 */
+int mg_avgpool2_bwd_tilemask(const float* gy, const unsigned char* mask, float* gx, int NC, int H, int W, float slope,
+                             mg_stream_t stream);
 /* out = g * (act > 0 ? 1 : slope) */
 int mg_lrelu_bwd(const float* g, const float* act, float* out, size_t n, float slope, mg_stream_t stream);
 /* backward of the critic's fade-in blend [discriminator.py:111-113] and of the two LeakyReLUs feeding it, in one pass:

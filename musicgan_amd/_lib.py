@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmusicgan_hip.so")
 
 MG_CONV_UPS_IN, MG_CONV_LRELU, MG_CONV_MASK_AUX, MG_CONV_PIXNORM, MG_CONV_POOL_OUT = 1, 2, 4, 8, 16
+MG_CONV_MASK_OUT, MG_CONV_MASK_BYTES, MG_CONV_UNPOOL = 32, 64, 128
 MG_C1_LRELU, MG_C1_TANH, MG_C1_MASK_AUX, MG_C1_TRANSPOSED, MG_C1_TANH_BWD_IN = 1, 2, 4, 8, 16
 
 
@@ -79,6 +80,7 @@ SIGNATURES = {
     "mg_upsample2x_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "mg_avgpool2_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "mg_avgpool2_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, _P]),
+    "mg_avgpool2_bwd_tilemask": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "mg_lrelu_bwd": (c_int, [_P, _P, _P, c_size_t, c_float, _P]),
     "mg_blend_lrelu_bwd": (c_int, [_P, _P, _P, c_float, c_float, _P, _P, c_size_t, c_float, _P]),
     "mg_axpby": (c_int, [c_float, _P, c_float, _P, _P, c_size_t, _P]),

@@ -248,6 +248,32 @@ __global__ void __launch_bounds__(256) avgpool2_bwd_k(const float* __restrict__ 
   }
 }
 
+// the same with the mask as tile bytes (MG_CONV_MASK_OUT of mg_wino3x3: bit 2i+j of byte [nc][h][w] <-> act[2h+i][2w+j] > 0).
+// One thread per PAIR of pooled elements: 8-byte gradient load, 2-byte mask load, two 16-byte stores.
+__global__ void __launch_bounds__(256) avgpool2_bwd_bytes_k(const float* __restrict__ gy, const unsigned char* __restrict__ mask,
+                                                            float* __restrict__ gx, size_t pairs, int Ho, int Wo2,
+                                                            float slope) {
+  const float qh = 0.25f, ql = 0.25f * slope;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x) {
+    const int w2 = (int)(i % Wo2);
+    const size_t r = i / Wo2;
+    const int h = (int)(r % Ho);
+    const size_t nc = r / Ho;
+    const float2 g = *reinterpret_cast<const float2*>(gy + 2 * i);
+    const unsigned m = *reinterpret_cast<const unsigned short*>(mask + 2 * i);
+    const size_t o = (nc * (2 * Ho) + 2 * h) * (size_t)(4 * Wo2) + 4 * w2;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      float4 v;
+      v.x = g.x * (((m >> (2 * rr)) & 1u) ? qh : ql);
+      v.y = g.x * (((m >> (2 * rr + 1)) & 1u) ? qh : ql);
+      v.z = g.y * (((m >> (8 + 2 * rr)) & 1u) ? qh : ql);
+      v.w = g.y * (((m >> (9 + 2 * rr)) & 1u) ? qh : ql);
+      *reinterpret_cast<float4*>(gx + o + (size_t)rr * (4 * Wo2)) = v;
+    }
+  }
+}
+
 // `coef` (optional, all three fade-in kernels): the two coefficients in DEVICE memory instead of launch arguments, so that a
 // captured HIP graph of an update stays valid while alpha moves through the fade-in (the values, hence the results, are the same)
 __global__ void __launch_bounds__(256) blend_up_k(float a, const float* __restrict__ x, float b,
@@ -602,6 +628,16 @@ extern "C" int mg_avgpool2_bwd(const float* gy, const float* act, float* gx, int
   const size_t total = (size_t)NC * (H / 2) * (W / 2);
   EW_LAUNCH(avgpool2_bwd_k, ew_grid(total), 256, gy, act, gx, total, H / 2, W / 2, slope);
   MG_CHECK_LAUNCH("mg_avgpool2_bwd");
+  return MG_OK;
+}
+
+extern "C" int mg_avgpool2_bwd_tilemask(const float* gy, const unsigned char* mask, float* gx, int NC, int H, int W, float slope,
+                                        mg_stream_t stream) {
+  MG_CHECK_ARG(gy && mask && gx && NC > 0 && H > 0 && W > 0 && (H % 2 == 0) && (W % 4 == 0),
+               "mg_avgpool2_bwd_tilemask: bad arguments (W must be a multiple of 4)");
+  const size_t pairs = (size_t)NC * (H / 2) * (W / 4);
+  EW_LAUNCH(avgpool2_bwd_bytes_k, ew_grid(pairs), 256, gy, mask, gx, pairs, H / 2, W / 4, slope);
+  MG_CHECK_LAUNCH("mg_avgpool2_bwd_tilemask");
   return MG_OK;
 }
 

@@ -301,9 +301,29 @@ __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(co
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));
   };
   const size_t pixw = odd ? pix0 - 2 + a.W : pix0;  // even: row 2TY of the pair; odd: row 2TY+1 of the pair
-  auto store_tile = [&](int ni, float (&on)[4][4], const float (&rnv)[4], auto mask_, auto pn_, auto pool_, auto hasy_) {
-    constexpr bool MASK = decltype(mask_)::value, PN = decltype(pn_)::value, POOL = decltype(pool_)::value,
-                   HASY = decltype(hasy_)::value;
+  auto store_tile = [&](int ni, float (&on)[4][4], const float (&rnv)[4], auto mask_, auto pn_, auto pool_, auto hasy_,
+                        auto mout_) {
+    constexpr int MASKK = decltype(mask_)::value;  // 0: none, 1: aux = fp32 activations (N,Cout,H,W), 2: aux = tile bytes
+    constexpr bool MASK = MASKK == 1, PN = decltype(pn_)::value, POOL = decltype(pool_)::value,
+                   HASY = decltype(hasy_)::value, MOUT = decltype(mout_)::value;
+    if constexpr (MASKK == 2 || MOUT) {  // one byte per 2x2 tile and out-channel, bit 2i+j <-> pixel (i, j): the lane's own tile
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int oc = oc0 + ni * 16 + g;
+        const bool act = tok && oc < a.Cout;
+        const size_t ti = pp0 + (size_t)oc * (Ht * Wt);
+        if constexpr (MASKK == 2) {
+          const unsigned mb = act ? (unsigned)reinterpret_cast<const unsigned char*>(a.aux)[ti] : 15u;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) on[g][q] *= ((mb >> q) & 1u) ? 1.f : a.slope;
+        }
+        if constexpr (MOUT) {
+          const unsigned mb = (on[g][0] > 0.f ? 1u : 0u) | (on[g][1] > 0.f ? 2u : 0u) | (on[g][2] > 0.f ? 4u : 0u) |
+                              (on[g][3] > 0.f ? 8u : 0u);
+          if (act) reinterpret_cast<unsigned char*>(a.y)[ti] = (unsigned char)mb;
+        }
+      }
+    }
     if (wide) {
       f32x4 rnw = f32x4{1.f, 1.f, 1.f, 1.f};
       if constexpr (PN) {
@@ -363,15 +383,68 @@ __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(co
     }
   };
   // no PixelNorm: one out-channel tile at a time (16 live outputs)
-  auto tail = [&](auto mask_, auto pool_) {
+  auto tail = [&](auto mask_, auto pool_, auto hasy_, auto mout_) {
     const float one[4] = {1.f, 1.f, 1.f, 1.f};
-    constexpr bool MASKED = decltype(mask_)::value;
+    constexpr bool MASKED = decltype(mask_)::value != 0;
 #pragma unroll
     for (int ni = 0; ni < NIW; ++ni) {
       float on[4][4];
       if (MASKED && a.bias == nullptr) transform(ni, on, std::false_type{});  // MASK_AUX excludes LRELU; no bias: plain A^T M A
       else transform(ni, on, std::true_type{});
-      store_tile(ni, on, one, mask_, std::false_type{}, pool_, std::true_type{});
+      store_tile(ni, on, one, mask_, std::false_type{}, pool_, hasy_, mout_);
+    }
+  };
+  // MG_CONV_UNPOOL: y (N,Cout,2H,2W) = AvgPool2d backward of the result, times the LeakyReLU mask of the layer below it
+  // (aux: one byte per OUTPUT PIXEL of this convolution = per 2x2 block of y).  A lane of the wide path holds one image row of
+  // a tile pair (4 pixels, 4 mask bytes = one dword) and writes 2 rows x 8 floats; y index of pixel (Y, X) = 4*idx - 2*X.
+  auto tail_unpool = [&]() {
+    const unsigned char* mb = reinterpret_cast<const unsigned char*>(a.aux);
+    const float qh = 0.25f, ql = 0.25f * a.slope;
+    const int W2 = 2 * a.W;
+#pragma unroll
+    for (int ni = 0; ni < NIW; ++ni) {
+      float on[4][4];
+      transform(ni, on, std::false_type{});
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int oc = oc0 + ni * 16 + g;
+        const bool act = tok && oc < a.Cout;
+        if (wide) {
+          const float r0 = swap1(odd ? on[g][0] : on[g][2]), r1 = swap1(odd ? on[g][1] : on[g][3]);
+          const f32x4 v = odd ? f32x4{r0, r1, on[g][2], on[g][3]} : f32x4{on[g][0], on[g][1], r0, r1};
+          if (act) {
+            const size_t idx = pixw + (size_t)oc * HW;
+            const unsigned mw = *reinterpret_cast<const unsigned*>(mb + idx);
+            float* dst = a.y + 4 * idx - 2 * (size_t)(2 * (TX - (odd ? 1 : 0)));
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+              f32x4 o[2];
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) o[e >> 1][(e & 1) * 2 + j] = v[e] * (((mw >> (8 * e + 2 * r + j)) & 1u) ? qh : ql);
+              *reinterpret_cast<f32x4*>(dst + (size_t)r * W2) = o[0];
+              *reinterpret_cast<f32x4*>(dst + (size_t)r * W2 + 4) = o[1];
+            }
+          }
+        } else if (act) {
+          const size_t idx0 = pix0 + (size_t)oc * HW;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const unsigned mw = *reinterpret_cast<const unsigned short*>(mb + idx0 + (size_t)i * a.W);  // pixels (i, 0), (i, 1)
+            float* dst = a.y + 4 * (idx0 + (size_t)i * a.W) - 2 * (size_t)(2 * TX);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+              f32x4 o;
+#pragma unroll
+              for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) o[e * 2 + j] = on[g][2 * i + e] * (((mw >> (8 * e + 2 * r + j)) & 1u) ? qh : ql);
+              *reinterpret_cast<f32x4*>(dst + (size_t)r * W2) = o;
+            }
+          }
+        }
+      }
     }
   };
   // PixelNorm: all channels of the pixel first (sum of squares over ni, g in-lane, rq by shuffles, wave groups via LDS)
@@ -405,7 +478,8 @@ __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(co
 #pragma unroll
     for (int q = 0; q < 4; ++q) rnv[q] = 1.0f / sqrtf(rnv[q] / (float)a.Cout + PN_EPS);
 #pragma unroll
-    for (int ni = 0; ni < NIW; ++ni) store_tile(ni, o[ni], rnv, std::false_type{}, std::true_type{}, std::false_type{}, hasy_);
+    for (int ni = 0; ni < NIW; ++ni)
+      store_tile(ni, o[ni], rnv, std::integral_constant<int, 0>{}, std::true_type{}, std::false_type{}, hasy_, std::false_type{});
     if (tok && rq == 0 && wc == 0 && a.rn != nullptr && blockIdx.y == 0) {
       const size_t r0 = ((size_t)n * a.H + 2 * TY) * a.W + 2 * TX;
       *reinterpret_cast<float2*>(a.rn + r0) = make_float2(rnv[0], rnv[1]);
@@ -414,15 +488,22 @@ __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(co
   };
   using T_ = std::true_type;
   using F_ = std::false_type;
+  using I0_ = std::integral_constant<int, 0>;
+  using I1_ = std::integral_constant<int, 1>;
+  using I2_ = std::integral_constant<int, 2>;
   if (a.flags & MG_CONV_PIXNORM) {
     if (a.y != nullptr) tail_pn(T_{});
     else tail_pn(F_{});
+  } else if (a.flags & MG_CONV_UNPOOL) {
+    tail_unpool();
   } else if (a.flags & MG_CONV_MASK_AUX) {
-    if (a.flags & MG_CONV_POOL_OUT) tail(T_{}, T_{});
-    else tail(T_{}, F_{});
+    if (a.flags & MG_CONV_MASK_BYTES) tail(I2_{}, T_{}, F_{}, F_{});  // pooled result only
+    else if (a.flags & MG_CONV_POOL_OUT) tail(I1_{}, T_{}, T_{}, F_{});
+    else tail(I1_{}, F_{}, T_{}, F_{});
   } else {
-    if (a.flags & MG_CONV_POOL_OUT) tail(F_{}, T_{});
-    else tail(F_{}, F_{});
+    if (a.flags & MG_CONV_MASK_OUT) tail(I0_{}, T_{}, F_{}, T_{});  // pooled result + tile mask bytes instead of y
+    else if (a.flags & MG_CONV_POOL_OUT) tail(I0_{}, T_{}, T_{}, F_{});
+    else tail(I0_{}, F_{}, T_{}, F_{});
   }
 }
 
@@ -477,11 +558,18 @@ extern "C" int mg_wino3x3(const float* x, const float* up, const float* bias, co
   MG_CHECK_ARG(!(flags & MG_CONV_UPS_IN), "mg_wino3x3: UPS_IN unsupported (use mg_upconv3x3)");
   MG_CHECK_ARG(!(flags & MG_CONV_MASK_AUX) || aux, "mg_wino3x3: MASK_AUX without aux");
   MG_CHECK_ARG(!pn || ((flags & MG_CONV_LRELU) && p), "mg_wino3x3: PIXNORM needs LRELU and p");
-  MG_CHECK_ARG(pn || y, "mg_wino3x3: y is NULL");
+  const bool mask_bytes = flags & MG_CONV_MASK_BYTES, mask_out = flags & MG_CONV_MASK_OUT, unpool = flags & MG_CONV_UNPOOL;
+  MG_CHECK_ARG(pn || y || mask_bytes, "mg_wino3x3: y is NULL");
+  MG_CHECK_ARG(!mask_out || ((flags & MG_CONV_POOL_OUT) && (flags & MG_CONV_LRELU) && !(flags & MG_CONV_MASK_AUX) && !unpool),
+               "mg_wino3x3: MASK_OUT needs POOL_OUT and LRELU");
+  MG_CHECK_ARG(!mask_bytes || ((flags & MG_CONV_MASK_AUX) && (flags & MG_CONV_POOL_OUT) && !unpool),
+               "mg_wino3x3: MASK_BYTES needs MASK_AUX and POOL_OUT (the pooled result is the only output)");
+  MG_CHECK_ARG(!unpool || (aux && y && !(flags & ~MG_CONV_UNPOOL) && !bias), "mg_wino3x3: UNPOOL takes aux and y and no other flag");
   MG_CHECK_ARG(!(flags & MG_CONV_POOL_OUT) || (!pn && p), "mg_wino3x3: POOL_OUT needs p and no PIXNORM");
   MG_CHECK_ARG(!((flags & MG_CONV_MASK_AUX) && (flags & (MG_CONV_LRELU | MG_CONV_PIXNORM))),
                "mg_wino3x3: MASK_AUX excludes LRELU/PIXNORM");
-  MG_CHECK_ARG(!(flags & ~(MG_CONV_LRELU | MG_CONV_PIXNORM | MG_CONV_MASK_AUX | MG_CONV_POOL_OUT)), "mg_wino3x3: unknown flag");
+  MG_CHECK_ARG(!(flags & ~(MG_CONV_LRELU | MG_CONV_PIXNORM | MG_CONV_MASK_AUX | MG_CONV_POOL_OUT | MG_CONV_MASK_OUT |
+                           MG_CONV_MASK_BYTES | MG_CONV_UNPOOL)), "mg_wino3x3: unknown flag");
   MG_CHECK_ARG((long long)N * Cin * H * W < (1ll << 40) && (long long)N * Cout * H * W < (1ll << 40), "mg_wino3x3: tensor too large");
   const int nt = mg_cdiv(Cout, 16);
   MG_CHECK_ARG(!pn || nt <= 4, "mg_wino3x3: PIXNORM needs Cout <= 64 (all channels of a pixel in one workgroup)");

@@ -271,6 +271,14 @@ class DiscWeights:
         return out
 
 
+def _tile_mask_ok(n: int, cin: int, cout: int, h: int, w: int) -> bool:
+    """Tile masks are an epilogue of the Winograd kernel: usable where it runs for the whole batch AND for the third of it that
+    the penalty's tangent pass sends through the same layer again (MG_TILEMASK=0 keeps fp32 activations everywhere)."""
+    if os.environ.get("MG_TILEMASK", "1") == "0" or (w % 4) or (h % 2):
+        return False
+    return ops.wino3x3_supported(max(1, n // 3), cout, h, w, cin=cin)
+
+
 def disc_forward(W: DiscWeights, x: torch.Tensor, alpha: float, cache: PackCache, save: bool):
     x = x.contiguous()
     n = x.shape[0]
@@ -281,7 +289,11 @@ def disc_forward(W: DiscWeights, x: torch.Tensor, alpha: float, cache: PackCache
     xp = o = None
     for i, (w1, b1, w2, b2) in enumerate(W.blocks):
         c1 = w1.shape[0]
-        a1, q1 = cache.conv(inp, w1, False, b1, c1, lrelu=True, pool=True)  # AvgPool2d fused in the epilogue
+        # AvgPool2d fused in the epilogue.  Of the full-resolution activation the backward passes only need the sign, so on the
+        # large maps (Winograd kernel, for every batch slice that will come back with the mask) it is kept as one byte per
+        # 2x2 tile and a1 is that uint8 tile mask (N,c1,H/2,W/2) instead of the fp32 tensor.
+        a1, q1 = cache.conv(inp, w1, False, b1, c1, lrelu=True, pool=True,
+                            mask_out=save and _tile_mask_ok(n, w1.shape[1], c1, inp.shape[2], inp.shape[3]))
         a2 = cache.conv(q1, w2, False, b2, c1, lrelu=True)
         if save:
             saved.append((inp, a1, q1, a2))
@@ -331,8 +343,11 @@ def disc_backward(W: DiscWeights, ctx, g_out: torch.Tensor, cache: PackCache, si
             gw2, acc = sink.slot(w2)
             gb2, _ = sink.slot(b2)
             ops.conv3x3_wgrad(q1, gpre2, gw2, gb2, accumulate=acc)
-        gq1 = cache.conv(gpre2, w2, True, None, c1)
-        gpre1 = ops.avgpool2_bwd(gq1, a1)
+        if a1.dtype == torch.uint8 and ops.wino3x3_supported(n, c1, gpre2.shape[2], gpre2.shape[3], cin=c1):
+            gpre1 = cache.conv(gpre2, w2, True, None, c1, unpool_mask=a1)  # AvgPool2d + LeakyReLU backward in the conv epilogue
+        else:
+            gq1 = cache.conv(gpre2, w2, True, None, c1)
+            gpre1 = ops.avgpool2_bwd(gq1, a1)
         if sink is not None:
             gw1, acc = sink.slot(w1)
             gb1, _ = sink.slot(b1)
@@ -444,7 +459,10 @@ def disc_step_fused(W: DiscWeights, x_real: torch.Tensor, x_fake: torch.Tensor, 
     for i, (w1, b1, w2, b2) in enumerate(W.blocks):
         inp, a1, q1, a2 = saved[i]
         c1 = w1.shape[0]
-        cache.conv(inp[sl], w1, False, None, c1, mask_aux=a1[sl], out=a1[sl], pool_out=q1[sl])
+        if a1.dtype == torch.uint8:
+            cache.conv(inp[sl], w1, False, None, c1, mask_aux=a1[sl], pool_out=q1[sl])
+        else:
+            cache.conv(inp[sl], w1, False, None, c1, mask_aux=a1[sl], out=a1[sl], pool_out=q1[sl])
         cache.conv(q1[sl], w2, False, None, c1, mask_aux=a2[sl], out=a2[sl])
         if i == 0 and W.old_stem is not None:
             target = saved[1][0][sl] if nb > 1 else flat[sl].reshape(a2[sl].shape)

@@ -108,12 +108,27 @@ def wino3x3_supported(n: int, cout: int, h: int, w: int, *, ups=False, pixnorm=F
     return n * h * w >= int(os.environ.get("MG_WINO_MIN_PIXELS", "8192"))  # fewer 2x2 tiles do not fill the chip
 
 
+def _chk_tilemask(m, shape):
+    if not m.is_cuda or m.dtype != torch.uint8 or not m.is_contiguous() or tuple(m.shape) != tuple(shape):
+        raise _lib.MusicGanHipError(f"tile mask must be a contiguous uint8 GPU tensor of shape {tuple(shape)}, got "
+                                    f"{m.dtype} {tuple(m.shape)}")
+
+
 def conv3x3(x, wp, bias, cout: int, *, ups=False, lrelu=False, mask_aux=None, pixnorm=False, want_y=True, out=None,
-            pool=False, pool_out=None, wino=None):
+            pool=False, pool_out=None, wino=None, mask_out=False, unpool_mask=None):
     """`wino` (optional, from pack_wino3x3): run the Winograd F(2x2,3x3) kernel instead of the direct one (`wp` is then unused).
     Returns y, or (y, p, rn) with pixnorm, or (y, pooled) with pool (AvgPool2d(2,2) of y fused in the epilogue).  Output
     spatial size = input (x2 with ups).  `out` (optional) receives y; it may alias mask_aux (the mask is read and the result
-    written by the same lane); `pool_out` (optional) receives the pooled tensor."""
+    written by the same lane); `pool_out` (optional) receives the pooled tensor.
+    Tile masks (Winograd kernel only; one uint8 per 2x2 tile and channel, bit 2i+j <-> y[2Y+i, 2X+j] > 0):
+    `mask_out` with pool + lrelu returns (tile mask, pooled) -- the full-resolution y is never written;
+    a uint8 `mask_aux` (with pool) is such a mask of this conv's own output: returns (None, pooled);
+    `unpool_mask` (N,cout,H,W uint8, nothing else): returns the (N,cout,2H,2W) tensor 0.25 * up2(conv) * lrelu'(mask) --
+    AvgPool2d backward + LeakyReLU backward of the layer below, fused on the data-gradient conv that feeds them."""
+    if unpool_mask is not None or mask_out or (mask_aux is not None and mask_aux.dtype == torch.uint8):
+        return _conv3x3_tilemask(x, bias, cout, lrelu=lrelu, mask_aux=mask_aux, pool=pool or pool_out is not None,
+                                 pool_out=pool_out, wino=wino, mask_out=mask_out, unpool_mask=unpool_mask, ups=ups,
+                                 pixnorm=pixnorm, out=out)
     _chk(x, wp, bias, mask_aux, out, pool_out)
     pool = pool or pool_out is not None
     n, cin, hin, win = x.shape
@@ -140,6 +155,40 @@ def conv3x3(x, wp, bias, cout: int, *, ups=False, lrelu=False, mask_aux=None, pi
     if pool:
         return y, p
     return (y, p, rn) if pixnorm else y
+
+
+def _conv3x3_tilemask(x, bias, cout, *, lrelu, mask_aux, pool, pool_out, wino, mask_out, unpool_mask, ups, pixnorm, out):
+    if wino is None or ups or pixnorm or out is not None:
+        raise _lib.MusicGanHipError("tile masks are an epilogue of the Winograd kernel only (no ups / pixnorm / out)")
+    _chk(x, wino, bias, pool_out)
+    n, cin, h, w = x.shape
+    lib = _lib.load()
+    if unpool_mask is not None:
+        if lrelu or mask_aux is not None or pool or mask_out or bias is not None:
+            raise _lib.MusicGanHipError("unpool_mask excludes every other epilogue")
+        _chk_tilemask(unpool_mask, (n, cout, h, w))
+        y = torch.empty((n, cout, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+        check(lib.mg_wino3x3(_p(x), _p(wino), None, _p(unpool_mask), _p(y), None, None, n, cin, cout, h, w, _lib.MG_CONV_UNPOOL,
+                             SLOPE, _s()), "mg_wino3x3")
+        return y
+    if not pool:
+        raise _lib.MusicGanHipError("tile masks go with the fused AvgPool2d epilogue")
+    p = pool_out if pool_out is not None else torch.empty((n, cout, h // 2, w // 2), dtype=torch.float32, device=x.device)
+    if mask_out:
+        if not lrelu or mask_aux is not None:
+            raise _lib.MusicGanHipError("mask_out needs lrelu and no mask_aux")
+        m = torch.empty((n, cout, h // 2, w // 2), dtype=torch.uint8, device=x.device)
+        flags = MG_CONV_LRELU | MG_CONV_POOL_OUT | _lib.MG_CONV_MASK_OUT
+        check(lib.mg_wino3x3(_p(x), _p(wino), _p(bias), None, _p(m), _p(p), None, n, cin, cout, h, w, flags, SLOPE, _s()),
+              "mg_wino3x3")
+        return m, p
+    if lrelu:
+        raise _lib.MusicGanHipError("mask_aux excludes lrelu")
+    _chk_tilemask(mask_aux, (n, cout, h // 2, w // 2))
+    flags = MG_CONV_MASK_AUX | MG_CONV_POOL_OUT | _lib.MG_CONV_MASK_BYTES
+    check(lib.mg_wino3x3(_p(x), _p(wino), _p(bias), _p(mask_aux), None, _p(p), None, n, cin, cout, h, w, flags, SLOPE, _s()),
+          "mg_wino3x3")
+    return None, p
 
 
 def pack_upconv3x3(w: torch.Tensor) -> torch.Tensor:
@@ -370,9 +419,16 @@ def avgpool2_fwd(x, out=None):
 
 
 def avgpool2_bwd(gy, act=None):
-    """gx = 0.25 * up2(gy) * lrelu'(act) (act None: no mask)."""
-    _chk(gy, act)
+    """gx = 0.25 * up2(gy) * lrelu'(act) (act None: no mask; a uint8 act is a tile mask, see conv3x3)."""
     n, c, h2, w2 = gy.shape
+    if act is not None and act.dtype == torch.uint8:  # tile mask of conv3x3(mask_out=True)
+        _chk(gy)
+        _chk_tilemask(act, gy.shape)
+        gx = torch.empty((n, c, 2 * h2, 2 * w2), dtype=torch.float32, device=gy.device)
+        check(_lib.load().mg_avgpool2_bwd_tilemask(_p(gy), _p(act), _p(gx), n * c, 2 * h2, 2 * w2, SLOPE, _s()),
+              "mg_avgpool2_bwd_tilemask")
+        return gx
+    _chk(gy, act)
     gx = torch.empty((n, c, 2 * h2, 2 * w2), dtype=torch.float32, device=gy.device)
     check(_lib.load().mg_avgpool2_bwd(_p(gy), _p(act), _p(gx), n * c, 2 * h2, 2 * w2, SLOPE, _s()), "mg_avgpool2_bwd")
     return gx

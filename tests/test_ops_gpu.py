@@ -380,6 +380,26 @@ def test_wino3x3_fwd_dgrad_mask_pool(shape, cfg, monkeypatch):
     refm = refd * torch.where(act > 0, 1.0, 0.2).double()
     report("wino dgrad+mask", gxm, refm, 2e-6)
     report("wino dgrad+mask pooled", gq, F.avg_pool2d(refm, 2), 2e-6)
+    # tile masks: one byte per 2x2 tile instead of the full-resolution activation.  Same arithmetic as the fp32-mask paths above
+    # => bitwise the same numbers.
+    m, q2 = ops.conv3x3(x.to(DEV), None, b.to(DEV), co, lrelu=True, pool=True, wino=up, mask_out=True)
+    assert m.dtype == torch.uint8 and tuple(m.shape) == (n, co, h // 2, w // 2)
+    assert torch.equal(q2, q)
+    bits = (y > 0).reshape(n, co, h // 2, 2, w // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, co, h // 2, w // 2, 4).to(torch.uint8)
+    want = bits[..., 0] + 2 * bits[..., 1] + 4 * bits[..., 2] + 8 * bits[..., 3]
+    assert torch.equal(m, want)
+    mact = (act > 0).reshape(n, ci, h // 2, 2, w // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, ci, h // 2, w // 2, 4).to(torch.uint8)
+    mact = (mact[..., 0] + 2 * mact[..., 1] + 4 * mact[..., 2] + 8 * mact[..., 3]).to(DEV).contiguous()
+    none, gq2 = ops.conv3x3(gy.to(DEV), None, None, ci, mask_aux=mact, pool=True, wino=upd)
+    assert none is None and torch.equal(gq2, gq)
+    # AvgPool2d backward + LeakyReLU backward fused on the data-gradient conv: mask bytes at the conv's OUTPUT resolution
+    act2 = torch.randn(n, ci, 2 * h, 2 * w, generator=g)
+    m2 = (act2 > 0).reshape(n, ci, h, 2, w, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, ci, h, w, 4).to(torch.uint8)
+    m2 = (m2[..., 0] + 2 * m2[..., 1] + 4 * m2[..., 2] + 8 * m2[..., 3]).to(DEV).contiguous()
+    gun = ops.conv3x3(gy.to(DEV), None, None, ci, wino=upd, unpool_mask=m2)
+    assert torch.equal(gun, ops.avgpool2_bwd(gx, act2.to(DEV)))
+    if w % 2 == 0:  # the stand-alone kernel with a tile mask handles pairs of pooled pixels
+        assert torch.equal(ops.avgpool2_bwd(gx, m2), gun)
 
 
 @pytest.mark.parametrize("wt", ["", "4"])
