@@ -79,6 +79,22 @@ int mg_wino3x3_pack(const float* w, float* up, int Co, int Ci, int dgrad, mg_str
 int mg_wino3x3(const float* x, const float* up, const float* bias, const float* aux, float* y, float* p, float* rn, int N,
                int Cin, int Cout, int H, int W, int flags, float slope, mg_stream_t stream);
 
+/* The critic's fade-in blend [discriminator.py:111-116: alpha * conv_blocks[curr](start_block(x)) + (1 - alpha) *
+ * last_start_block(x)] fused on the Winograd convolution next to it, so that neither the blend nor its backward is a pass of its
+ * own.  coef: {alpha, 1 - alpha} in DEVICE memory (a captured graph stays valid while alpha moves); tile masks as above.
+ *   MG_FADE_FWD      y = coef[0] * leaky_relu(conv(x) + bias) + coef[1] * other;   out2 (uint8, N,Cout,H/2,W/2) = tile mask of
+ *                    the LeakyReLU output (all the backward passes need of it)
+ *   MG_FADE_TANGENT  y = coef[0] * (conv(x) * lrelu'(mask_in)) + coef[1] * other   (tangent pass of the gradient penalty)
+ *   MG_FADE_BWD      up = data-gradient filters, x = gradient w.r.t. the conv AFTER the blend:
+ *                    y = (coef[0] * conv(x)) * lrelu'(mask_in),  out2 (float, N,Cout,H,W) = (coef[1] * conv(x)) * lrelu'(other > 0)
+ * Results are bitwise those of mg_wino3x3 followed by mg_axpby / mg_blend_lrelu_bwd. */
+#define MG_FADE_FWD 1
+#define MG_FADE_TANGENT 2
+#define MG_FADE_BWD 3
+int mg_wino3x3_fade(const float* x, const float* up, const float* bias, const unsigned char* mask_in, const float* other,
+                    const float* coef, float* y, void* out2, int N, int Cin, int Cout, int H, int W, int mode, float slope,
+                    mg_stream_t stream);
+
 /* Weight (+ bias) gradient of the same convolution in Winograd F(3x3,2x2) form (even H, W; flags: MG_CONV_UPS_IN): same result as
  * mg_conv3x3_wgrad within fp32 rounding, 2.25x fewer multiplies, split-K slabs reduced in a fixed order (deterministic).
  * gw[Cout][Cin][3][3] (+)= ..., gb[Cout] (+)= sum of gy over samples n < bias_n (0: all; gb may be NULL). */

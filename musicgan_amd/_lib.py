@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmusicgan_hip.so")
 
 MG_CONV_UPS_IN, MG_CONV_LRELU, MG_CONV_MASK_AUX, MG_CONV_PIXNORM, MG_CONV_POOL_OUT = 1, 2, 4, 8, 16
 MG_CONV_MASK_OUT, MG_CONV_MASK_BYTES, MG_CONV_UNPOOL = 32, 64, 128
+MG_FADE_FWD, MG_FADE_TANGENT, MG_FADE_BWD = 1, 2, 3
 MG_C1_LRELU, MG_C1_TANH, MG_C1_MASK_AUX, MG_C1_TRANSPOSED, MG_C1_TANH_BWD_IN = 1, 2, 4, 8, 16
 
 
@@ -58,6 +59,7 @@ SIGNATURES = {
     "mg_wino3x3_packed_floats": (c_size_t, [c_int, c_int]),
     "mg_wino3x3_pack": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "mg_wino3x3": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
+    "mg_wino3x3_fade": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "mg_wino3x3_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "mg_wino3x3_wgrad": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "mg_wino3x3_wgrad_partial": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,

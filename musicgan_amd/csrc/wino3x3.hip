@@ -52,7 +52,15 @@ struct WinoArgs {
   int blocks_x, blocks_y, blocks_n;
   int nchunk;
   int NT;  // out-channel tiles in the packed weights (padded)
+  const unsigned char* mi;  // tile mask read by the epilogue (MG_CONV_MASK_BYTES, fade-in tangent / backward forms)
+  unsigned char* mo;        // tile mask written by the epilogue (MG_CONV_MASK_OUT, fade-in forward form)
+  const float* other;       // fade-in forms: the old branch (forward / tangent) or its activation (backward)
+  const float* coef;        // fade-in forms: {alpha, 1 - alpha} in device memory
 };
+
+// internal epilogue selectors of mg_wino3x3_fade (above the public MG_CONV_* bits)
+constexpr int WF_BLEND = 1 << 8;      // y = coef[0] * result + coef[1] * other
+constexpr int WF_BLEND_BWD = 1 << 9;  // y = (coef[0] * acc) * lrelu'(mi),  p = (coef[1] * acc) * lrelu'(other)
 
 // WT = tile groups (16 tiles each) per workgroup: 2 (two workgroups per CU) or 4 (one 8..12-wave workgroup per CU)
 template <int NIW, int WC, int WT>
@@ -134,7 +142,7 @@ __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(co
   float rE[NITEM][4];
   f32x4 rw[NU4];
 
-  auto load_chunk = [&](int ch) {
+  auto load_chunk = [&](int ch) __attribute__((always_inline)) {
     const int soff = ch * WCC * HW * 4;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img_base), 0, (int)img_bytes, 0x00020000);
@@ -152,7 +160,7 @@ __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(co
       if (NU4 * NTHR == U4 || tid + NTHR * j < U4) rw[j] = src[tid + NTHR * j];
   };
 
-  auto store_chunk = [&](int ch) {
+  auto store_chunk = [&](int ch) __attribute__((always_inline)) {
     if (a.Cin - ch * WCC < WCC) {  // ragged last chunk: channels that do not exist must read as zero (the loads see real data)
       const int lim = a.Cin - ch * WCC;
 #pragma unroll
@@ -204,7 +212,7 @@ __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(co
 
   // operands of component pair cp+1 are requested from LDS before the MFMAs of pair cp are issued (two register sets): a wave
   // that issues its reads only after its MFMAs leaves the matrix pipe idle for an LDS round trip every 8 instructions
-  auto compute_chunk = [&]() {
+  auto compute_chunk = [&]() __attribute__((always_inline)) {
     const float* va = Vs + wt * 2048 + lane * 4;
     const float* ub = Us + (wc * NIW) * 2048 + lane * 4;
     f32x4 av[2], bv[2][NIW];
@@ -257,7 +265,7 @@ __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(co
   // A^T M A + bias + LeakyReLU of out-channel tile ni -> on[g][2*i + j: pixel (i, j) of the lane's 2x2 tile].  The accumulator
   // of Winograd component (xi, nu) is acc[4*xi + slot(nu)] with slots [nu0, nu3, nu1, nu2] (see store_chunk); all math runs on
   // the f32x4 accumulators (g = 4 out-channels) so it packs.
-  auto transform = [&](int ni, float (&on)[4][4], auto act_) {
+  auto transform = [&](int ni, float (&on)[4][4], auto act_) __attribute__((always_inline)) {
     constexpr bool ACT = decltype(act_)::value;  // bias + LeakyReLU present (forward paths)
     f32x4 bv4;
 #pragma unroll
@@ -297,15 +305,17 @@ __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(co
   // per lane, 128 per 8 lanes -- and each (tile, out-channel) costs one dwordx4 store (and mask load) instead of two dwordx2.
   const bool odd = (lane & 1) != 0;
   const bool wide = (a.TBW >= 2) && ((Wt & 1) == 0);  // tile pairs exist and share validity
-  auto swap1 = [&](float x) {  // value of lane ^ 1
+  auto swap1 = [&](float x) __attribute__((always_inline)) {  // value of lane ^ 1
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));
   };
   const size_t pixw = odd ? pix0 - 2 + a.W : pix0;  // even: row 2TY of the pair; odd: row 2TY+1 of the pair
   auto store_tile = [&](int ni, float (&on)[4][4], const float (&rnv)[4], auto mask_, auto pn_, auto pool_, auto hasy_,
-                        auto mout_) {
-    constexpr int MASKK = decltype(mask_)::value;  // 0: none, 1: aux = fp32 activations (N,Cout,H,W), 2: aux = tile bytes
+                        auto mout_, auto blend_) __attribute__((always_inline)) {
+    constexpr int MASKK = decltype(mask_)::value;  // 0: none, 1: aux = fp32 activations (N,Cout,H,W), 2: a.mi = tile bytes
     constexpr bool MASK = MASKK == 1, PN = decltype(pn_)::value, POOL = decltype(pool_)::value,
-                   HASY = decltype(hasy_)::value, MOUT = decltype(mout_)::value;
+                   HASY = decltype(hasy_)::value, MOUT = decltype(mout_)::value, BLEND = decltype(blend_)::value;
+    float bca = 1.f, bcb = 0.f;
+    if constexpr (BLEND) { bca = a.coef[0]; bcb = a.coef[1]; }
     if constexpr (MASKK == 2 || MOUT) {  // one byte per 2x2 tile and out-channel, bit 2i+j <-> pixel (i, j): the lane's own tile
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -313,14 +323,14 @@ __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(co
         const bool act = tok && oc < a.Cout;
         const size_t ti = pp0 + (size_t)oc * (Ht * Wt);
         if constexpr (MASKK == 2) {
-          const unsigned mb = act ? (unsigned)reinterpret_cast<const unsigned char*>(a.aux)[ti] : 15u;
+          const unsigned mb = act ? (unsigned)a.mi[ti] : 15u;
 #pragma unroll
           for (int q = 0; q < 4; ++q) on[g][q] *= ((mb >> q) & 1u) ? 1.f : a.slope;
         }
         if constexpr (MOUT) {
           const unsigned mb = (on[g][0] > 0.f ? 1u : 0u) | (on[g][1] > 0.f ? 2u : 0u) | (on[g][2] > 0.f ? 4u : 0u) |
                               (on[g][3] > 0.f ? 8u : 0u);
-          if (act) reinterpret_cast<unsigned char*>(a.y)[ti] = (unsigned char)mb;
+          if (act) a.mo[ti] = (unsigned char)mb;
         }
       }
     }
@@ -342,6 +352,11 @@ __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(co
           if (act) ax = *reinterpret_cast<const f32x4*>(a.aux + idx);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] *= mg_lrelu_mask(ax[e], a.slope);
+        }
+        if constexpr (BLEND) {  // fade-in: alpha * new branch + (1 - alpha) * old branch (axpby_k's arithmetic)
+          f32x4 o4 = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (act) o4 = *reinterpret_cast<const f32x4*>(a.other + idx);
+          v = bca * v + bcb * o4;
         }
         float pooled = 0.f;
         if constexpr (POOL) {  // the pair's two pooled pixels: each lane holds one image row of both
@@ -370,6 +385,12 @@ __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(co
           v1.x *= mg_lrelu_mask(a1.x, a.slope);
           v1.y *= mg_lrelu_mask(a1.y, a.slope);
         }
+        if constexpr (BLEND) {
+          const float2 o0 = *reinterpret_cast<const float2*>(a.other + idx0);
+          const float2 o1 = *reinterpret_cast<const float2*>(a.other + idx0 + a.W);
+          v0 = make_float2(bca * v0.x + bcb * o0.x, bca * v0.y + bcb * o0.y);
+          v1 = make_float2(bca * v1.x + bcb * o1.x, bca * v1.y + bcb * o1.y);
+        }
         if constexpr (HASY) {
           *reinterpret_cast<float2*>(a.y + idx0) = v0;
           *reinterpret_cast<float2*>(a.y + idx0 + a.W) = v1;
@@ -383,7 +404,7 @@ __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(co
     }
   };
   // no PixelNorm: one out-channel tile at a time (16 live outputs)
-  auto tail = [&](auto mask_, auto pool_, auto hasy_, auto mout_) {
+  auto tail = [&](auto mask_, auto pool_, auto hasy_, auto mout_, auto blend_) __attribute__((always_inline)) {
     const float one[4] = {1.f, 1.f, 1.f, 1.f};
     constexpr bool MASKED = decltype(mask_)::value != 0;
 #pragma unroll
@@ -391,13 +412,59 @@ __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(co
       float on[4][4];
       if (MASKED && a.bias == nullptr) transform(ni, on, std::false_type{});  // MASK_AUX excludes LRELU; no bias: plain A^T M A
       else transform(ni, on, std::true_type{});
-      store_tile(ni, on, one, mask_, std::false_type{}, pool_, hasy_, mout_);
+      store_tile(ni, on, one, mask_, std::false_type{}, pool_, hasy_, mout_, blend_);
+    }
+  };
+  // backward of the fade-in blend and of the two LeakyReLUs in front of it, on the data-gradient conv that produces the blend's
+  // gradient (blend_lrelu_bwd_k's arithmetic): y = (alpha * acc) * lrelu'(new branch, tile mask a.mi),
+  // p = ((1 - alpha) * acc) * lrelu'(old branch activation a.other)
+  auto tail_blend_bwd = [&]() __attribute__((always_inline)) {
+    const float ca = a.coef[0], cb = a.coef[1];
+#pragma unroll
+    for (int ni = 0; ni < NIW; ++ni) {
+      float on[4][4];
+      transform(ni, on, std::false_type{});
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int oc = oc0 + ni * 16 + g;
+        const bool act = tok && oc < a.Cout;
+        const unsigned mb = act ? (unsigned)a.mi[pp0 + (size_t)oc * (Ht * Wt)] : 15u;
+        float oa[4], ob[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          oa[q] = (ca * on[g][q]) * (((mb >> q) & 1u) ? 1.f : a.slope);
+          ob[q] = cb * on[g][q];
+        }
+        if (wide) {
+          const float a0 = swap1(odd ? oa[0] : oa[2]), a1 = swap1(odd ? oa[1] : oa[3]);
+          const float b0 = swap1(odd ? ob[0] : ob[2]), b1 = swap1(odd ? ob[1] : ob[3]);
+          const f32x4 va = odd ? f32x4{a0, a1, oa[2], oa[3]} : f32x4{oa[0], oa[1], a0, a1};
+          f32x4 vb = odd ? f32x4{b0, b1, ob[2], ob[3]} : f32x4{ob[0], ob[1], b0, b1};
+          if (act) {
+            const size_t idx = pixw + (size_t)oc * HW;
+            const f32x4 ax = *reinterpret_cast<const f32x4*>(a.other + idx);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vb[e] *= mg_lrelu_mask(ax[e], a.slope);
+            *reinterpret_cast<f32x4*>(a.y + idx) = va;
+            *reinterpret_cast<f32x4*>(a.p + idx) = vb;
+          }
+        } else if (act) {
+          const size_t idx0 = pix0 + (size_t)oc * HW;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const float2 ax = *reinterpret_cast<const float2*>(a.other + idx0 + (size_t)i * a.W);
+            *reinterpret_cast<float2*>(a.y + idx0 + (size_t)i * a.W) = make_float2(oa[2 * i], oa[2 * i + 1]);
+            *reinterpret_cast<float2*>(a.p + idx0 + (size_t)i * a.W) =
+                make_float2(ob[2 * i] * mg_lrelu_mask(ax.x, a.slope), ob[2 * i + 1] * mg_lrelu_mask(ax.y, a.slope));
+          }
+        }
+      }
     }
   };
   // MG_CONV_UNPOOL: y (N,Cout,2H,2W) = AvgPool2d backward of the result, times the LeakyReLU mask of the layer below it
   // (aux: one byte per OUTPUT PIXEL of this convolution = per 2x2 block of y).  A lane of the wide path holds one image row of
   // a tile pair (4 pixels, 4 mask bytes = one dword) and writes 2 rows x 8 floats; y index of pixel (Y, X) = 4*idx - 2*X.
-  auto tail_unpool = [&]() {
+  auto tail_unpool = [&]() __attribute__((always_inline)) {
     const unsigned char* mb = reinterpret_cast<const unsigned char*>(a.aux);
     const float qh = 0.25f, ql = 0.25f * a.slope;
     const int W2 = 2 * a.W;
@@ -448,7 +515,7 @@ __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(co
     }
   };
   // PixelNorm: all channels of the pixel first (sum of squares over ni, g in-lane, rq by shuffles, wave groups via LDS)
-  auto tail_pn = [&](auto hasy_) {
+  auto tail_pn = [&](auto hasy_) __attribute__((always_inline)) {
     float o[NIW][4][4];
 #pragma unroll
     for (int ni = 0; ni < NIW; ++ni) transform(ni, o[ni], std::true_type{});
@@ -479,7 +546,8 @@ __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(co
     for (int q = 0; q < 4; ++q) rnv[q] = 1.0f / sqrtf(rnv[q] / (float)a.Cout + PN_EPS);
 #pragma unroll
     for (int ni = 0; ni < NIW; ++ni)
-      store_tile(ni, o[ni], rnv, std::integral_constant<int, 0>{}, std::true_type{}, std::false_type{}, hasy_, std::false_type{});
+      store_tile(ni, o[ni], rnv, std::integral_constant<int, 0>{}, std::true_type{}, std::false_type{}, hasy_, std::false_type{},
+                 std::false_type{});
     if (tok && rq == 0 && wc == 0 && a.rn != nullptr && blockIdx.y == 0) {
       const size_t r0 = ((size_t)n * a.H + 2 * TY) * a.W + 2 * TX;
       *reinterpret_cast<float2*>(a.rn + r0) = make_float2(rnv[0], rnv[1]);
@@ -496,14 +564,19 @@ __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(co
     else tail_pn(F_{});
   } else if (a.flags & MG_CONV_UNPOOL) {
     tail_unpool();
+  } else if (a.flags & WF_BLEND_BWD) {
+    tail_blend_bwd();
+  } else if (a.flags & WF_BLEND) {
+    if (a.flags & MG_CONV_MASK_BYTES) tail(I2_{}, F_{}, T_{}, F_{}, T_{});  // tangent pass through the blend
+    else tail(I0_{}, F_{}, T_{}, T_{}, T_{});                                // forward: blend + tile mask of the new branch
   } else if (a.flags & MG_CONV_MASK_AUX) {
-    if (a.flags & MG_CONV_MASK_BYTES) tail(I2_{}, T_{}, F_{}, F_{});  // pooled result only
-    else if (a.flags & MG_CONV_POOL_OUT) tail(I1_{}, T_{}, T_{}, F_{});
-    else tail(I1_{}, F_{}, T_{}, F_{});
+    if (a.flags & MG_CONV_MASK_BYTES) tail(I2_{}, T_{}, F_{}, F_{}, F_{});  // pooled result only
+    else if (a.flags & MG_CONV_POOL_OUT) tail(I1_{}, T_{}, T_{}, F_{}, F_{});
+    else tail(I1_{}, F_{}, T_{}, F_{}, F_{});
   } else {
-    if (a.flags & MG_CONV_MASK_OUT) tail(I0_{}, T_{}, F_{}, T_{});  // pooled result + tile mask bytes instead of y
-    else if (a.flags & MG_CONV_POOL_OUT) tail(I0_{}, T_{}, T_{}, F_{});
-    else tail(I0_{}, F_{}, T_{}, F_{});
+    if (a.flags & MG_CONV_MASK_OUT) tail(I0_{}, T_{}, F_{}, T_{}, F_{});  // pooled result + tile mask bytes instead of y
+    else if (a.flags & MG_CONV_POOL_OUT) tail(I0_{}, T_{}, T_{}, F_{}, F_{});
+    else tail(I0_{}, F_{}, T_{}, F_{}, F_{});
   }
 }
 
@@ -532,6 +605,7 @@ int launch_wino(const WinoArgs& a, dim3 grid, hipStream_t s) {
 }
 
 int wino_nt_padded(int Cout) { return pack_wino_nt_padded(Cout); }
+int wino_run(WinoArgs& a, bool pn, hipStream_t s);  // tile geometry + variant dispatch (below)
 
 }  // namespace
 
@@ -571,13 +645,22 @@ extern "C" int mg_wino3x3(const float* x, const float* up, const float* bias, co
   MG_CHECK_ARG(!(flags & ~(MG_CONV_LRELU | MG_CONV_PIXNORM | MG_CONV_MASK_AUX | MG_CONV_POOL_OUT | MG_CONV_MASK_OUT |
                            MG_CONV_MASK_BYTES | MG_CONV_UNPOOL)), "mg_wino3x3: unknown flag");
   MG_CHECK_ARG((long long)N * Cin * H * W < (1ll << 40) && (long long)N * Cout * H * W < (1ll << 40), "mg_wino3x3: tensor too large");
-  const int nt = mg_cdiv(Cout, 16);
-  MG_CHECK_ARG(!pn || nt <= 4, "mg_wino3x3: PIXNORM needs Cout <= 64 (all channels of a pixel in one workgroup)");
+  MG_CHECK_ARG(!pn || mg_cdiv(Cout, 16) <= 4, "mg_wino3x3: PIXNORM needs Cout <= 64 (all channels of a pixel in one workgroup)");
 
   WinoArgs a;
   a.x = x; a.up = up; a.bias = bias; a.aux = aux; a.y = y; a.p = p; a.rn = rn;
+  a.mi = reinterpret_cast<const unsigned char*>(aux);
+  a.mo = reinterpret_cast<unsigned char*>(y);
+  a.other = nullptr; a.coef = nullptr;
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
   a.flags = flags; a.slope = slope;
+  return wino_run(a, pn, (hipStream_t)stream);
+}
+
+namespace {
+int wino_run(WinoArgs& a, bool pn, hipStream_t s) {
+  const int N = a.N, Cin = a.Cin, Cout = a.Cout, H = a.H, W = a.W;
+  const int nt = mg_cdiv(Cout, 16);
   a.nchunk = mg_cdiv(Cin, WCC);
   a.NT = wino_nt_padded(Cout);
   const int Ht = H / 2, Wt = W / 2;
@@ -613,7 +696,6 @@ extern "C" int mg_wino3x3(const float* x, const float* up, const float* bias, co
   a.blocks_x = mg_cdiv(Wt, a.TBW); a.blocks_y = mg_cdiv(Ht, a.TBH); a.blocks_n = mg_cdiv(N, a.TBN);
   MG_CHECK_ARG((long long)a.TBN * Cin * H * W < (1ll << 29), "mg_wino3x3: image block too large for 32-bit offsets");
   dim3 grid(a.blocks_x * a.blocks_y * a.blocks_n, mg_cdiv(nt, cfg));
-  hipStream_t s = (hipStream_t)stream;
   switch (cfg * 10 + wt) {
     case 44: return launch_wino<2, 2, 4>(a, grid, s);
     case 42: return launch_wino<2, 2, 2>(a, grid, s);
@@ -622,4 +704,29 @@ extern "C" int mg_wino3x3(const float* x, const float* up, const float* bias, co
     case 24: return launch_wino<1, 2, 4>(a, grid, s);
     default: return launch_wino<1, 2, 2>(a, grid, s);
   }
+}
+}  // namespace
+
+extern "C" int mg_wino3x3_fade(const float* x, const float* up, const float* bias, const unsigned char* mask_in, const float* other,
+                               const float* coef, float* y, void* out2, int N, int Cin, int Cout, int H, int W, int mode,
+                               float slope, mg_stream_t stream) {
+  MG_CHECK_ARG(x && up && other && coef && y && N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "mg_wino3x3_fade: bad arguments");
+  MG_CHECK_ARG((H % 2 == 0) && (W % 2 == 0), "mg_wino3x3_fade: H=%d W=%d must be even", H, W);
+  MG_CHECK_ARG(Cout <= 160, "mg_wino3x3_fade: Cout=%d > 160 unsupported", Cout);
+  MG_CHECK_ARG(mode == MG_FADE_FWD || mode == MG_FADE_TANGENT || mode == MG_FADE_BWD, "mg_wino3x3_fade: unknown mode %d", mode);
+  MG_CHECK_ARG(mode == MG_FADE_FWD ? (out2 != nullptr && mask_in == nullptr) : mask_in != nullptr,
+               "mg_wino3x3_fade: FWD writes a tile mask to out2, TANGENT / BWD read mask_in");
+  MG_CHECK_ARG(mode != MG_FADE_BWD || (out2 != nullptr && bias == nullptr), "mg_wino3x3_fade: BWD needs out2 and no bias");
+  MG_CHECK_ARG((long long)N * Cin * H * W < (1ll << 40) && (long long)N * Cout * H * W < (1ll << 40), "mg_wino3x3_fade: tensor too large");
+  WinoArgs a;
+  a.x = x; a.up = up; a.bias = bias; a.aux = nullptr; a.y = y; a.rn = nullptr;
+  a.p = mode == MG_FADE_BWD ? static_cast<float*>(out2) : nullptr;
+  a.mi = mask_in;
+  a.mo = mode == MG_FADE_FWD ? static_cast<unsigned char*>(out2) : nullptr;
+  a.other = other; a.coef = coef;
+  a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+  a.flags = mode == MG_FADE_FWD ? (WF_BLEND | MG_CONV_LRELU)
+          : mode == MG_FADE_TANGENT ? (WF_BLEND | MG_CONV_MASK_AUX | MG_CONV_MASK_BYTES) : WF_BLEND_BWD;
+  a.slope = slope;
+  return wino_run(a, false, (hipStream_t)stream);
 }

@@ -134,6 +134,24 @@ class FadeIn:
     def of(alpha) -> "FadeIn":
         return alpha if isinstance(alpha, FadeIn) else FadeIn(alpha)
 
+    def coef(self, device) -> torch.Tensor:
+        """The coefficients in device memory (kernels that only take them from there): `dev`, or a filled scratch pair."""
+        if self.dev is not None:
+            return self.dev
+        key = (self.a, str(device))
+        t = _COEF.get(key)
+        if t is None:
+            if len(_COEF) >= 16:
+                _COEF.clear()
+            t = torch.empty(2, dtype=torch.float32, device=device)
+            t[0:1].fill_(self.a)
+            t[1:2].fill_(self.b)
+            _COEF[key] = t
+        return t
+
+
+_COEF: Dict[tuple, torch.Tensor] = {}
+
 
 class GradSink:
     """Collects parameter gradients keyed by the parameter object; a second write to the same key accumulates.
@@ -279,6 +297,15 @@ def _tile_mask_ok(n: int, cin: int, cout: int, h: int, w: int) -> bool:
     return ops.wino3x3_supported(max(1, n // 3), cout, h, w, cin=cin)
 
 
+def _fade_fused_ok(n: int, c1: int, c_next: int, h: int, w: int) -> bool:
+    """Whether the fade-in blend rides on the Winograd convs around it (ops.conv3x3_fade): the block's second conv forward and
+    in the tangent pass (a third of the batch), and the data-gradient conv of the next block's first conv on the way back."""
+    if os.environ.get("MG_TILEMASK", "1") == "0" or c_next == 0 or (w % 4) or (h % 2):
+        return False
+    nmin = max(1, n // 3)
+    return ops.wino3x3_supported(nmin, c1, h, w, cin=c1) and ops.wino3x3_supported(nmin, c1, h, w, cin=c_next)
+
+
 def disc_forward(W: DiscWeights, x: torch.Tensor, alpha: float, cache: PackCache, save: bool):
     x = x.contiguous()
     n = x.shape[0]
@@ -294,15 +321,22 @@ def disc_forward(W: DiscWeights, x: torch.Tensor, alpha: float, cache: PackCache
         # 2x2 tile and a1 is that uint8 tile mask (N,c1,H/2,W/2) instead of the fp32 tensor.
         a1, q1 = cache.conv(inp, w1, False, b1, c1, lrelu=True, pool=True,
                             mask_out=save and _tile_mask_ok(n, w1.shape[1], c1, inp.shape[2], inp.shape[3]))
-        a2 = cache.conv(q1, w2, False, b2, c1, lrelu=True)
-        if save:
-            saved.append((inp, a1, q1, a2))
-        inp = a2
-        if i == 0 and W.old_stem is not None:
+        if i == 0 and W.old_stem is not None:  # fade-in: the block's output is blended with the old stem's
             xp = ops.avgpool2_fwd(x)
             o = ops.conv1x1(xp, W.old_stem[0], W.old_stem[1], c1, lrelu=True)
             F = FadeIn.of(alpha)
-            inp = ops.axpby(F.a, a2, F.b, o, coef=F.dev)
+            c_next = W.blocks[1][0].shape[0] if len(W.blocks) > 1 else 0
+            if _fade_fused_ok(n, c1, c_next, q1.shape[2], q1.shape[3]):
+                # blend in the conv's epilogue; of the new branch itself only the sign is needed later: a2 = uint8 tile mask
+                nxt, a2 = ops.conv3x3_fade(q1, cache.get_wino(w2, False), b2, c1, _lib.MG_FADE_FWD, o, F.coef(x.device))
+            else:
+                a2 = cache.conv(q1, w2, False, b2, c1, lrelu=True)
+                nxt = ops.axpby(F.a, a2, F.b, o, coef=F.dev)
+        else:
+            a2 = nxt = cache.conv(q1, w2, False, b2, c1, lrelu=True)
+        if save:
+            saved.append((inp, a1, q1, a2))
+        inp = nxt
     assert inp.shape[2] == 1 and inp.shape[3] == 1, \
         f"discriminator input must be square with side 2**(9-curr_layer); final map is {tuple(inp.shape)}"
     flat = inp.reshape(n, -1)
@@ -357,8 +391,12 @@ def disc_backward(W: DiscWeights, ctx, g_out: torch.Tensor, cache: PackCache, si
         if i > 0:
             a2_prev = saved[i - 1][3]
             if i == 1 and W.old_stem is not None:  # inp is the fade-in blend of a2_prev and the old stem path
-                gblend = cache.conv(gpre1, w1, True, None, cin)
-                gpre2, gpre_o = ops.blend_lrelu_bwd(gblend, a2_prev, o, F.a, F.b, coef=F.dev)
+                if a2_prev.dtype == torch.uint8:  # blend + LeakyReLU backward in the data-gradient conv's epilogue
+                    gpre2, gpre_o = ops.conv3x3_fade(gpre1, cache.get_wino(w1, True), None, cin, _lib.MG_FADE_BWD, o,
+                                                     F.coef(x.device), mask_in=a2_prev)
+                else:
+                    gblend = cache.conv(gpre1, w1, True, None, cin)
+                    gpre2, gpre_o = ops.blend_lrelu_bwd(gblend, a2_prev, o, F.a, F.b, coef=F.dev)
             else:
                 gpre2 = cache.conv(gpre1, w1, True, None, cin, mask_aux=a2_prev)
         else:
@@ -406,10 +444,14 @@ def disc_gp_param_grads(W: DiscWeights, ctx, hs, u0: torch.Tensor, cache: PackCa
         t1, tq = cache.conv(t, w1, False, None, c1, mask_aux=a1, pool=True)
         gw2, acc = sink.slot(w2)
         ops.conv3x3_wgrad(tq, gpre2, gw2, None, accumulate=acc)
-        t = cache.conv(tq, w2, False, None, c1, mask_aux=a2)
-        if i == 0 and to is not None:
+        if a2.dtype == torch.uint8:
             F = FadeIn.of(alpha)
-            t = ops.axpby(F.a, t, F.b, to, out=t, coef=F.dev)
+            t = ops.conv3x3_fade(tq, cache.get_wino(w2, False), None, c1, _lib.MG_FADE_TANGENT, to, F.coef(x.device), mask_in=a2)
+        else:
+            t = cache.conv(tq, w2, False, None, c1, mask_aux=a2)
+            if i == 0 and to is not None:
+                F = FadeIn.of(alpha)
+                t = ops.axpby(F.a, t, F.b, to, out=t, coef=F.dev)
     ones = torch.ones((n, 1), dtype=torch.float32, device=x.device)
     gwc, acc = sink.slot(W.clf[0])
     ops.linear1_bwd(t.reshape(n, -1), W.clf[0], ones, gw=gwc, gb=None, need_gx=False, accumulate=acc)
@@ -463,6 +505,11 @@ def disc_step_fused(W: DiscWeights, x_real: torch.Tensor, x_fake: torch.Tensor, 
             cache.conv(inp[sl], w1, False, None, c1, mask_aux=a1[sl], pool_out=q1[sl])
         else:
             cache.conv(inp[sl], w1, False, None, c1, mask_aux=a1[sl], out=a1[sl], pool_out=q1[sl])
+        if a2.dtype == torch.uint8:  # fade-in block with the blend fused: straight into the next block's input slice
+            F = FadeIn.of(alpha)
+            ops.conv3x3_fade(q1[sl], cache.get_wino(w2, False), None, c1, _lib.MG_FADE_TANGENT, o[sl], F.coef(x.device),
+                             mask_in=a2[sl], out=saved[1][0][sl])
+            continue
         cache.conv(q1[sl], w2, False, None, c1, mask_aux=a2[sl], out=a2[sl])
         if i == 0 and W.old_stem is not None:
             target = saved[1][0][sl] if nb > 1 else flat[sl].reshape(a2[sl].shape)

@@ -191,6 +191,27 @@ def _conv3x3_tilemask(x, bias, cout, *, lrelu, mask_aux, pool, pool_out, wino, m
     return None, p
 
 
+def conv3x3_fade(x, wino, bias, cout: int, mode: int, other, coef, mask_in=None, out=None):
+    """The critic's fade-in blend fused on the Winograd conv next to it (mg_wino3x3_fade; `coef` = device tensor {alpha, 1-alpha}):
+    MG_FADE_FWD -> (blend, tile mask of the new branch);  MG_FADE_TANGENT (mask_in) -> blend of the tangents;
+    MG_FADE_BWD (wino = data-gradient pack, mask_in, other = old branch's activation) -> (grad new branch, grad old branch)."""
+    _chk(x, wino, bias, other, coef, out)
+    n, cin, h, w = x.shape
+    if tuple(other.shape) != (n, cout, h, w):
+        raise _lib.MusicGanHipError(f"conv3x3_fade: other has shape {tuple(other.shape)}, expected {(n, cout, h, w)}")
+    if mode != _lib.MG_FADE_FWD:
+        _chk_tilemask(mask_in, (n, cout, h // 2, w // 2))
+    y = out if out is not None else torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+    out2 = None
+    if mode == _lib.MG_FADE_FWD:
+        out2 = torch.empty((n, cout, h // 2, w // 2), dtype=torch.uint8, device=x.device)
+    elif mode == _lib.MG_FADE_BWD:
+        out2 = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+    check(_lib.load().mg_wino3x3_fade(_p(x), _p(wino), _p(bias), _p(mask_in), _p(other), _p(coef), _p(y), _p(out2), n, cin, cout,
+                                      h, w, mode, SLOPE, _s()), "mg_wino3x3_fade")
+    return y if out2 is None else (y, out2)
+
+
 def pack_upconv3x3(w: torch.Tensor) -> torch.Tensor:
     """Effective sub-pixel weights of Upsample(x2) -> Conv3x3 in the kernel's LDS image layout."""
     _chk(w)

@@ -402,6 +402,52 @@ def test_wino3x3_fwd_dgrad_mask_pool(shape, cfg, monkeypatch):
         assert torch.equal(ops.avgpool2_bwd(gx, m2), gun)
 
 
+def _tile_mask(act: torch.Tensor) -> torch.Tensor:
+    n, c, h, w = act.shape
+    b = (act > 0).reshape(n, c, h // 2, 2, w // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, c, h // 2, w // 2, 4).to(torch.uint8)
+    return (b[..., 0] + 2 * b[..., 1] + 4 * b[..., 2] + 8 * b[..., 3]).contiguous()
+
+
+@pytest.mark.parametrize("cfg", ["", "2", "3w", "4w"])
+@pytest.mark.parametrize("shape", [(3, 64, 64, 64, 64), (2, 24, 40, 6, 10), (3, 20, 17, 2, 12), (1, 80, 64, 32, 32), (5, 16, 32, 4, 2)])
+def test_wino3x3_fade_in_epilogues_equal_the_separate_kernels(shape, cfg, monkeypatch):
+    """mg_wino3x3_fade: the critic's fade-in blend (forward, tangent) and its backward fused on the Winograd conv -- bitwise the
+    results of the conv followed by mg_axpby / mg_blend_lrelu_bwd, and the tile mask is the sign of the new branch."""
+    ops = _ops()
+    from musicgan_amd import _lib
+    if cfg.endswith("w"):
+        monkeypatch.setenv("MG_WINO_WT", "4")
+        cfg = cfg[:-1]
+    if cfg:
+        monkeypatch.setenv("MG_WINO_CFG", cfg)
+    n, ci, co, h, w = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, ci, h, w, generator=g).to(DEV)
+    wt = (torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(9 * ci)).to(DEV)
+    b = torch.randn(co, generator=g).to(DEV)
+    other = torch.randn(n, co, h, w, generator=g).to(DEV)
+    coef = torch.tensor([0.37, 0.63], dtype=torch.float32).to(DEV)
+    up = ops.pack_wino3x3(wt, dgrad=False)
+    y = ops.conv3x3(x, None, b, co, lrelu=True, wino=up)
+    blend, m = ops.conv3x3_fade(x, up, b, co, _lib.MG_FADE_FWD, other, coef)
+    assert torch.equal(blend, ops.axpby(0.37, y, 0.63, other, coef=coef))
+    assert torch.equal(m, _tile_mask(y))
+    # tangent: conv * lrelu'(new branch), blended with the old branch's tangent
+    t = ops.conv3x3(x, None, None, co, mask_aux=y.clone(), wino=up)
+    out = torch.empty_like(t)
+    got = ops.conv3x3_fade(x, up, None, co, _lib.MG_FADE_TANGENT, other, coef, mask_in=m, out=out)
+    assert got is out and torch.equal(out, ops.axpby(0.37, t, 0.63, other, coef=coef))
+    # backward: x plays the gradient w.r.t. the conv after the blend (co channels), result has ci channels
+    gy = torch.randn(n, co, h, w, generator=g).to(DEV)
+    act_new = torch.randn(n, ci, h, w, generator=g).to(DEV)
+    act_old = torch.randn(n, ci, h, w, generator=g).to(DEV)
+    upd = ops.pack_wino3x3(wt, dgrad=True)
+    gblend = ops.conv3x3(gy, None, None, ci, wino=upd)
+    ra, ro = ops.blend_lrelu_bwd(gblend, act_new, act_old, 0.37, 0.63, coef=coef)
+    ga, go = ops.conv3x3_fade(gy, upd, None, ci, _lib.MG_FADE_BWD, act_old, coef, mask_in=_tile_mask(act_new))
+    assert torch.equal(ga, ra) and torch.equal(go, ro)
+
+
 @pytest.mark.parametrize("wt", ["", "4"])
 @pytest.mark.parametrize("shape", [(2, 8, 8, 2, 2), (2, 64, 64, 32, 32), (1, 80, 48, 64, 16), (3, 24, 33, 6, 10),
                                    (2, 32, 16, 16, 16)])
