@@ -77,18 +77,26 @@ __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(co
   float* Us = smem + V_FLOATS;  // [WC*NIW tiles][8 comp pairs][64 lanes][4]
   float* red = Us + U4 * 4;     // PixelNorm cross-wave partial sums [WC][TPB][4]
 
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int col = lane & 15, rq = lane >> 4;
-  const int wt = wave % WT, wc = wave / WT;
+  // Persistent form: a workgroup walks the tile blocks item, item + gridDim.x, ... (gridDim.x = workgroups the chip holds at
+  // once) and requests the first chunk of its NEXT block while the last chunk of the current one is in the matrix pipe, so that
+  // the ~2 us from "addresses known" to "first operands in LDS" are hidden under the epilogue instead of opening every block.
+  // The thread index is laundered once per block: what derives from it is then recomputed per block rather than hoisted out of
+  // the loop and kept live across it (the hoisted form costs ~60 registers and spills).
+  int tid = threadIdx.x, lane, wave, col, rq, wt, wc;
+  auto thread_coords = [&]() __attribute__((always_inline)) {
+    asm volatile("" : "+v"(tid));
+    lane = tid & 63;
+    wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    col = lane & 15;
+    rq = lane >> 4;
+    wt = wave % WT;
+    wc = wave / WT;
+  };
+  thread_coords();
   const int ct0 = blockIdx.y * (WC * NIW);
   const int HW = a.H * a.W;
   const int Ht = a.H >> 1, Wt = a.W >> 1;
-  const int bid = mg_xcd_remap(blockIdx.x, gridDim.x);
-  const int bx = bid % a.blocks_x;
-  const int t2 = bid / a.blocks_x;
-  const int by = t2 % a.blocks_y;
-  const int bn = t2 / a.blocks_y;
+  const int nblk = a.blocks_x * a.blocks_y * a.blocks_n;
 
   // staging geometry: item it = tid + k*NTHR -> tile it % TPB, chunk-local channel it / TPB, so lanes l and l+1 of a
   // half-wave hold horizontally adjacent tiles of one channel.  Each item loads only its OWN two pixel columns of the 4 patch
@@ -99,43 +107,45 @@ __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(co
   unsigned voffP[NITEM][4], voffE[NITEM][4];  // own pair; halo column of an edge lane (left OR right: a lane is at most one)
   bool ledge[NITEM], redge[NITEM];
   int vdst[NITEM];  // LDS float offset of the item's first component pair
-  const int n0 = bn * a.TBN;
-  const int nimg = (a.N - n0) < a.TBN ? (a.N - n0) : a.TBN;
-  const float* img_base = a.x + (size_t)n0 * a.Cin * HW;
-  const unsigned img_bytes = (unsigned)nimg * (unsigned)(a.Cin * HW) * 4u;
+  int bx, by, n0;   // tile block of the staging geometry (the epilogue keeps its own copy: the geometry runs one block ahead)
+  const float* img_base;
+  unsigned img_bytes;
+  auto block_geometry = [&](int item) __attribute__((always_inline)) {
+    const int bid = mg_xcd_remap(item, nblk);
+    bx = bid % a.blocks_x;
+    const int t2 = bid / a.blocks_x;
+    by = t2 % a.blocks_y;
+    n0 = (t2 / a.blocks_y) * a.TBN;
+    const int nimg = (a.N - n0) < a.TBN ? (a.N - n0) : a.TBN;
+    img_base = a.x + (size_t)n0 * a.Cin * HW;
+    img_bytes = (unsigned)nimg * (unsigned)(a.Cin * HW) * 4u;
 #pragma unroll
-  for (int k = 0; k < NITEM; ++k) {
-    const int it = tid + k * NTHR;
-    const int tl = it % TPB, cl = it / TPB;
-    const int txl = tl & (a.TBW - 1);
-    const int tyl = (tl >> a.lgTBW) & (a.TBH - 1);
-    const int nl = tl >> (a.lgTBW + a.lgTBH);
-    const int TY = by * a.TBH + tyl, TX = bx * a.TBW + txl;
-    const bool ok = (it < NITEMS) && (nl < nimg) && (TY < Ht) && (TX < Wt);
-    const int base = (nl * a.Cin + cl) * HW + 2 * TX;
-    ledge[k] = txl == 0;
-    redge[k] = txl == a.TBW - 1;
+    for (int k = 0; k < NITEM; ++k) {
+      const int it = tid + k * NTHR;
+      const int tl = it % TPB, cl = it / TPB;
+      const int txl = tl & (a.TBW - 1);
+      const int tyl = (tl >> a.lgTBW) & (a.TBH - 1);
+      const int nl = tl >> (a.lgTBW + a.lgTBH);
+      const int TY = by * a.TBH + tyl, TX = bx * a.TBW + txl;
+      const bool ok = (it < NITEMS) && (nl < nimg) && (TY < Ht) && (TX < Wt);
+      const int base = (nl * a.Cin + cl) * HW + 2 * TX;
+      ledge[k] = txl == 0;
+      redge[k] = txl == a.TBW - 1;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int Y = 2 * TY - 1 + r;
-      const bool rv = ok && (Y >= 0) && (Y < a.H);
-      const unsigned o = (unsigned)(base + Y * a.W) * 4u;
-      voffP[k][r] = rv ? o : 0x80000000u;
-      // a block one tile wide has both halos outside the image (W == 2), so one offset per lane is enough
-      voffE[k][r] = (rv && ledge[k] && TX > 0) ? o - 4u : ((rv && redge[k] && 2 * TX + 2 < a.W) ? o + 8u : 0x80000000u);
+      for (int r = 0; r < 4; ++r) {
+        const int Y = 2 * TY - 1 + r;
+        const bool rv = ok && (Y >= 0) && (Y < a.H);
+        const unsigned o = (unsigned)(base + Y * a.W) * 4u;
+        voffP[k][r] = rv ? o : 0x80000000u;
+        // a block one tile wide has both halos outside the image (W == 2), so one offset per lane is enough
+        voffE[k][r] = (rv && ledge[k] && TX > 0) ? o - 4u : ((rv && redge[k] && 2 * TX + 2 < a.W) ? o + 8u : 0x80000000u);
+      }
+      // [tile group][component pair][lane' = (cl>>1)*16 + tile%16][k-step = cl&1][parity]
+      vdst[k] = (it < NITEMS) ? (((tl >> 4) * 8 * 64 + (cl >> 1) * 16 + (tl & 15)) * 4 + (cl & 1) * 2) : -1;
     }
-    // [tile group][component pair][lane' = (cl>>1)*16 + tile%16][k-step = cl&1][parity]
-    vdst[k] = (it < NITEMS) ? (((tl >> 4) * 8 * 64 + (cl >> 1) * 16 + (tl & 15)) * 4 + (cl & 1) * 2) : -1;
-  }
+  };
 
   f32x4 acc[16][NIW];
-#pragma unroll
-  for (int c = 0; c < 16; ++c)
-#pragma unroll
-    for (int ni = 0; ni < NIW; ++ni) {  // cleared with 64-bit moves: fp32 MFMA and VALU time add up on gfx950, every VALU counts
-      typedef double f64x2 __attribute__((ext_vector_type(2)));
-      acc[c][ni] = __builtin_bit_cast(f32x4, f64x2{0.0, 0.0});
-    }
 
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   f32x2 rP[NITEM][4];
@@ -241,14 +251,34 @@ __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(co
     }
   };
 
+  block_geometry(blockIdx.x);
   load_chunk(0);
-  for (int ch = 0; ch < a.nchunk; ++ch) {
+#pragma nounroll
+  for (int item = blockIdx.x;;) {
+  const int next = item + (int)gridDim.x;
+  const int ebx = bx, eby = by, en0 = n0;  // this block, for the epilogue
+#pragma unroll
+  for (int c = 0; c < 16; ++c)
+#pragma unroll
+    for (int ni = 0; ni < NIW; ++ni) {  // cleared with 64-bit moves: fp32 MFMA and VALU time add up on gfx950, every VALU counts
+      typedef double f64x2 __attribute__((ext_vector_type(2)));
+      acc[c][ni] = __builtin_bit_cast(f32x4, f64x2{0.0, 0.0});
+    }
+  for (int ch = 0; ch + 1 < a.nchunk; ++ch) {
     __syncthreads();  // previous chunk's operand reads done
     store_chunk(ch);
     __syncthreads();
-    load_chunk(ch + 1 < a.nchunk ? ch + 1 : ch);  // in flight during the MFMA phase below (the last one is a harmless repeat)
+    load_chunk(ch + 1);  // in flight during the MFMA phase below
     compute_chunk();
   }
+  // last chunk (peeled, so that the block geometry stays out of the loop above): the loads in flight during its MFMA phase are
+  // chunk 0 of the workgroup's next tile block -- or, for its last block, a harmless repeat
+  __syncthreads();
+  store_chunk(a.nchunk - 1);
+  __syncthreads();
+  if (WT == 4 && next < nblk) block_geometry(next);  // (the 32-tile form is never launched persistent: two workgroups share a CU)
+  load_chunk(0);
+  compute_chunk();
 
   // ---------------------------------------------------------------- epilogue: A^T M A, then the fused point-wise tail
   const float slope_eff = (a.flags & MG_CONV_LRELU) ? a.slope : 1.0f;  // branch-free LeakyReLU switch
@@ -256,7 +286,7 @@ __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(co
   const int txl = tl & (a.TBW - 1);
   const int tyl = (tl >> a.lgTBW) & (a.TBH - 1);
   const int nl = tl >> (a.lgTBW + a.lgTBH);
-  const int n = n0 + nl, TY = by * a.TBH + tyl, TX = bx * a.TBW + txl;
+  const int n = en0 + nl, TY = eby * a.TBH + tyl, TX = ebx * a.TBW + txl;
   const bool tok = (n < a.N) && (TY < Ht) && (TX < Wt);
   const int oc0 = (ct0 + wc * NIW) * 16 + rq * 4;  // out-channel of (ni, g) = oc0 + ni*16 + g
   const size_t pix0 = ((size_t)n * a.Cout * a.H + 2 * TY) * a.W + 2 * TX;  // + oc*H*W + i*W
@@ -578,6 +608,10 @@ __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(co
     else if (a.flags & MG_CONV_POOL_OUT) tail(I0_{}, T_{}, T_{}, F_{}, F_{});
     else tail(I0_{}, F_{}, T_{}, F_{}, F_{});
   }
+  if (WT != 4 || next >= nblk) break;
+  item = next;
+  thread_coords();
+  }
 }
 
 // U = G g G^T for every (out, in) channel pair, written in MFMA operand order (pack_kernels.h):
@@ -696,6 +730,10 @@ int wino_run(WinoArgs& a, bool pn, hipStream_t s) {
   a.blocks_x = mg_cdiv(Wt, a.TBW); a.blocks_y = mg_cdiv(Ht, a.TBH); a.blocks_n = mg_cdiv(N, a.TBN);
   MG_CHECK_ARG((long long)a.TBN * Cin * H * W < (1ll << 29), "mg_wino3x3: image block too large for 32-bit offsets");
   dim3 grid(a.blocks_x * a.blocks_y * a.blocks_n, mg_cdiv(nt, cfg));
+  {  // persistent launch of the 64-tile form: one workgroup per CU, each walking its tile blocks
+    const char* e = getenv("MG_WINO_PERSIST");  // measurement switch: 0 = one workgroup per tile block
+    if (wt == 4 && (e == nullptr || atoi(e) != 0) && (int)grid.x > n_cu) grid.x = n_cu;
+  }
   switch (cfg * 10 + wt) {
     case 44: return launch_wino<2, 2, 4>(a, grid, s);
     case 42: return launch_wino<2, 2, 2>(a, grid, s);
