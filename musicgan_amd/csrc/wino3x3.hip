@@ -37,6 +37,20 @@ namespace {
 constexpr int WCC = 8;  // input channels per LDS chunk
 constexpr float PN_EPS = 1e-8f;
 
+// Packed fp32 subtraction as ONE instruction (hipcc lowers vector subtraction to one v_sub_f32 per element; fp32 MFMA and VALU
+// time add up on gfx950, so every vector instruction of the staging code and the epilogue is matrix time lost).
+typedef float wf32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ wf32x2 pk_sub(wf32x2 x, wf32x2 y) {
+  wf32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(y));
+  return d;
+}
+__device__ __forceinline__ f32x4 pk_sub4(f32x4 x, f32x4 y) {
+  const wf32x2 lo = pk_sub(__builtin_shufflevector(x, x, 0, 1), __builtin_shufflevector(y, y, 0, 1));
+  const wf32x2 hi = pk_sub(__builtin_shufflevector(x, x, 2, 3), __builtin_shufflevector(y, y, 2, 3));
+  return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
 struct WinoArgs {
   const float* x;
   const float* up;
@@ -198,17 +212,18 @@ __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(co
         E[r] = f32x2{ledge[k] ? (a.TBW > 1 ? rE[k][r] : 0.f) : fl, redge[k] ? (a.TBW > 1 ? rE[k][r] : 0.f) : fr};
       }
       f32x2 UE[4], UP[4];  // B^T d (rows)
-      UE[0] = E[0] - E[2];  UP[0] = P[0] - P[2];
-      UE[1] = E[1] + E[2];  UP[1] = P[1] + P[2];
-      UE[2] = E[2] - E[1];  UP[2] = P[2] - P[1];
-      UE[3] = E[1] - E[3];  UP[3] = P[1] - P[3];
+      UE[0] = pk_sub(E[0], E[2]);  UP[0] = pk_sub(P[0], P[2]);
+      UE[1] = E[1] + E[2];         UP[1] = P[1] + P[2];
+      UE[2] = pk_sub(E[2], E[1]);  UP[2] = pk_sub(P[2], P[1]);
+      UE[3] = pk_sub(E[1], E[3]);  UP[3] = pk_sub(P[1], P[3]);
       if (NITEM * NTHR == NITEMS || vdst[k] >= 0) {
         float* dst = Vs + vdst[k];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {  // (B^T d) B (columns); component slots of row i: [v0, v3 | v1, v2]
-          const f32x2 ps = __builtin_shufflevector(UP[i], UP[i], 1, 0);  // (p1, p0)
-          const f32x2 v03 = f32x2{UE[i][0], -UE[i][1]} + f32x2{-ps[0], ps[1]};
-          const f32x2 v12 = UP[i] + f32x2{ps[0], -ps[1]};
+          // one v_pk_add_f32 per result pair, swaps and negations in the operand modifiers (hipcc builds them with v_mov / v_xor)
+          f32x2 v03, v12;
+          asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(v03) : "v"(UE[i]), "v"(UP[i]));  // (e0 - p1, p0 - e1)
+          asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(v12) : "v"(UP[i]));             // (p0 + p1, p1 - p0)
           *reinterpret_cast<f32x2*>(dst + (2 * i) * 256) = v03;
           *reinterpret_cast<f32x2*>(dst + (2 * i + 1) * 256) = v12;
         }
