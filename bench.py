@@ -123,9 +123,9 @@ def dominant_kernel_probe(device, batch: int, iters: int = 10):
     w = torch.randn(64, 48, 3, 3, device=device, generator=g) * 0.04
     b = torch.randn(64, device=device, generator=g)
     up = ops.pack_wino3x3(w, dgrad=False)
-    y = torch.empty(n, 64, 128, 128, device=device)
     q = torch.empty(n, 64, 64, 64, device=device)
-    fn = lambda: ops.conv3x3(x, None, b, 64, lrelu=True, out=y, pool_out=q, wino=up)  # as engine.disc_step_fused calls it
+    # as engine.disc_forward calls it: pooled result + one sign byte per 2x2 tile (the full-resolution activation is not written)
+    fn = lambda: ops.conv3x3(x, None, b, 64, lrelu=True, pool_out=q, wino=up, mask_out=True)
     for _ in range(2):
         fn()
     stream = torch.cuda.current_stream()
@@ -137,9 +137,9 @@ def dominant_kernel_probe(device, batch: int, iters: int = 10):
     e1.synchronize()
     ms = e0.elapsed_time(e1) / iters
     flop = 2.0 * 9 * 48 * 64 * 128 * 128 * n
-    out = {"name": "wino3x3_mfma<2,2,4> Winograd F(2x2,3x3) conv 48->64@128x128 + lrelu + avgpool, 3x batch", "ms": ms,
+    out = {"name": "wino3x3_mfma<2,2,4> Winograd F(2x2,3x3) conv 48->64@128x128 + lrelu + avgpool + tile mask, 3x batch", "ms": ms,
            "flop": flop, "tflops": flop / ms / 1e9, "executed_tflops": flop / 2.25 / ms / 1e9,
-           "algorithmic_bytes": 4.0 * n * (48 * 128 * 128 + 64 * 128 * 128 + 64 * 64 * 64)}
+           "algorithmic_bytes": n * (4.0 * 48 * 128 * 128 + 4.0 * 64 * 64 * 64 + 1.0 * 64 * 64 * 64)}
     # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), measured by tools/measure_traffic.sh
     tpath = os.path.join(ROOT, "profiles", "traffic_dominant_kernel.json")
     if os.path.exists(tpath):

@@ -1,5 +1,5 @@
 #!/bin/bash
-# HBM traffic of the dominant kernel (Winograd conv 48->64@128x128 + lrelu + avgpool over 3x64 images) from rocprofv3 PMC counters, collected in
+# HBM traffic of the dominant kernel (Winograd conv 48->64@128x128 + lrelu + avgpool + tile mask over 3x64 images) from rocprofv3 PMC counters, collected in
 # separate passes as /opt/skills/guides/MI355X_MICROARCH.md prescribes (FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2; on gfx950
 # FETCH_SIZE reports half the bytes of a wide coalesced stream -> x2).  Run on the GPU box from the repo root:
 #   bash tools/measure_traffic.sh        -> profiles/traffic_dominant_kernel.json
@@ -17,10 +17,10 @@ def avg(kind, name):
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "wino3x3_mfma" in r["Kernel_Name"] and r["Counter_Name"] == name]
     return sum(v) / len(v)
 fetch_kb, write_kb = avg("fetch", "FETCH_SIZE"), avg("write", "WRITE_SIZE")
-out = {"kernel": "wino3x3_mfma<2,2,4> lrelu+avgpool 48->64@128x128, 192 images (y and pooled y written)",
+out = {"kernel": "wino3x3_mfma<2,2,4> lrelu+avgpool+tile mask 48->64@128x128, 192 images (pooled y and mask bytes written)",
        "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB": write_kb, "fetch_correction": 2.0,
        "bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
-       "algorithmic_bytes": 4.0 * 192 * (48 * 128 * 128 + 64 * 128 * 128 + 64 * 64 * 64)}
+       "algorithmic_bytes": 192 * (4.0 * 48 * 128 * 128 + 4.0 * 64 * 64 * 64 + 1.0 * 64 * 64 * 64)}
 out["traffic_over_algorithmic"] = out["bytes_per_launch"] / out["algorithmic_bytes"]
 json.dump(out, open(f"{R}/gpurun_out/traffic_dominant_kernel.json", "w"), indent=1)
 print(json.dumps(out))

@@ -20,10 +20,10 @@ elif case == "w20":    # wgrad 48->64 @128
 elif case == "w54":
     x = R(N, 64, 64, 64); gy = R(N, 48, 128, 128); gw = torch.empty(48, 64, 3, 3, device=dev); gb = torch.empty(48, device=dev)
     fn = lambda: ops.conv3x3_wgrad(x, gy, gw, gb, ups=True)
-elif case == "wino3n":  # the step's dominant launch: Winograd conv 48->64 @128 + lrelu + fused pool over 3N images
+elif case == "wino3n":  # the step's dominant launch: Winograd conv 48->64 @128 + lrelu + fused pool + tile mask over 3N images
     x = R(3 * N, 48, 128, 128); up = ops.pack_wino3x3(R(64, 48, 3, 3) * 0.05, False); b = R(64)
-    y = torch.empty(3 * N, 64, 128, 128, device=dev); q = torch.empty(3 * N, 64, 64, 64, device=dev)
-    fn = lambda: ops.conv3x3(x, None, b, 64, lrelu=True, out=y, pool_out=q, wino=up)
+    q = torch.empty(3 * N, 64, 64, 64, device=dev)
+    fn = lambda: ops.conv3x3(x, None, b, 64, lrelu=True, pool_out=q, wino=up, mask_out=True)
 elif case == "wino":   # Winograd conv 48->64 @128 + lrelu + fused pool
     x = R(N, 48, 128, 128); up = ops.pack_wino3x3(R(64, 48, 3, 3) * 0.05, False); b = R(64)
     fn = lambda: ops.conv3x3(x, None, b, 64, lrelu=True, pool=True, wino=up)
