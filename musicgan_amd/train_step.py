@@ -40,7 +40,7 @@ class ProGANStepper:
         self.rand_channels, self.h, self.w = rand_channels, height, width
         self.fused_d_step = fused_d_step
         self.dp = is_distributed()
-        self.use_graphs = (not self.dp) and fused_d_step and os.environ.get("MG_GRAPHS", "1") != "0"
+        self.use_graphs = fused_d_step and os.environ.get("MG_GRAPHS", "1") != "0"
         self._graphs: Dict[tuple, dict] = {}
         from . import ops
         self._defer_d, self._defer_g = ops.WgradDefer(), ops.WgradDefer()  # one-launch weight-gradient reductions per sweep
@@ -97,7 +97,7 @@ class ProGANStepper:
         return {"disc_loss": disc_loss.detach(), "grad_pen": grad_pen.detach(),
                 "out_real_mean": out_real.detach().mean(), "out_fake_mean": out_fake.detach().mean()}
 
-    def _d_step_fused(self, x_real, alpha, z, eps) -> Dict[str, torch.Tensor]:
+    def _d_step_fused(self, x_real, alpha, z, eps, update_in_line: bool = True) -> Dict[str, torch.Tensor]:
         """Same update as the module path above through `engine.disc_step_fused`: one batched critic pass over
         [real | fake | interpolated] instead of three, one weight-gradient launch per layer."""
         from .networks import engine
@@ -105,7 +105,9 @@ class ProGANStepper:
         dev = x_real.device
         if eps is None:
             eps = torch.rand(n, 1, 1, 1, device=dev, generator=self.noise)
-        if self.dp:
+        if self.dp and not update_in_line:
+            pass  # (graph replay: the caller has joined the side streams before the replay)
+        elif self.dp:
             self.bucket_d.wait()
             self.bucket_g.wait()
         xcat = torch.empty((3 * n,) + tuple(x_real.shape[1:]), dtype=torch.float32, device=dev)
@@ -123,7 +125,8 @@ class ProGANStepper:
         self.disc.zero_grad()
         for p in W.tensors():
             p.grad = sink.get(p)
-        self._update(self.bucket_d, self.disc, self.optim_disc)
+        if update_in_line:
+            self._update(self.bucket_d, self.disc, self.optim_disc)
         return {"disc_loss": disc_loss, "grad_pen": grad_pen, "out_real_mean": stats[0], "out_fake_mean": stats[1]}
 
     def g_step(self, batch_size: int, alpha: float, device, z: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
@@ -153,11 +156,13 @@ class ProGANStepper:
         self._update(self.bucket_g, self.gen, self.optim_gen)
         return {"gen_loss": gen_loss.detach(), "out_fake_mean": out_fake.detach().mean()}
 
-    def _g_step_fused(self, z, alpha) -> Dict[str, torch.Tensor]:
+    def _g_step_fused(self, z, alpha, update_in_line: bool = True) -> Dict[str, torch.Tensor]:
         """The generator update through `engine.gen_step_fused` (no autograd graph, no critic weight gradients)."""
         from .networks import engine
         before_disc = None
-        if self.dp:
+        if self.dp and not update_in_line:
+            self._refresh_packs()  # (graph replay: the caller has joined the side streams before the replay)
+        elif self.dp:
             # G's forward runs while the critic's gradient exchange + Adam are still on the side stream; the critic's weights
             # (and their packed layouts) are only touched behind bucket_d.wait()
             self.bucket_g.wait()
@@ -177,7 +182,8 @@ class ProGANStepper:
         self.disc.zero_grad()
         for p in Wg.tensors():
             p.grad = sink.get(p)
-        self._update(self.bucket_g, self.gen, self.optim_gen)
+        if update_in_line:
+            self._update(self.bucket_g, self.gen, self.optim_gen)
         return {"gen_loss": gen_loss, "out_fake_mean": stats[0]}
 
     def _refresh_packs(self) -> None:
@@ -194,8 +200,13 @@ class ProGANStepper:
         net, other = (self.disc, self.gen) if kind == "D" else (self.gen, self.disc)
         key = (kind, self.gen.curr_layer, tuple(tuple(t.shape) for t in inputs), tuple(id(p) for p in net.parameters()))
 
-        def run(fade, *a):
-            return self._d_step_fused(a[0], fade, a[1], a[2]) if kind == "D" else self._g_step_fused(a[0], fade)
+        # Data-parallel: the graph ends with the gradients in the bucket's flat buffer; the exchange (RCCL, side stream) and Adam
+        # behind it stay outside, so a replay is bracketed by "join the side streams" and "launch the exchange".
+        in_line = not self.dp
+
+        def run(fade, *a, captured=False):
+            upd = in_line or not captured
+            return self._d_step_fused(a[0], fade, a[1], a[2], upd) if kind == "D" else self._g_step_fused(a[0], fade, upd)
         ent = self._graphs.get(key)
         if ent is None:
             # growth or a new batch shape: graphs of other levels (and their private memory pools, GBs at the large levels)
@@ -212,6 +223,8 @@ class ProGANStepper:
             # capture: static copies of the inputs, every weight form re-packed inside the graph (caches emptied first), the
             # gradients and the four scalars the caller reads live in the graph's pool
             ent["inputs"] = [t.detach().clone().contiguous() for t in inputs]
+            if self.dp:
+                self.finish()
             net.zero_grad()
             other.zero_grad()
             torch.cuda.synchronize()
@@ -222,14 +235,15 @@ class ProGANStepper:
             graph = torch.cuda.CUDAGraph()
             # thread_local: loader threads (pinned-memory staging, uploads on their own stream) keep working during the capture
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                m = run(FadeIn(alpha, dev=self._fade), *ent["inputs"])
+                m = run(FadeIn(alpha, dev=self._fade), *ent["inputs"], captured=True)
                 ent["names"] = list(m.keys())
                 ent["out"] = torch.stack([m[k].reshape(()) for k in ent["names"]])
             ent["graph"] = graph
             ent["grads"] = [(p, p.grad) for p in net.parameters() if p.grad is not None]
             opt = self.optim_disc if kind == "D" else self.optim_gen
-            for p, _ in ent["grads"]:  # the captured optimizer step advanced the host mirrors, but nothing ran yet
-                opt.state[p]["step"] -= 1
+            if in_line:
+                for p, _ in ent["grads"]:  # the captured optimizer step advanced the host mirrors, but nothing ran yet
+                    opt.state[p]["step"] -= 1
             # the captured run itself did not execute: fall through to the first replay with the caller's inputs
         for dst, src in zip(ent["inputs"], inputs):
             dst.copy_(src)
@@ -237,12 +251,18 @@ class ProGANStepper:
             self._fade[0:1].fill_(float(alpha))
             self._fade[1:2].fill_(1.0 - float(alpha))
             self._fade_value = float(alpha)
+        if self.dp:  # both networks' weights final before the replay reads them
+            self.bucket_d.wait()
+            self.bucket_g.wait()
         ent["graph"].replay()
         self.gen.zero_grad()
         self.disc.zero_grad()
         for p, g in ent["grads"]:
             p.grad = g
-        (self.optim_disc if kind == "D" else self.optim_gen).note_replay([p for p, _ in ent["grads"]])
+        if in_line:
+            (self.optim_disc if kind == "D" else self.optim_gen).note_replay([p for p, _ in ent["grads"]])
+        else:
+            self._update(self.bucket_d if kind == "D" else self.bucket_g, net, self.optim_disc if kind == "D" else self.optim_gen)
         out = ent["out"].clone()
         return {k: out[i] for i, k in enumerate(ent["names"])}
 

@@ -48,21 +48,23 @@ def _run(steps, level=3, batch=4):
 
 
 def test_data_parallel_path_is_bit_identical_to_single_process(one_rank_nccl, monkeypatch):
-    """Three critic + two generator updates through the final stepper (fused critic step) with the DP machinery live, against
-    the same run without it: every weight bit-identical, every loss equal."""
-    st_dp, w_dp, l_dp = _run(3)
+    """Six critic + three generator updates through the final stepper (fused critic step; the third call of each kind captures
+    and replays its HIP graph -- under DP the graph ends with the gradients in the flat bucket and the exchange + Adam follow it on
+    the side stream) with the DP machinery live, against the same run without it: every weight bit-identical, every loss equal."""
+    st_dp, w_dp, l_dp = _run(6)
+    assert st_dp.use_graphs and len(st_dp._graphs) == 2 and all("graph" in e for e in st_dp._graphs.values())
     assert st_dp.dp and st_dp.bucket_d.stream() is not None and st_dp.bucket_g.stream() is not None
     assert st_dp.optim_disc.grad_scale == 1.0
     monkeypatch.setenv("MG_FORCE_DP", "0")
-    st_sp, w_sp, l_sp = _run(3)
+    st_sp, w_sp, l_sp = _run(6)
     assert not st_sp.dp
     assert l_dp == l_sp
     assert w_dp.keys() == w_sp.keys()
     for k in w_dp:
         assert torch.equal(w_dp[k], w_sp[k]), k
     # gradients of the DP run are views into ONE flat buffer per network (what was all-reduced)
-    flat = st_dp.bucket_g._flat  # the run's last update was a generator step
-    live = [p for p in st_dp.gen.parameters() if p.grad is not None]
+    flat = st_dp.bucket_d._flat  # the run's last update was a critic step (a graph replay)
+    live = [p for p in st_dp.disc.parameters() if p.grad is not None]
     assert flat is not None and sum(p.numel() for p in live) == flat.numel()
     assert all(flat.data_ptr() <= p.grad.data_ptr() < flat.data_ptr() + 4 * flat.numel() for p in live)
 
