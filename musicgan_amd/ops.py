@@ -284,13 +284,14 @@ def upconv3x3_dgrad(gy, wp, cin: int):
 
 
 def wino_wgrad_supported(n: int, cin: int, cout: int, h: int, w: int, *, ups=False) -> bool:
-    """Whether conv3x3_wgrad takes the Winograd F(3x3,2x2) kernel: even sizes, enough 2x2 tiles for its split-K pipeline, byte
-    offsets within 31 bits."""
+    """Whether conv3x3_wgrad takes the Winograd F(3x3,2x2) kernel: even sizes, byte offsets within 31 bits.  The size threshold is
+    low on purpose: with the slab reductions of a sweep in one launch the Winograd form beats the direct one down to 2x2 maps
+    (threshold sweep 8192 -> 64: level 5 15.35 -> 15.22 ms, level 4 5.15 -> 5.02, level 3 2.73 -> 2.59)."""
     if os.environ.get("MG_WINO_WGRAD", "1") == "0" or (h % 2) or (w % 2):
         return False
     if n * max(cin, cout) * h * w >= (1 << 29):
         return False
-    return n * h * w >= int(os.environ.get("MG_WINO_WGRAD_MIN_PIXELS", "8192"))
+    return n * h * w >= int(os.environ.get("MG_WINO_WGRAD_MIN_PIXELS", "64"))
 
 
 class WgradDefer:
