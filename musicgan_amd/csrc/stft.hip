@@ -218,7 +218,9 @@ __global__ void __launch_bounds__(64 * NWAVE, 2) stft1024_kernel(const float* __
     }
     __syncthreads();
     // transposed write-out: the 16 frames of one bin row per 8 lanes, two frames (16 bytes) per lane -- stores are issue-bound per
-    // instruction, so half as many twice as wide; a store instruction writes eight 128-byte runs along t
+    // instruction, so half as many twice as wide; a store instruction writes eight 128-byte runs along t.  Non-temporal stores:
+    // the bins are written once and not read back by this kernel, and keeping them out of the L2's way is worth 6-8 %
+    // (0.146-0.166 -> 0.136-0.152 ms per 10-minute file, same box, alternating libraries)
     {
       const int fp = tid & (FPB / 2 - 1);  // frame pair
       const int t = t0 + 2 * fp;
@@ -227,7 +229,7 @@ __global__ void __launch_bounds__(64 * NWAVE, 2) stft1024_kernel(const float* __
 #pragma unroll 4
           for (int k = tid / (FPB / 2); k < NB; k += 64 * NWAVE / (FPB / 2)) {
             const c2 o0 = xbuf[(2 * fp) * XSTR + k], o1 = xbuf[(2 * fp + 1) * XSTR + k];
-            *reinterpret_cast<f32x4*>(out_re + 2 * ((size_t)k * T + t)) = f32x4{o0.x, o0.y, o1.x, o1.y};
+            __builtin_nontemporal_store(f32x4{o0.x, o0.y, o1.x, o1.y}, reinterpret_cast<f32x4*>(out_re + 2 * ((size_t)k * T + t)));
           }
         }
       } else {
@@ -239,10 +241,10 @@ __global__ void __launch_bounds__(64 * NWAVE, 2) stft1024_kernel(const float* __
             const c2 o = xbuf[f * XSTR + k];
             const size_t idx = (size_t)k * T + tt;
             if (out_im != nullptr) {
-              out_re[idx] = o.x;
-              out_im[idx] = o.y;
+              __builtin_nontemporal_store(o.x, out_re + idx);
+              __builtin_nontemporal_store(o.y, out_im + idx);
             } else {
-              *reinterpret_cast<c2*>(out_re + 2 * idx) = o;
+              __builtin_nontemporal_store(o, reinterpret_cast<c2*>(out_re + 2 * idx));
             }
           }
         }
