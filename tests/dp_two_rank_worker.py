@@ -1,0 +1,59 @@
+"""Worker of tests/test_dp_gpu.py::test_two_ranks_sharing_the_gpu_equal_one_process_on_the_concatenated_batch.
+
+Launched by torch.distributed.run with 2 ranks (backend gloo: both ranks sit on the ONE GPU of the test box, which RCCL refuses;
+the gradient exchange code above the backend is the same) or stand-alone with WORLD_SIZE unset (the single-process reference on
+the concatenated batch).  Every rank runs the product's ProGANStepper for STEPS critic updates (the third one is captured and
+replayed as a HIP graph) on its slice of fixed inputs and rank 0 saves the mean gradient of each critic update."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main(out_path: str) -> None:
+    import torch.distributed as dist
+    import bench
+    from musicgan_amd.optim import FusedAdam
+    from musicgan_amd.train_step import ProGANStepper
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    level, per_rank, steps = 3, 4, 4
+    gen, disc = bench.build_nets(level, 32, dev)
+    # a tiny learning rate: the comparison is about gradients; Adam's first steps are sign-like (beta1 = 0) and would turn
+    # round-off differences of near-zero gradient entries into +-lr weight differences that the next gradient then sees
+    og = FusedAdam(gen.parameters(), lr=1e-6, betas=(0.0, 0.9))
+    od = FusedAdam(disc.parameters(), lr=1e-6, betas=(0.0, 0.9))
+    st = ProGANStepper(gen, disc, og, od, 32)
+    assert st.dp == (world > 1) and st.use_graphs
+    side = bench.LEVEL_SIDE[level]
+    g = torch.Generator(device="cpu").manual_seed(5)
+    total = 2 * per_rank  # the global batch, whoever computes it
+    grads = []
+    for i in range(steps):
+        x = (torch.rand(total, 2, side, side, generator=g) * 2 - 1).to(dev)
+        z = torch.randn(total, 32, 2, 2, generator=g).to(dev)
+        eps = torch.rand(total, 1, 1, 1, generator=g).to(dev)
+        sl = slice(rank * per_rank, (rank + 1) * per_rank) if world > 1 else slice(0, total)
+        st.d_step(x[sl].contiguous(), 0.5, z=z[sl].contiguous(), eps=eps[sl].contiguous())
+        st.finish()
+        torch.cuda.synchronize()
+        scale = st.bucket_d.grad_scale if world > 1 else 1.0  # DP keeps the SUM in .grad, the mean goes into Adam
+        grads.append({k: (p.grad * scale).cpu() for k, p in disc.named_parameters() if p.grad is not None})
+    if world > 1:
+        assert all("graph" in e for e in st._graphs.values()) and len(st._graphs) == 1
+        dist.barrier()
+    if rank == 0:
+        torch.save(grads, out_path)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

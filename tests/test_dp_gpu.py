@@ -89,3 +89,32 @@ def test_bench_runs_under_torchrun_as_the_driver_launches_it(tmp_path):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["parallelism"] == "dp1" and "workload" in d["config"]
+
+
+def test_two_ranks_sharing_the_gpu_equal_one_process_on_the_concatenated_batch(tmp_path):
+    """N = 2 for real: two processes (gloo -- both ranks on this box's one GPU, which RCCL does not allow; everything above the
+    backend is the product's DP path: flat bucket, side stream, exchange, fused Adam with 1/world, HIP-graph replay of the
+    gradient computation from the third update on) each take half of a fixed batch; the mean gradient of every critic update
+    must equal the single-process gradient on the whole batch within fp32 summation noise."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    worker = os.path.join(root, "tests", "dp_two_rank_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MG_FORCE_DP="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
+    r = subprocess.run([sys.executable, worker, one], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29900 + os.getpid() % 90), worker, two]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    g1, g2 = torch.load(one), torch.load(two)
+    assert len(g1) == len(g2) == 4
+    for step, (a, b) in enumerate(zip(g1, g2)):
+        assert a.keys() == b.keys() and len(a) > 10
+        for k in a:
+            scale = float(a[k].abs().max()) + 1e-12
+            err = float((a[k] - b[k]).abs().max())
+            assert err <= 2e-4 * scale + 1e-7, f"update {step} {k}: {err:.2e} vs max {scale:.2e}"
