@@ -261,25 +261,21 @@ __global__ void __launch_bounds__(256) conv1x1_wgrad_part(const W1Args a) {
   }
   // wave reduce, then across the 4 waves through LDS
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  auto wred = [&](float v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-    return v;
-  };
+  // (84 values per wave: DPP adds, not shuffles -- the shuffle butterflies alone took 25 us per launch)
 #pragma unroll
   for (int m = 0; m < MC; ++m) {
 #pragma unroll
     for (int f = 0; f < FEW; ++f) {
-      const float r = wred(s[m][f]);
-      if (lane == 0) red[wave][m * (FEW + 1) + f] = r;
+      const float r = mg_wave_sum_to_lane63(s[m][f]);
+      if (lane == 63) red[wave][m * (FEW + 1) + f] = r;
     }
-    const float r = wred(sm[m]);
-    if (lane == 0) red[wave][m * (FEW + 1) + FEW] = r;
+    const float r = mg_wave_sum_to_lane63(sm[m]);
+    if (lane == 63) red[wave][m * (FEW + 1) + FEW] = r;
   }
 #pragma unroll
   for (int f = 0; f < FEW; ++f) {
-    const float r = wred(sf[f]);
-    if (lane == 0) red[wave][MC * (FEW + 1) + f] = r;
+    const float r = mg_wave_sum_to_lane63(sf[f]);
+    if (lane == 63) red[wave][MC * (FEW + 1) + f] = r;
   }
   __syncthreads();
   const int per = MC * (FEW + 1) + FEW;

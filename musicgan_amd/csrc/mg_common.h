@@ -1,5 +1,6 @@
 // Shared host/device helpers for libmusicgan_hip.so (gfx950 only).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -60,6 +61,24 @@ __host__ __device__ static inline int mg_cdiv(int a, int b) { return (a + b - 1)
 __device__ __forceinline__ int mg_xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// Sum over the 64 lanes of a wave with DPP adds (6 vector instructions, no LDS round trips); the total ends up in LANE 63
+// (every lane of the last row of 16, in fact).  A __shfl_xor butterfly is 6 dependent ds_bpermute round trips (~100 cycles
+// each): fine for one value per wave, 25 us for the 84 partial sums of conv1x1_wgrad_part.  Fixed order => deterministic.
+__device__ __forceinline__ float mg_wave_sum_to_lane63(float v) {
+  auto dpp_add = [](float x, auto ctrl_, auto rmask_) {
+    constexpr int CTRL = decltype(ctrl_)::value, RMASK = decltype(rmask_)::value;
+    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, RMASK, 0xf, true));
+  };
+  using I = int;
+  v = dpp_add(v, std::integral_constant<I, 0xB1>{}, std::integral_constant<I, 0xf>{});   // quad_perm [1,0,3,2]
+  v = dpp_add(v, std::integral_constant<I, 0x4E>{}, std::integral_constant<I, 0xf>{});   // quad_perm [2,3,0,1]
+  v = dpp_add(v, std::integral_constant<I, 0x141>{}, std::integral_constant<I, 0xf>{});  // row_half_mirror
+  v = dpp_add(v, std::integral_constant<I, 0x140>{}, std::integral_constant<I, 0xf>{});  // row_mirror: every lane = its row's sum
+  v = dpp_add(v, std::integral_constant<I, 0x142>{}, std::integral_constant<I, 0xa>{});  // row_bcast15 into rows 1, 3
+  v = dpp_add(v, std::integral_constant<I, 0x143>{}, std::integral_constant<I, 0xc>{});  // row_bcast31 into rows 2, 3
+  return v;
 }
 
 __device__ __forceinline__ float mg_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
