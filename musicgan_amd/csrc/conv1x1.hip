@@ -3,6 +3,8 @@
 // [generator.py:43-52], their data gradients (weights used transposed) and weight/bias gradients.
 // These are HBM-bound streams (2 <-> 48..160 channels per pixel): one thread owns 4 consecutive pixels (16-byte
 // accesses), channel loops run in registers, weights come through the scalar cache.
+#include <type_traits>
+
 #include "mg_common.h"
 
 namespace {
@@ -59,35 +61,49 @@ __global__ void __launch_bounds__(256) conv1x1_few_in(const C1Args a) {
       }
     }
     const int o_lo = blockIdx.y * a.co_per, o_hi = o_lo + a.co_per < a.Cout ? o_lo + a.co_per : a.Cout;
-    for (int o = o_lo; o < o_hi; ++o) {
-      const float b = a.bias ? a.bias[o] : 0.f;
-      float acc[V];
+    // 8 out-channels at a time: their bias, weights (and mask values) are requested before any of them is used -- written as
+    // one loop over o, every iteration waited for its own scalar loads (one memory round trip per out-channel)
+    constexpr int OB = 8;
+    const bool has_mask = (a.flags & MG_C1_MASK_AUX) != 0;
+    for (int ob = o_lo; ob < o_hi; ob += OB) {
+      float bv[OB], wv[OB][FEW], mv[OB][V];
 #pragma unroll
-      for (int v = 0; v < V; ++v) acc[v] = b;
+      for (int u = 0; u < OB; ++u) {
+        const int o = ob + u < o_hi ? ob + u : o_hi - 1;
+        bv[u] = a.bias ? a.bias[o] : 0.f;
 #pragma unroll
-      for (int c = 0; c < FEW; ++c) {
-        if (c < a.Cin) {
-          const float wv = a.w[o * a.so + c * a.sc];
+        for (int c = 0; c < FEW; ++c) wv[u][c] = a.w[o * a.so + (c < a.Cin ? c : 0) * a.sc];
+        if (has_mask) load_v<V>(a.aux + ((size_t)n * a.Cout + o) * a.HW + p, mv[u]);
+      }
 #pragma unroll
-          for (int v = 0; v < V; ++v) acc[v] = fmaf(wv, xv[c][v], acc[v]);
+      for (int u = 0; u < OB; ++u) {
+        const int o = ob + u;
+        if (o >= o_hi) break;
+        float acc[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[v] = bv[u];
+#pragma unroll
+        for (int c = 0; c < FEW; ++c) {
+          if (c < a.Cin) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v] = fmaf(wv[u][c], xv[c][v], acc[v]);
+          }
         }
-      }
-      const size_t oidx = ((size_t)n * a.Cout + o) * a.HW + p;
-      float mv[V];
-      if (a.flags & MG_C1_MASK_AUX) load_v<V>(a.aux + oidx, mv);
+        const size_t oidx = ((size_t)n * a.Cout + o) * a.HW + p;
 #pragma unroll
-      for (int v = 0; v < V; ++v) {
-        float r = acc[v];
-        if (a.flags & MG_C1_LRELU) r = mg_lrelu(r, a.slope);
-        if (a.flags & MG_C1_TANH) r = tanhf(r);
-        if (a.flags & MG_C1_MASK_AUX) r *= mg_lrelu_mask(mv[v], a.slope);
-        acc[v] = r;
-      }
-      if (V == 4) {
-        *reinterpret_cast<f32x4*>(a.y + oidx) = f32x4{acc[0], acc[1], acc[2], acc[3]};
-      } else {
+        for (int v = 0; v < V; ++v) {
+          float r = acc[v];
+          if (a.flags & MG_C1_LRELU) r = mg_lrelu(r, a.slope);
+          if (a.flags & MG_C1_TANH) r = tanhf(r);
+          if (has_mask) r *= mg_lrelu_mask(mv[u][v], a.slope);
+          acc[v] = r;
+        }
+        if (V == 4) {
+          *reinterpret_cast<f32x4*>(a.y + oidx) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+        } else {
 #pragma unroll
-        for (int v = 0; v < V; ++v) a.y[oidx + v] = acc[v];
+          for (int v = 0; v < V; ++v) a.y[oidx + v] = acc[v];
+        }
       }
     }
   }
@@ -98,7 +114,7 @@ __global__ void __launch_bounds__(256) conv1x1_few_in(const C1Args a) {
 // channels of 64 pixels (lane = pixel, so loads stay coalesced) and combine their partial sums through LDS in a fixed order.
 __global__ void __launch_bounds__(256) conv1x1_few_out_split(const C1Args a) {
   __shared__ float red[3][FEW][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform: weights via SMEM
   const size_t total = (size_t)a.N * a.HW;
   for (size_t base = (size_t)blockIdx.x * 64; base < total; base += (size_t)gridDim.x * 64) {
     const size_t i = base + lane;
@@ -109,15 +125,38 @@ __global__ void __launch_bounds__(256) conv1x1_few_out_split(const C1Args a) {
 #pragma unroll
     for (int o = 0; o < FEW; ++o) acc[o] = 0.f;
     const float* xp = a.x + (size_t)n * a.Cin * a.HW + p;
-    if (ok) {
-#pragma unroll 4
-      for (int c = wave; c < a.Cin; c += 4) {
-        float xv = xp[(size_t)c * a.HW];
-        if (a.flags & MG_C1_MASK_AUX) xv *= mg_lrelu_mask(a.aux[((size_t)n * a.Cin + c) * a.HW + p], a.slope);
+    // Loads first, arithmetic second, 8 channels at a time and branch-free (out-channels beyond Cout re-read channel 0's weight
+    // into an accumulator nobody looks at; channels beyond Cin re-read the wave's first channel and are multiplied by 0; the
+    // mask is a compile-time variant).  Written as a plain loop hipcc re-uses one register set per channel and waits for
+    // every load before issuing the next: three memory round trips per channel, 8-12 us per launch whatever the size.
+    auto channel_loop = [&](auto masked_) __attribute__((always_inline)) {
+      constexpr bool MASKED = decltype(masked_)::value;
+      constexpr int U = 8;
+      int wo[FEW];
 #pragma unroll
-        for (int o = 0; o < FEW; ++o)
-          if (o < a.Cout) acc[o] = fmaf(a.w[o * a.so + c * a.sc], xv, acc[o]);
+      for (int o = 0; o < FEW; ++o) wo[o] = (o < a.Cout ? o : 0) * a.so;
+      for (int c0 = wave; c0 < a.Cin; c0 += 4 * U) {
+        float xv[U], mv[U], wv[U][FEW];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int c = c0 + 4 * u < a.Cin ? c0 + 4 * u : wave;
+          xv[u] = xp[(size_t)c * a.HW];
+          mv[u] = MASKED ? a.aux[((size_t)n * a.Cin + c) * a.HW + p] : 1.f;
+#pragma unroll
+          for (int o = 0; o < FEW; ++o) wv[u][o] = a.w[wo[o] + c * a.sc];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          float xm = c0 + 4 * u < a.Cin ? xv[u] : 0.f;
+          if constexpr (MASKED) xm *= mg_lrelu_mask(mv[u], a.slope);
+#pragma unroll
+          for (int o = 0; o < FEW; ++o) acc[o] = fmaf(wv[u][o], xm, acc[o]);
+        }
       }
+    };
+    if (ok) {
+      if (a.flags & MG_C1_MASK_AUX) channel_loop(std::true_type{});
+      else channel_loop(std::false_type{});
     }
     if (wave > 0) {
 #pragma unroll
@@ -244,17 +283,22 @@ __global__ void __launch_bounds__(256) conv1x1_wgrad_part(const W1Args a) {
         for (int v = 0; v < V; ++v) sf[f] += fv[f][v];
       }
     }
+    // the MC loads first (channels past Cm re-read the last one and are discarded), then the arithmetic: with the range test
+    // around each load hipcc waits for one load before it issues the next
+    float mvs[MC][V];
+#pragma unroll
+    for (int m = 0; m < MC; ++m) {
+      const int mm = m0 + m < a.Cm ? m0 + m : a.Cm - 1;
+      load_v<V>(a.many + ((size_t)n * a.Cm + mm) * a.HW + p, mvs[m]);
+    }
 #pragma unroll
     for (int m = 0; m < MC; ++m) {
       if (m0 + m < a.Cm) {
-        const size_t idx = ((size_t)n * a.Cm + m0 + m) * a.HW + p;
-        float mv[V];
-        load_v<V>(a.many + idx, mv);
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-          sm[m] += mv[v];
+          sm[m] += mvs[m][v];
 #pragma unroll
-          for (int f = 0; f < FEW; ++f) s[m][f] = fmaf(mv[v], fv[f][v], s[m][f]);
+          for (int f = 0; f < FEW; ++f) s[m][f] = fmaf(mvs[m][v], fv[f][v], s[m][f]);
         }
       }
     }

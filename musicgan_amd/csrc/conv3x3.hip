@@ -382,15 +382,20 @@ __global__ void __launch_bounds__(256) conv3x3_mfma(const ConvArgs a) {
 // tile would hold 64..256 samples with a 4x..9x halo and 5 of 9 taps entirely in the zero padding; here one thread owns one
 // output value, lanes run along the output channel (coalesced packed weights), and only in-range taps are visited.
 __global__ void __launch_bounds__(256) conv3x3_tiny(const ConvArgs a) {
+  // workgroup = 64 consecutive output values (lane = out-channel: coalesced packed weights); its 4 waves split the input channels
+  // and combine their partial sums through LDS in a fixed order -- a single thread walking all 160 channels is a chain of memory
+  // round trips (19-25 us per launch with 4 loads in flight, 10 with 16; this form keeps 8-10 batches of them in parallel)
+  __shared__ double part[3][64];
   const int HW = a.H * a.W;
   const size_t total = (size_t)a.N * HW * a.OPF;
-  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= total) return;
-  const int o = (int)(e % a.OPF);
-  const size_t r = e / a.OPF;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t e = (size_t)blockIdx.x * 64 + lane;
+  const bool live = e < total;
+  const int o = live ? (int)(e % a.OPF) : 0;
+  const size_t r = live ? e / a.OPF : 0;
   const int pix = (int)(r % HW);
   const int n = (int)(r / HW);
-  if (o >= a.Cout) return;
+  const bool act = live && o < a.Cout;
   const int y = pix / a.W, x = pix - y * a.W;
   const bool ups = (a.flags & MG_CONV_UPS_IN) != 0;
   const int HWin = a.Hin * a.Win;
@@ -398,16 +403,33 @@ __global__ void __launch_bounds__(256) conv3x3_tiny(const ConvArgs a) {
   // fp64 accumulation (each fp32 product is exact in fp64; the work is a few hundred fmas per thread on a full-rate fp64 VALU): this
   // layer's output is the classifier's input, and the classifier weight gradient -- a difference of mean features -- inherits its
   // round-off one to one (tools/diag_act_noise.py: 4.2x the CPU library's rms error with a sequential fp32 sum, 1x with this)
-  double acc64 = a.bias != nullptr ? (double)a.bias[o] : 0.0;
-  for (int t = 0; t < 9; ++t) {
-    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-    if (yy < 0 || yy >= a.H || xx < 0 || xx >= a.W) continue;
-    const int sp = ups ? (yy >> 1) * a.Win + (xx >> 1) : yy * a.Win + xx;
-    const float* wt = a.wp + (size_t)t * CC * a.OPF + o;
-#pragma unroll 4
-    for (int c = 0; c < a.Cin; ++c)
-      acc64 += (double)xn[(size_t)c * HWin + sp] * (double)wt[((size_t)(c >> 3) * 9 * CC + (c & 7)) * a.OPF];
+  double acc64 = 0.0;
+  if (act) {
+    for (int t = 0; t < 9; ++t) {
+      const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+      if (yy < 0 || yy >= a.H || xx < 0 || xx >= a.W) continue;
+      const int sp = ups ? (yy >> 1) * a.Win + (xx >> 1) : yy * a.Win + xx;
+      const float* wt = a.wp + (size_t)t * CC * a.OPF + o;
+      // loads first, arithmetic second, 8 channels at a time (as a plain loop hipcc waits for each pair of loads before it issues
+      // the next one); channels past Cin re-read the wave's first channel and are multiplied by 0
+      for (int c0 = wave; c0 < a.Cin; c0 += 32) {
+        float xv[8], wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int c = c0 + 4 * u < a.Cin ? c0 + 4 * u : wave;
+          xv[u] = xn[(size_t)c * HWin + sp];
+          wv[u] = wt[((size_t)(c >> 3) * 9 * CC + (c & 7)) * a.OPF];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc64 += (double)(c0 + 4 * u < a.Cin ? xv[u] : 0.f) * (double)wv[u];
+      }
+    }
   }
+  if (wave > 0) part[wave - 1][lane] = acc64;
+  __syncthreads();
+  if (wave != 0 || !act) return;
+  acc64 = ((acc64 + part[0][lane]) + part[1][lane]) + part[2][lane];
+  if (a.bias != nullptr) acc64 += (double)a.bias[o];
   float acc = (float)acc64;
   const size_t idx = ((size_t)n * a.Cout + o) * HW + pix;
   if (a.flags & MG_CONV_LRELU) acc = mg_lrelu(acc, a.slope);
@@ -520,7 +542,7 @@ extern "C" int mg_conv3x3(const float* x, const float* wp, const float* bias, co
 
   if (H * W == 1 && !pn) {
     const size_t total = (size_t)N * H * W * a.OPF;
-    hipLaunchKernelGGL(conv3x3_tiny, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(conv3x3_tiny, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, (hipStream_t)stream, a);
     MG_CHECK_LAUNCH("mg_conv3x3(tiny)");
     return MG_OK;
   }
