@@ -142,6 +142,8 @@ __global__ void __launch_bounds__(256) conv3x3_mfma(const ConvArgs a) {
 
   if constexpr (PF) {
     const int nouter = (a.nchunk + SUB - 1) / SUB;
+    int toff[RIN];  // this thread's entries of the (chunk-invariant) source-offset table, in registers: read from LDS in front of
+                    // every load they put an LDS round trip between consecutive loads
     auto load_chunk = [&](int ch) {
 #pragma unroll
       for (int sub = 0; sub < SUB; ++sub) {
@@ -152,12 +154,8 @@ __global__ void __launch_bounds__(256) conv3x3_mfma(const ConvArgs a) {
         const float* xc = xn + (size_t)c * HWin;
 #pragma unroll
         for (int j = 0; j < RIN; ++j) {
-          const int pos = l32_ + 32 * j;
           float v = 0.f;
-          if (pos < a.plane) {
-            const int off = tab[pos];
-            if (cok && off >= 0) v = xc[off];
-          }
+          if (cok && toff[j] >= 0) v = xc[toff[j]];
           rin[sub * RIN + j] = v;
         }
         const float* src = a.wp + (size_t)chs * (9 * CC) * a.OPF + o0;
@@ -195,6 +193,8 @@ __global__ void __launch_bounds__(256) conv3x3_mfma(const ConvArgs a) {
       }
     };
     __syncthreads();  // tab visible
+#pragma unroll
+    for (int j = 0; j < RIN; ++j) toff[j] = l32_ + 32 * j < a.plane ? tab[l32_ + 32 * j] : -1;
     load_chunk(0);
     for (int ch = 0; ch < nouter; ++ch) {
       __syncthreads();  // previous chunk's LDS reads done
