@@ -11,7 +11,8 @@
 // One workgroup of 8 waves owns a (CT*16) x (OT*16) block of ALL 16 components -- wave w accumulates component pair w, 2*CT*OT
 // accumulator tiles -- over a slab of tiles (split-K over workgroups); both operands are transformed on the way from HBM to LDS
 // (x: coalesced 8-byte row loads + DPP halo exchange + packed adds exactly as in wino3x3.hip; gy: two 8-byte loads), the LDS
-// stages are double-buffered with one barrier per chunk, and a second kernel sums the slabs in a fixed order and applies G^T . G
+// stages are double-buffered with one barrier per chunk, G^T . G is applied per slab (the components of a channel pair meet in LDS
+// once the tile loop is done), and a second kernel sums the 9-tap slabs in a fixed order
 // (bitwise deterministic, no float atomics).  The bias gradient rides along in the gy staging threads.
 #include <cstdlib>
 
@@ -34,7 +35,7 @@ constexpr int STAGE = 2 * IMG;         // V image + Y image
 struct WwArgs {
   const float* x;
   const float* gy;
-  float* slab;    // [nsplit][16 slots][CinP][CoutP]
+  float* slab;    // [nsplit][9 taps][CinP][CoutP]
   float* slab_b;  // [nsplit][CoutP]
   int N, Cin, Cout, H, W;
   int TBW, TBH, TBN, lgTBW, lgTBH;  // chunk geometry in TILES: TBW * TBH * TBN == 8
@@ -231,21 +232,60 @@ __global__ void __launch_bounds__(512) wino_wgrad_mfma(const WwArgs a) {
     __syncthreads();
   }
 
-  // slab[split][slot = 2*wave + p][c][o]
+  // Slab of this split: dW_split = G^T M G per (c, o), 9 planes [split][k][c][o] -- the transform is linear, so it is applied per
+  // split and the reduce kernel only sums (9/16 of the bytes, which is what the small-map layers' weight gradients cost: their
+  // slabs are larger than their inputs).  A (c, o) pair's 16 components sit in 8 different waves: they meet in LDS (the two
+  // stages are free now), 32 in-channels x 64 out-channels x 16 slots = exactly its 128 KB, in two passes over the in-channel
+  // tiles; the out-channel tile index is XOR-ed with the row group so that the four row groups of a wave hit disjoint banks.
+  float* G = smem;  // [slot 16][cc 32][o 64]
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    float* sl = a.slab + ((size_t)split * 16 + 2 * wave + p) * a.CinP * a.CoutP;
+  for (int h = 0; h < 2; ++h) {
+    __syncthreads();  // MFMA loop / previous pass done with the buffer
 #pragma unroll
-    for (int i = 0; i < CT; ++i)
+    for (int p = 0; p < 2; ++p)
 #pragma unroll
-      for (int j = 0; j < OT; ++j) {
-        const int o = o0 + j * 16 + col;
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = 2 * h + ii;
+        if (i < CT) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int c = c0 + i * 16 + rq * 4 + g;
-          if (c < a.CinP && o < a.CoutP) sl[(size_t)c * a.CoutP + o] = acc[p][i][j][g];
+          for (int j = 0; j < OT; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              G[((2 * wave + p) * 32 + ii * 16 + rq * 4 + g) * 64 + ((j ^ rq) * 16 + col)] = acc[p][i][j][g];
         }
       }
+    __syncthreads();
+    constexpr int SL[4] = {0, 2, 3, 1};  // slot of column nu within a row of components
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const int cc = (tid >> 6) + 8 * k4;  // wave-uniform row of the half block
+      const int ol = tid & 63;
+      const int i = 2 * h + (cc >> 4);
+      const int c = c0 + i * 16 + (cc & 15), o = o0 + ol;
+      if (i < CT && ol < OT * 16 && c < a.CinP && o < a.CoutP) {
+        const int osw = ((ol >> 4) ^ ((cc >> 2) & 3)) * 16 + (ol & 15);
+        float M[4][4];
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+          for (int nu = 0; nu < 4; ++nu) M[xi][nu] = G[((4 * xi + SL[nu]) * 32 + cc) * 64 + osw];
+        float hh[3][4];  // G^T M
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+          hh[0][nu] = M[0][nu] + 0.5f * (M[1][nu] + M[2][nu]);
+          hh[1][nu] = 0.5f * (M[1][nu] - M[2][nu]);
+          hh[2][nu] = 0.5f * (M[1][nu] + M[2][nu]) + M[3][nu];
+        }
+        float* sl = a.slab + (size_t)split * 9 * a.CinP * a.CoutP + (size_t)c * a.CoutP + o;
+        const size_t plane = (size_t)a.CinP * a.CoutP;
+#pragma unroll
+        for (int aa = 0; aa < 3; ++aa) {
+          sl[(size_t)(aa * 3 + 0) * plane] = hh[aa][0] + 0.5f * (hh[aa][1] + hh[aa][2]);
+          sl[(size_t)(aa * 3 + 1) * plane] = 0.5f * (hh[aa][1] - hh[aa][2]);
+          sl[(size_t)(aa * 3 + 2) * plane] = 0.5f * (hh[aa][1] + hh[aa][2]) + hh[aa][3];
+        }
+      }
+    }
   }
   // bias gradient: the 8 tile lanes of a channel slot, then one value per (split, out-channel); in-channel block 0 only
   bsum += __shfl_xor(bsum, 1);
@@ -254,57 +294,38 @@ __global__ void __launch_bounds__(512) wino_wgrad_mfma(const WwArgs a) {
   if (cb == 0 && t == 0 && chs < OT * 16 && o0 + chs < a.CoutP) a.slab_b[(size_t)split * a.CoutP + o0 + chs] = bsum;
 }
 
-// Sum the split-K slabs in a fixed order and apply  dW = G^T M G.  Block = 64 consecutive (c, o) pairs x 4 split-lanes x 4
-// component groups (a thread sums every 4th split of 4 components: 1024 threads keep enough loads in flight for what is a pure
-// latency problem), LDS-combined as ((l0 + l1) + (l2 + l3)) => deterministic.  Component slots per row: [nu0, nu3, nu1, nu2].
+// Sum the split-K slabs (already transformed to the 9 taps by the partial kernel) in a fixed order.  Block = 64 consecutive (c, o)
+// pairs x 8 split-lanes (a thread sums every 8th split of the 9 taps: enough loads in flight for what is a pure latency problem),
+// LDS-combined as a fixed tree => deterministic.
 __device__ __forceinline__ void wino_wgrad_reduce_body(const float* __restrict__ slab, const float* __restrict__ slab_b, int nsplit,
                                                        float* __restrict__ gw, float* __restrict__ gb, int Cout, int Cin,
                                                        int CoutP, int CinP, int accumulate, int block) {
-  __shared__ float red[4][16][64];
-  const int el = threadIdx.x & 63, kl = (threadIdx.x >> 6) & 3, cg = threadIdx.x >> 8;
+  __shared__ float red[8][9][64];
+  const int el = threadIdx.x & 63, kl = threadIdx.x >> 6;  // 64 (c, o) pairs x 8 split-lanes
   const int e = block * 64 + el;  // e = c * CoutP + o over the padded block
   const int total = CinP * CoutP;
-  float m[4] = {0.f, 0.f, 0.f, 0.f};
-  if (e < total) {
-    for (int k = kl; k < nsplit; k += 4) {
-      const float* src = slab + ((size_t)k * 16 + cg * 4) * total + e;
+  float m[9];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) m[s] += src[(size_t)s * total];
+  for (int s = 0; s < 9; ++s) m[s] = 0.f;
+  if (e < total) {
+    for (int k = kl; k < nsplit; k += 8) {
+      const float* src = slab + (size_t)k * 9 * total + e;
+#pragma unroll
+      for (int s = 0; s < 9; ++s) m[s] += src[(size_t)s * total];
     }
   }
 #pragma unroll
-  for (int s = 0; s < 4; ++s) red[kl][cg * 4 + s][el] = m[s];
+  for (int s = 0; s < 9; ++s) red[kl][s][el] = m[s];
   __syncthreads();
-  if (cg != 0) return;
   if (kl != 0 || e >= total) return;
   const int c = e / CoutP, o = e % CoutP;
-  float M[4][4];  // [xi][nu]
-#pragma unroll
-  for (int xi = 0; xi < 4; ++xi) {
-    constexpr int SL[4] = {0, 2, 3, 1};
-#pragma unroll
-    for (int nu = 0; nu < 4; ++nu) {
-      const int s = 4 * xi + SL[nu];
-      M[xi][nu] = (red[0][s][el] + red[1][s][el]) + (red[2][s][el] + red[3][s][el]);
-    }
-  }
   if (c < Cin && o < Cout) {
-    float h[3][4];  // G^T M : 3x4
-#pragma unroll
-    for (int nu = 0; nu < 4; ++nu) {
-      h[0][nu] = M[0][nu] + 0.5f * (M[1][nu] + M[2][nu]);
-      h[1][nu] = 0.5f * (M[1][nu] - M[2][nu]);
-      h[2][nu] = 0.5f * (M[1][nu] + M[2][nu]) + M[3][nu];
-    }
     float* dst = gw + ((size_t)o * Cin + c) * 9;
 #pragma unroll
-    for (int aa = 0; aa < 3; ++aa) {
-      const float w0 = h[aa][0] + 0.5f * (h[aa][1] + h[aa][2]);
-      const float w1 = 0.5f * (h[aa][1] - h[aa][2]);
-      const float w2 = 0.5f * (h[aa][1] + h[aa][2]) + h[aa][3];
-      dst[aa * 3 + 0] = accumulate ? dst[aa * 3 + 0] + w0 : w0;
-      dst[aa * 3 + 1] = accumulate ? dst[aa * 3 + 1] + w1 : w1;
-      dst[aa * 3 + 2] = accumulate ? dst[aa * 3 + 2] + w2 : w2;
+    for (int s = 0; s < 9; ++s) {
+      const float w = ((red[0][s][el] + red[1][s][el]) + (red[2][s][el] + red[3][s][el])) +
+                      ((red[4][s][el] + red[5][s][el]) + (red[6][s][el] + red[7][s][el]));
+      dst[s] = accumulate ? dst[s] + w : w;
     }
   }
   if (gb != nullptr && c == 0 && o < Cout) {
@@ -328,7 +349,7 @@ constexpr int WW_JOBS = 40;
 struct WwJobs {
   mg_wgrad_job_t j[WW_JOBS];
 };
-__global__ void __launch_bounds__(1024) wino_wgrad_reduce_multi(const WwJobs jobs) {
+__global__ void __launch_bounds__(512) wino_wgrad_reduce_multi(const WwJobs jobs) {
   const mg_wgrad_job_t j = jobs.j[blockIdx.y];
   if ((int)blockIdx.x * 64 >= j.CinP * j.CoutP) return;
   wino_wgrad_reduce_body(j.slab, j.slab_b, j.nsplit, j.gw, j.gb, j.Cout, j.Cin, j.CoutP, j.CinP, j.accumulate, blockIdx.x);
@@ -366,7 +387,7 @@ void plan_ww(int N, int Cin, int Cout, int H, int W, WwPlan& pl) {
   if (ns > a.nblk) ns = a.nblk;
   a.per = mg_cdiv(a.nblk, ns);
   pl.nsplit = mg_cdiv(a.nblk, a.per);
-  pl.ws_floats = (size_t)pl.nsplit * (16 * (size_t)a.CinP * a.CoutP + a.CoutP);
+  pl.ws_floats = (size_t)pl.nsplit * (9 * (size_t)a.CinP * a.CoutP + a.CoutP);
 }
 
 template <int CT, int OT, bool UPS>
@@ -408,7 +429,7 @@ extern "C" int mg_wino3x3_wgrad_partial(const float* x, const float* gy, float* 
   WwArgs& a = pl.a;
   a.x = x; a.gy = gy;
   a.slab = reinterpret_cast<float*>(ws);
-  a.slab_b = a.slab + (size_t)pl.nsplit * 16 * a.CinP * a.CoutP;
+  a.slab_b = a.slab + (size_t)pl.nsplit * 9 * a.CinP * a.CoutP;
   a.bias_n = (bias_n <= 0 || bias_n > N) ? N : bias_n;
   a.x_bytes = (unsigned)((size_t)N * Cin * (ups ? (H / 2) * (W / 2) : H * W) * 4);
   a.gy_bytes = (unsigned)((size_t)N * Cout * H * W * 4);
@@ -445,7 +466,7 @@ extern "C" int mg_wino3x3_wgrad_reduce(const mg_wgrad_job_t* jobs, int n, mg_str
       const int blocks = mg_cdiv(c.j[i].CinP * c.j[i].CoutP, 64);
       if (blocks > most) most = blocks;
     }
-    hipLaunchKernelGGL(wino_wgrad_reduce_multi, dim3(most, m), dim3(1024), 0, (hipStream_t)stream, c);
+    hipLaunchKernelGGL(wino_wgrad_reduce_multi, dim3(most, m), dim3(512), 0, (hipStream_t)stream, c);
     MG_CHECK_LAUNCH("mg_wino3x3_wgrad_reduce");
   }
   return MG_OK;
