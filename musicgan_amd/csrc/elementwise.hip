@@ -4,6 +4,8 @@
 // 166-184, train.py:64-70.  One thread owns 4 consecutive floats wherever the shape allows (16-byte accesses).
 #include <cstdlib>
 
+#include <cstdint>
+
 #include "mg_common.h"
 
 namespace {
@@ -538,13 +540,38 @@ __global__ void __launch_bounds__(256) adam_dev_k(const AdamDevChunk desc, float
   const float bc1 = 1.f - (beta1 > 0.f ? powf(beta1, t) : 0.f);
   const float bc2s = sqrtf(1.f - powf(beta2, t));
   const float step_size = lr / bc1;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.numel; i += (int64_t)gridDim.x * blockDim.x) {
-    const float g = d.grad[i] * grad_scale;
-    float m = d.exp_avg[i], v = d.exp_avg_sq[i];
+  auto update = [&](float g, float& p, float& m, float& v) {
+    g *= grad_scale;
     m = m + (g - m) * (1.f - beta1);
     v = v * beta2 + (1.f - beta2) * g * g;
     const float denom = sqrtf(v) / bc2s + eps;
-    d.param[i] = d.param[i] - step_size * (m / denom);
+    p = p - step_size * (m / denom);
+  };
+  // 16-byte path when the four arrays allow it (a tensor's slice of a flat gradient bucket may start at any multiple of 4 bytes)
+  const bool vec = ((d.numel & 3) == 0) &&
+                   (((uintptr_t)d.param | (uintptr_t)d.grad | (uintptr_t)d.exp_avg | (uintptr_t)d.exp_avg_sq) & 15) == 0;
+  if (vec) {
+    const int64_t nq = d.numel >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (int64_t)gridDim.x * blockDim.x) {
+      const f32x4 g4 = reinterpret_cast<const f32x4*>(d.grad)[i];
+      f32x4 p4 = reinterpret_cast<f32x4*>(d.param)[i], m4 = reinterpret_cast<f32x4*>(d.exp_avg)[i],
+            v4 = reinterpret_cast<f32x4*>(d.exp_avg_sq)[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float p = p4[e], m = m4[e], v = v4[e];
+        update(g4[e], p, m, v);
+        p4[e] = p; m4[e] = m; v4[e] = v;
+      }
+      reinterpret_cast<f32x4*>(d.param)[i] = p4;
+      reinterpret_cast<f32x4*>(d.exp_avg)[i] = m4;
+      reinterpret_cast<f32x4*>(d.exp_avg_sq)[i] = v4;
+    }
+    return;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.numel; i += (int64_t)gridDim.x * blockDim.x) {
+    float p = d.param[i], m = d.exp_avg[i], v = d.exp_avg_sq[i];
+    update(d.grad[i], p, m, v);
+    d.param[i] = p;
     d.exp_avg[i] = m;
     d.exp_avg_sq[i] = v;
   }
