@@ -557,6 +557,29 @@ def test_pixelnorm_bwd_lds_path_is_bitwise_the_two_pass_kernel(shape, monkeypatc
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("shape", [(3, 37, 5, 7), (32, 128, 4, 4), (1, 160, 2, 2), (64, 112, 8, 8), (16, 96, 32, 32), (2, 33, 16, 16)])
+def test_pixelnorm_bwd_small_maps(shape):
+    """Maps of <= 16 k pixels take the split-channel kernel (4 waves share a pixel's channels): against the fp64 formula, both
+    conventions of `y` (post-LeakyReLU activation / the normalised output itself), ragged pixel and channel counts."""
+    ops = _ops()
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(52)
+    gp = torch.randn(n, c, h, w, generator=g)
+    yv = torch.randn(n, c, h, w, generator=g)
+    for from_p in (False, True):
+        y64 = yv.double()
+        if from_p:  # y is p = act * rn: any positive rn is consistent
+            rn64 = torch.rand(n, 1, h, w, generator=g).double() + 0.5
+            t = y64
+        else:
+            rn64 = 1.0 / torch.sqrt((y64 * y64).mean(dim=1, keepdim=True) + 1e-8)
+            t = y64 * rn64
+        dot = (gp.double() * t).mean(dim=1, keepdim=True)
+        ref = torch.where(y64 > 0, 1.0, 0.2) * rn64 * (gp.double() - t * dot)
+        got = ops.pixelnorm_lrelu_bwd(gp.to(DEV), yv.to(DEV), rn64.float().to(DEV), from_p=from_p)
+        report(f"pixelnorm bwd small from_p={from_p}", got, ref, 2e-6)
+
+
 @pytest.mark.parametrize("case", [(3, 512, 128, torch.float64), (2, 512, 4, torch.float64), (2, 512, 512, torch.float32),
                                   (2, 96, 32, torch.float64), (1, 100, 30, torch.float32), (2, 512, 64, torch.float32)])
 def test_input_transform_matches_the_tensor_expressions(case):
