@@ -150,10 +150,12 @@ int mg_conv3x3_wgrad(const float* x, const float* gy, float* gw, float* gb, void
 #define MG_C1_TANH_BWD_IN 16 /* input is gy*(1-aux_in^2): tanh backward fused on the INPUT side (aux_in: N,Cin,HW) */
 int mg_conv1x1(const float* x, const float* w, const float* bias, const float* aux, float* y, int N, int Cin, int Cout,
                int HW, int flags, float slope, mg_stream_t stream);
-/* gw[Cout][Cin] (+)= sum gy*x, gb (+)= sum gy; if tanh_y != NULL gy is first multiplied by (1 - tanh_y^2). */
+/* gw[Cout][Cin] (+)= sum gy*x, gb (+)= sum gy; if tanh_y != NULL gy is first multiplied by (1 - tanh_y^2).
+ * bias_n (as for the 3x3 weight gradients): only samples n < bias_n feed gb (0: all) -- the penalty's tangent samples of the
+ * fused critic step have no bias gradient. */
 size_t mg_conv1x1_wgrad_ws_bytes(int N, int Cin, int Cout, int HW);
 int mg_conv1x1_wgrad(const float* x, const float* gy, const float* tanh_y, float* gw, float* gb, void* ws,
-                     size_t ws_bytes, int N, int Cin, int Cout, int HW, int accumulate, mg_stream_t stream);
+                     size_t ws_bytes, int N, int Cin, int Cout, int HW, int accumulate, int bias_n, mg_stream_t stream);
 
 /* ------------------------------------------------------------------ element-wise / small ops */
 /* PixelNorm forward [layers.py:11-17]: p = y*rn, rn[n,hw] = 1/sqrt(mean_c y^2 + 1e-8) */

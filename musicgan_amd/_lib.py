@@ -75,7 +75,7 @@ SIGNATURES = {
     "mg_conv3x3_wgrad": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "mg_conv1x1": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "mg_conv1x1_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "mg_conv1x1_wgrad": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, _P]),
+    "mg_conv1x1_wgrad": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "mg_pixelnorm_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     "mg_pixelnorm_lrelu_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P]),
     "mg_upsample2x_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),

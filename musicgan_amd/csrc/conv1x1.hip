@@ -245,6 +245,7 @@ struct W1Args {
   const float* tanh_few;  // optional: few *= (1 - tanh_few^2)
   float* part;            // [gridDim.x][Mtot*(F+1) + F]
   int N, Cm, Cf, HW;
+  int bias_n;  // only samples n < bias_n feed the per-channel sums of gy (the bias gradient)
 };
 
 template <int V>
@@ -279,8 +280,10 @@ __global__ void __launch_bounds__(256) conv1x1_wgrad_part(const W1Args a) {
 #pragma unroll
           for (int v = 0; v < V; ++v) fv[f][v] *= (1.f - th[v] * th[v]);
         }
+        if (n < a.bias_n) {
 #pragma unroll
-        for (int v = 0; v < V; ++v) sf[f] += fv[f][v];
+          for (int v = 0; v < V; ++v) sf[f] += fv[f][v];
+        }
       }
     }
     // the MC loads first (channels past Cm re-read the last one and are discarded), then the arithmetic: with the range test
@@ -296,7 +299,7 @@ __global__ void __launch_bounds__(256) conv1x1_wgrad_part(const W1Args a) {
       if (m0 + m < a.Cm) {
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-          sm[m] += mvs[m][v];
+          sm[m] += n < a.bias_n ? mvs[m][v] : 0.f;
 #pragma unroll
           for (int f = 0; f < FEW; ++f) s[m][f] = fmaf(mvs[m][v], fv[f][v], s[m][f]);
         }
@@ -429,7 +432,7 @@ extern "C" size_t mg_conv1x1_wgrad_ws_bytes(int N, int Cin, int Cout, int HW) {
 }
 
 extern "C" int mg_conv1x1_wgrad(const float* x, const float* gy, const float* tanh_y, float* gw, float* gb, void* ws,
-                                size_t ws_bytes, int N, int Cin, int Cout, int HW, int accumulate,
+                                size_t ws_bytes, int N, int Cin, int Cout, int HW, int accumulate, int bias_n,
                                 mg_stream_t stream) {
   MG_CHECK_ARG(x && gy && gw && ws && N > 0 && Cin > 0 && Cout > 0 && HW > 0, "mg_conv1x1_wgrad: bad arguments");
   MG_CHECK_ARG(Cin <= FEW || Cout <= FEW, "mg_conv1x1_wgrad: needs Cin<=4 or Cout<=4");
@@ -445,6 +448,7 @@ extern "C" int mg_conv1x1_wgrad(const float* x, const float* gy, const float* ta
   a.tanh_few = tanh_y;
   a.part = reinterpret_cast<float*>(ws);
   a.N = N; a.HW = HW;
+  a.bias_n = (bias_n <= 0 || bias_n > N) ? N : bias_n;
   a.Cm = gy_is_many ? Cout : Cin;
   a.Cf = gy_is_many ? Cin : Cout;
   const int nx = w1_nx(N, HW), ny = mg_cdiv(a.Cm, MC);

@@ -526,15 +526,14 @@ def disc_step_fused(W: DiscWeights, x_real: torch.Tensor, x_fake: torch.Tensor, 
         gb2, _ = sink.slot(b2)
         ops.conv3x3_wgrad(q1, gpre2, gw2, gb2, accumulate=acc, bias_n=2 * n, defer=defer)
     lo = slice(0, 2 * n)
+    # x = [real | fake | u_0], gy = [delta_real | delta_fake | h_0]: one launch per stem, bias gradient from the first 2N samples
     gws, acc = sink.slot(W.stem[0])
     gbs, _ = sink.slot(W.stem[1])
-    ops.conv1x1_wgrad(x[lo], hs["stem"][lo], gws, gbs, accumulate=acc)
-    ops.conv1x1_wgrad(x[sl], hs["stem"][sl], gws, None, accumulate=True)
+    ops.conv1x1_wgrad(x, hs["stem"], gws, gbs, accumulate=acc, bias_n=2 * n)
     if W.old_stem is not None:
         gwo, acc = sink.slot(W.old_stem[0])
         gbo, _ = sink.slot(W.old_stem[1])
-        ops.conv1x1_wgrad(xp[lo], hs["old"][lo], gwo, gbo, accumulate=acc)
-        ops.conv1x1_wgrad(xp[sl], hs["old"][sl], gwo, None, accumulate=True)
+        ops.conv1x1_wgrad(xp, hs["old"], gwo, gbo, accumulate=acc, bias_n=2 * n)
     gwc, acc = sink.slot(W.clf[0])
     gbc, _ = sink.slot(W.clf[1])
     ops.linear1_bwd(flat, W.clf[0], g_out, gw=gwc, gb=None, need_gx=False, accumulate=acc)

@@ -379,7 +379,8 @@ def conv1x1(x, w, bias, cout: int, *, lrelu=False, tanh=False, mask_aux=None, tr
     return y
 
 
-def conv1x1_wgrad(x, gy, gw, gb, *, tanh_y=None, accumulate=False):
+def conv1x1_wgrad(x, gy, gw, gb, *, tanh_y=None, accumulate=False, bias_n: int = 0):
+    """gw (+)= sum gy x, gb (+)= sum of gy over the samples n < bias_n (0: all)."""
     _chk(x, gy, gw, gb, tanh_y)
     n, cout, h, wd = gy.shape
     cin = x.shape[1]
@@ -387,7 +388,7 @@ def conv1x1_wgrad(x, gy, gw, gb, *, tanh_y=None, accumulate=False):
     nbytes = lib.mg_conv1x1_wgrad_ws_bytes(n, cin, cout, h * wd)
     ws = workspace(nbytes, x.device)
     check(lib.mg_conv1x1_wgrad(_p(x), _p(gy), _p(tanh_y), _p(gw), _p(gb), _p(ws), ws.numel(), n, cin, cout, h * wd,
-                               int(accumulate), _s()), "mg_conv1x1_wgrad")
+                               int(accumulate), int(bias_n), _s()), "mg_conv1x1_wgrad")
 
 
 # ------------------------------------------------------------------ element-wise

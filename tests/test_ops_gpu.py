@@ -402,6 +402,25 @@ def test_wino3x3_fwd_dgrad_mask_pool(shape, cfg, monkeypatch):
         assert torch.equal(ops.avgpool2_bwd(gx, m2), gun)
 
 
+@pytest.mark.parametrize("case", [(6, 2, 48, 16, 16), (9, 2, 64, 5, 7), (6, 96, 2, 8, 8)])
+def test_conv1x1_wgrad_bias_n(case):
+    """`bias_n`: the weight gradient sums all samples, the bias gradient only the first bias_n (the fused critic step hands the
+    stem [real | fake | tangent] in one launch; the tangent third has no bias gradient) -- against fp64 sums."""
+    ops = _ops()
+    n, ci, co, h, w = case
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(n, ci, h, w, generator=g)
+    gy = torch.randn(n, co, h, w, generator=g)
+    bn = 2 * n // 3
+    gw = torch.full((co, ci, 1, 1), float("nan"), device=DEV)
+    gb = torch.full((co,), float("nan"), device=DEV)
+    ops.conv1x1_wgrad(x.to(DEV), gy.to(DEV), gw, gb, bias_n=bn)
+    ref_w = torch.einsum("nohw,nchw->oc", gy.double(), x.double())
+    ref_b = gy[:bn].double().sum(dim=(0, 2, 3))
+    report("conv1x1 wgrad (bias_n)", gw.reshape(co, ci), ref_w, 3e-6)
+    report("conv1x1 bias grad (bias_n)", gb, ref_b, 3e-6)
+
+
 def _tile_mask(act: torch.Tensor) -> torch.Tensor:
     n, c, h, w = act.shape
     b = (act > 0).reshape(n, c, h // 2, 2, w // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, c, h // 2, w // 2, 4).to(torch.uint8)
