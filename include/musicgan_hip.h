@@ -196,9 +196,9 @@ int mg_blend_lrelu_bwd_dev(const float* g, const float* act_a, const float* act_
                            size_t n, float slope, mg_stream_t stream);
 /* Linear(K -> 1) [discriminator.py:103-105]: y[n] = b + sum_k w[k] x[n,k] */
 int mg_linear1_fwd(const float* x, const float* w, const float* b, float* y, int N, int K, mg_stream_t stream);
-/* gx[n,k] = gy[n]*w[k]; gw[k] (+)= sum_n gy[n] x[n,k]; gb (+)= sum_n gy[n]   (gx/gw/gb may be NULL) */
+/* gx[n,k] = gy[n]*w[k]; gw[k] (+)= sum_n gy[n] x[n,k]; gb (+)= sum_{n < bias_n} gy[n] (0: all n)   (gx/gw/gb may be NULL) */
 int mg_linear1_bwd(const float* x, const float* w, const float* gy, float* gx, float* gw, float* gb, int N, int K,
-                   int accumulate, mg_stream_t stream);
+                   int accumulate, int bias_n, mg_stream_t stream);
 /* gradient-penalty helpers [discriminator.py:166-184] */
 int mg_gp_interp(const float* x_real, const float* x_fake, const float* eps, float* out, int N, size_t chw,
                  mg_stream_t stream); /* out = eps[n]*real + (1-eps[n])*fake */

@@ -91,7 +91,7 @@ SIGNATURES = {
     "mg_blend_up_dev": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "mg_blend_lrelu_bwd_dev": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, c_float, _P]),
     "mg_linear1_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
-    "mg_linear1_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "mg_linear1_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "mg_gp_interp": (c_int, [_P, _P, _P, _P, c_int, c_size_t, _P]),
     "mg_sumsq_per_sample": (c_int, [_P, _P, c_int, c_size_t, _P]),
     "mg_scale_per_sample": (c_int, [_P, _P, _P, c_int, c_size_t, _P]),

@@ -511,7 +511,7 @@ __global__ void __launch_bounds__(64) linear1_fwd_k(const float* __restrict__ x,
 __global__ void __launch_bounds__(256) linear1_bwd_k(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ gy, float* __restrict__ gx,
                                                      float* __restrict__ gw, float* __restrict__ gb, int N, int K,
-                                                     int accumulate) {
+                                                     int accumulate, int bias_n) {
   // The classifier weight gradient is a cancellation: -mean(real features) + mean(fake features) + penalty term leaves
   // ~1e-6 from ~0.05-sized summands.  Summing the few hundred terms in fp64 costs nothing (K = 160 threads x N <= 600 fmas) and
   // removes the order-dependent fp32 round-off of the intermediate sums (each product is exact in fp64).
@@ -535,7 +535,7 @@ __global__ void __launch_bounds__(256) linear1_bwd_k(const float* __restrict__ x
   }
   if (gb && blockIdx.x == 0 && threadIdx.x < 64) {
     double s = 0.0;
-    for (int n = lane; n < N; n += 64) s += (double)gy[n];
+    for (int n = lane; n < bias_n; n += 64) s += (double)gy[n];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
     if (lane == 0) gb[0] = accumulate ? (float)((double)gb[0] + s) : (float)s;
@@ -801,9 +801,9 @@ extern "C" int mg_linear1_fwd(const float* x, const float* w, const float* b, fl
 }
 
 extern "C" int mg_linear1_bwd(const float* x, const float* w, const float* gy, float* gx, float* gw, float* gb, int N,
-                              int K, int accumulate, mg_stream_t stream) {
+                              int K, int accumulate, int bias_n, mg_stream_t stream) {
   MG_CHECK_ARG(w && gy && N > 0 && K > 0 && (!gw || x), "mg_linear1_bwd: bad arguments");
-  EW_LAUNCH(linear1_bwd_k, (K + 3) / 4, 256, x, w, gy, gx, gw, gb, N, K, accumulate);
+  EW_LAUNCH(linear1_bwd_k, (K + 3) / 4, 256, x, w, gy, gx, gw, gb, N, K, accumulate, (bias_n <= 0 || bias_n > N) ? N : bias_n);
   MG_CHECK_LAUNCH("mg_linear1_bwd");
   return MG_OK;
 }

@@ -525,7 +525,6 @@ def disc_step_fused(W: DiscWeights, x_real: torch.Tensor, x_fake: torch.Tensor, 
         gw2, acc = sink.slot(w2)
         gb2, _ = sink.slot(b2)
         ops.conv3x3_wgrad(q1, gpre2, gw2, gb2, accumulate=acc, bias_n=2 * n, defer=defer)
-    lo = slice(0, 2 * n)
     # x = [real | fake | u_0], gy = [delta_real | delta_fake | h_0]: one launch per stem, bias gradient from the first 2N samples
     gws, acc = sink.slot(W.stem[0])
     gbs, _ = sink.slot(W.stem[1])
@@ -536,8 +535,7 @@ def disc_step_fused(W: DiscWeights, x_real: torch.Tensor, x_fake: torch.Tensor, 
         ops.conv1x1_wgrad(xp, hs["old"], gwo, gbo, accumulate=acc, bias_n=2 * n)
     gwc, acc = sink.slot(W.clf[0])
     gbc, _ = sink.slot(W.clf[1])
-    ops.linear1_bwd(flat, W.clf[0], g_out, gw=gwc, gb=None, need_gx=False, accumulate=acc)
-    ops.linear1_bwd(flat[lo], W.clf[0], g_out[lo], gw=None, gb=gbc, need_gx=False, accumulate=acc)
+    ops.linear1_bwd(flat, W.clf[0], g_out, gw=gwc, gb=gbc, need_gx=False, accumulate=acc, bias_n=2 * n)
     if defer is not None:
         defer.flush()  # the slab reductions of every Winograd weight gradient of the sweep, one launch
     stats = ops.group_means(out, 3)  # [mean D(real), mean D(fake), mean D(x~), -(mean D(real) - mean D(fake))]

@@ -507,12 +507,13 @@ def linear1_fwd(x, w, b):
     return y
 
 
-def linear1_bwd(x, w, gy, *, gw=None, gb=None, need_gx=True, accumulate=False):
+def linear1_bwd(x, w, gy, *, gw=None, gb=None, need_gx=True, accumulate=False, bias_n: int = 0):
+    """bias_n: the bias gradient sums the first bias_n samples only (0: all)."""
     _chk(x, w, gy, gw, gb)
     n = gy.shape[0]
     k = w.numel()
     gx = torch.empty((n, k), dtype=torch.float32, device=gy.device) if need_gx else None
-    check(_lib.load().mg_linear1_bwd(_p(x), _p(w), _p(gy), _p(gx), _p(gw), _p(gb), n, k, int(accumulate), _s()),
+    check(_lib.load().mg_linear1_bwd(_p(x), _p(w), _p(gy), _p(gx), _p(gw), _p(gb), n, k, int(accumulate), int(bias_n), _s()),
           "mg_linear1_bwd")
     return gx
 
