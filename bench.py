@@ -313,13 +313,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    # Rehearsal of the N > 1 code on a one-GPU box (tests/test_dp_gpu.py): MG_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
+    # takes gloo, because RCCL refuses two ranks on one device.  The driver's launches never set it.
+    share_gpu = os.environ.get("MG_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also with a single rank)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if share_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from musicgan_amd.optim import FusedAdam

@@ -118,3 +118,25 @@ def test_two_ranks_sharing_the_gpu_equal_one_process_on_the_concatenated_batch(t
             scale = float(a[k].abs().max()) + 1e-12
             err = float((a[k] - b[k]).abs().max())
             assert err <= 2e-4 * scale + 1e-7, f"update {step} {k}: {err:.2e} vs max {scale:.2e}"
+
+
+def test_bench_with_two_ranks_sharing_the_gpu(tmp_path):
+    """The driver's N = 2 command (`torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`) rehearsed on this box's one
+    GPU (MG_BENCH_SHARE_GPU=1: both ranks on cuda:0 over gloo): barriers, the max-over-ranks timing, the data-parallel stepper
+    with graph replay under two real ranks, rank 0 printing ONE line whose value is the whole-job rate."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MG_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1", MG_FORCE_DP="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29700 + os.getpid() % 90), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4",
+           "--warmup", "4", "--level", "3", "--batch", "8", "--no-cpu-baseline", "--no-extra"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["global_batch"] == 16
+    assert abs(d["value"] - 2 * 8 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]  # whole-job images/s over the slowest rank's time
