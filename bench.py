@@ -219,9 +219,10 @@ def stft_record(device, cpu: bool):
         e1.synchronize()
         return e0.elapsed_time(e1) / iters
 
-    # steady state as for the training step (>= 10 warm-up, >= 50 timed): the chip's clock needs a few ms of load to
-    # settle after the host-side work before this record (the first launches of a burst run 10-15 % slower)
-    ms_stft = timeit(lambda: ops.stft_1024(wav), 100, warm=30)
+    # steady state as for the training step (>= 10 warm-up, >= 50 timed).  This HBM-bound kernel needs ~25 ms of load
+    # (~200 launches) after host-side work before the chip's memory-side clocks have ramped: batches of 50 launches after 2 s of
+    # idle measure 0.44, 0.48, 0.52, 0.53, 0.54, 0.55, 0.55 ... of the HBM roofline (tools/bench_stft_ramp.py)
+    ms_stft = timeit(lambda: ops.stft_1024(wav), 200, warm=250)
     ms_both = timeit(lambda: audio.stft_to_phase_magn(ops.stft_1024(wav)), 10)
     mp = torch.stack(audio.stft_to_phase_magn(ops.stft_1024(wav)), dim=1)[:8].contiguous()  # 8 samples = 4 096 frames
     fps = T / (ms_stft * 1e-3)

@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(64 * NWAVE, 2) stft1024_kernel(const float* __
       const int t = t0 + 2 * fp;
       if (out_im == nullptr && (T & 1) == 0) {  // interleaved complex output, rows 16-byte aligned
         if (t < T) {  // T even: t + 1 < T too
-#pragma unroll 4
+#pragma unroll 8
           for (int k = tid / (FPB / 2); k < NB; k += 64 * NWAVE / (FPB / 2)) {
             const c2 o0 = xbuf[(2 * fp) * XSTR + k], o1 = xbuf[(2 * fp + 1) * XSTR + k];
             __builtin_nontemporal_store(f32x4{o0.x, o0.y, o1.x, o1.y}, reinterpret_cast<f32x4*>(out_re + 2 * ((size_t)k * T + t)));
