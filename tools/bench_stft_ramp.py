@@ -7,9 +7,9 @@ L = 44100 * 600
 wav = torch.rand(L, device=dev) - 0.5
 T = 1 + L // 256
 ops.stft_1024(wav); torch.cuda.synchronize()
-time.sleep(2.0)  # idle, as after host-side work
+time.sleep(float(sys.argv[1]) if len(sys.argv) > 1 else 2.0)  # idle, as after host-side work
 res = []
-for b in range(14):
+for b in range(int(sys.argv[2]) if len(sys.argv) > 2 else 14):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(50): ops.stft_1024(wav)
