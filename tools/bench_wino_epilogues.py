@@ -12,7 +12,7 @@ R = lambda *s: torch.randn(*s, device=dev, generator=g)
 
 
 def timeit(fn, iters=20):
-    for _ in range(3): fn()
+    for _ in range(30): fn()  # past the clock ramp that follows an idle chip
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters): fn()
