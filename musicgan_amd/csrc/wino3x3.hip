@@ -737,6 +737,11 @@ int wino_run(WinoArgs& a, bool pn, hipStream_t s) {
     const char* e = getenv("MG_WINO_WT");  // measurement override
     if (e != nullptr && (atoi(e) == 2 || atoi(e) == 4)) wt = atoi(e);
   }
+  // a grid that leaves CUs idle even in the 32-tile form takes two out-channel tiles per workgroup instead of three or four: more,
+  // lighter workgroups (the input tile is staged by more of them, which a half-empty chip does not notice)
+  if (wt == 2 && !pn && cfg > 2 && getenv("MG_WINO_CFG") == nullptr &&
+      ((long long)N * Ht * Wt + 31) / 32 * mg_cdiv(nt, cfg) < n_cu && mg_cdiv(nt, 2) * 2 <= a.NT)
+    cfg = 2;
   const int tpb = wt * 16;
   a.TBW = mg_pow2_ceil(Wt) < 16 ? mg_pow2_ceil(Wt) : 16;  // 16 tiles = 32 pixels = one 128-byte line per row and channel
   a.TBH = mg_pow2_ceil(Ht) < tpb / a.TBW ? mg_pow2_ceil(Ht) : tpb / a.TBW;
