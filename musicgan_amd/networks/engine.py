@@ -82,6 +82,12 @@ class PackCache:
         n, cin, h, wd = x.shape
         ho, wo = (2 * h, 2 * wd) if ups else (h, wd)
         if n * ho * wo >= int(os.environ.get("MG_PN_FUSE_MIN_PIXELS", "16384")):
+            # an under-filled sub-pixel launch (one 4-wave workgroup per 64 low-res pixels, all channels in a wave): the up-sampled
+            # tensor written out once + the Winograd conv sliced over out-channels + PixelNorm as its own pass fill the chip
+            if ups and n * h * wd < int(os.environ.get("MG_UPCONV_MIN_LOWRES_PIXELS", "32768")) and \
+                    ops.wino3x3_supported(n, cout, ho, wo, cin=cin):
+                y = self.conv(ops.upsample2x_fwd(x), w, False, bias, cout, lrelu=True)
+                return ops.pixelnorm_fwd(y)
             if ups and ops.upconv3x3_supported(cout, wd, x.numel()):  # sub-pixel form: 2.25x fewer MFMAs
                 _, p, rn = ops.upconv3x3(x, self.get_up(w), bias, cout, lrelu=True, pixnorm=True, want_y=False)
             else:
