@@ -224,7 +224,17 @@ def stft_record(device, cpu: bool):
     # steady state as for the training step (>= 10 warm-up, >= 50 timed).  This HBM-bound kernel needs ~25 ms of load
     # (~200 launches) after host-side work before the chip's memory-side clocks have ramped: batches of 50 launches after 2 s of
     # idle measure 0.44, 0.48, 0.52, 0.53, 0.54, 0.55, 0.55 ... of the HBM roofline (tools/bench_stft_ramp.py)
-    ms_stft = timeit(lambda: ops.stft_1024(wav), 200, warm=250)
+    # The ramp is not always the same length (what ran before matters: 250 launches were enough after the level-4 record on
+    # most boxes and left the record at 0.156 ms instead of 0.118 on one), so the warm-up is adaptive: batches of 50 launches until
+    # two successive batches agree within 1.5 % (at least 5, at most 40 batches), then 200 timed launches.
+    prev, settled = None, 0
+    for b in range(40):
+        cur = timeit(lambda: ops.stft_1024(wav), 50, warm=0)
+        settled = settled + 1 if (prev is not None and abs(cur - prev) <= 0.015 * prev) else 0
+        prev = cur
+        if b >= 4 and settled >= 2:
+            break
+    ms_stft = timeit(lambda: ops.stft_1024(wav), 200, warm=0)
     ms_both = timeit(lambda: audio.stft_to_phase_magn(ops.stft_1024(wav)), 10)
     mp = torch.stack(audio.stft_to_phase_magn(ops.stft_1024(wav)), dim=1)[:8].contiguous()  # 8 samples = 4 096 frames
     fps = T / (ms_stft * 1e-3)
