@@ -88,6 +88,12 @@ class PackCache:
                     ops.wino3x3_supported(n, cout, ho, wo, cin=cin):
                 y = self.conv(ops.upsample2x_fwd(x), w, False, bias, cout, lrelu=True)
                 return ops.pixelnorm_fwd(y)
+            # more than 64 channels cannot take the Winograd kernel's fused PixelNorm (all channels of a pixel in one workgroup)
+            # and the direct kernel's fused form puts 5-8 channel tiles on one wave: the Winograd conv + a PixelNorm pass is faster
+            if not ups and cout > 64 and os.environ.get("MG_PN_WIDE_UNFUSED", "1") == "1" and \
+                    ops.wino3x3_supported(n, cout, h, wd, cin=cin):
+                y = self.conv(x, w, False, bias, cout, lrelu=True)
+                return ops.pixelnorm_fwd(y)
             if ups and ops.upconv3x3_supported(cout, wd, x.numel()):  # sub-pixel form: 2.25x fewer MFMAs
                 _, p, rn = ops.upconv3x3(x, self.get_up(w), bias, cout, lrelu=True, pixnorm=True, want_y=False)
             else:
