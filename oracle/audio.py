@@ -1,7 +1,8 @@
 """CPU oracle for the STFT / magnitude-phase codec path.  TEST INFRASTRUCTURE ONLY (see oracle/progan.py header).
 
 numpy restatement of /root/reference/music_gan/audio/functions.py:
-  :13-23   diff / unwrap  (== np.unwrap along time incl. the -pi -> +pi correction)
+  :13-23   diff / unwrap  (== np.unwrap along time incl. the -pi -> +pi correction; the cumulative sum of the 2 pi
+           adjustments accumulates in float64 and is rounded to float32 per frame, as torch.cumsum does on the CPU)
   :26-35   bark_magn_scale: s = 6*asinh(linspace(20, 22050, F)/600), normalised to unit L2 norm
   :38-62   wav_to_stft: mono mean, periodic Hann(1024), torchaudio.functional.spectrogram(power=None, normalized=True)
            (== centre/reflect-padded framed rFFT divided by sqrt(sum w^2)), Nyquist row dropped
@@ -13,7 +14,9 @@ numpy restatement of /root/reference/music_gan/audio/functions.py:
 Third-party boundary: torchaudio (requirements.txt:5, unpinned, absent here).  Its two functional wrappers are restated
 from their documented behaviour; the pin is torch.stft/torch.istft in the build container (tools/ref_loader.py stand-in)
 plus the explicit DFT identity below -- "parity pinned on torch.stft, not on torchaudio" (DESIGN.md).
-Golden vectors: tests/golden/audio_codec.npz (tools/gen_golden.py: audio_case).
+  :117-118 the inverse's cumulative phase is a Python loop of float32 adds: sequential float32, NOT torch.cumsum.
+Golden vectors: tests/golden/audio_codec.npz (tools/gen_golden.py: audio_case) and, at BASELINE config 5's size (10-minute
+track, 103 360 frames), tests/golden/audio_config5.npz (audio_config5_case).
 """
 from __future__ import annotations
 
@@ -59,12 +62,28 @@ def unwrap(phi: np.ndarray) -> np.ndarray:
     dphi_m[(dphi_m == -pi) & (dphi > 0)] = pi
     adj = dphi_m - dphi
     adj[np.abs(dphi) < pi] = 0
-    return phi + np.cumsum(adj, axis=1, dtype=np.float32)
+    # functions.py:23 `phi_adj.cumsum(1)`: torch.cumsum on a CPU float32 tensor keeps its running sum in DOUBLE
+    # (at::acc_type<float, false>) and rounds every output to float32 -- not a float32 running sum.  The two differ by
+    # 5e-3 of the output range on a 10-minute track (unwrapped phase ~1e5 rad, ulp 2^-7), see DESIGN.md section 2.
+    return phi + np.cumsum(adj.astype(np.float64), axis=1).astype(np.float32)
 
 
-def stft_to_phase_magn(c: np.ndarray, nb_vec: int = N_VEC):
-    magn = np.abs(c).astype(np.float32)
-    phase = np.angle(c).astype(np.float32)
+def _abs_angle(c: np.ndarray, lib: str):
+    """functions.py:69-70 `th.abs` / `th.angle`: the two library calls of the codec.  lib="numpy" evaluates them with numpy's
+    float32 hypot / atan2; lib="torch" with the very library the reference calls (torch on the CPU -- third-party, not reference
+    code): numpy's and torch's atan2f differ by 1 ulp on ~40 % of the bins, and the exact running sum in `unwrap` turns that into
+    a one-ulp(1e5 rad) change of ~0.1 % of a 10-minute track's phase image, so the oracle is bit-identical to the reference at
+    that length only with lib="torch" (tests/test_oracle_golden.py::test_audio_oracle_config5_*)."""
+    if lib == "torch":
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(c, dtype=np.complex64))
+        return torch.abs(t).numpy(), torch.angle(t).numpy()
+    assert lib == "numpy", lib
+    return np.abs(c).astype(np.float32), np.angle(c).astype(np.float32)
+
+
+def stft_to_phase_magn(c: np.ndarray, nb_vec: int = N_VEC, lib: str = "numpy"):
+    magn, phase = _abs_angle(c, lib)
     magn = magn * bark_scale_vector(c.shape[0])[:, None]
     phase = unwrap(phase)
     phase = phase[:, 1:] - phase[:, :-1]

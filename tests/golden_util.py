@@ -91,3 +91,68 @@ def grad_atol(k, ref64, ref32, terms64=None):
     if terms64 is not None:
         tol = max(tol, 1e-6 * float(terms64[k].abs().max()))
     return tol
+
+
+# ---------------------------------------------------------------- BASELINE config 5 (10-minute track, 103 360 frames)
+# Inputs are regenerated from numpy's PCG64 stream (the same bits on every machine) and checked by SHA-256 against the fixture;
+# tools/gen_golden.py imports these very functions to feed the reference.
+C5_NSAMP = 65521
+C5_FRAMES = 103360
+
+
+def c5_sample_idx(numel: int) -> np.ndarray:
+    """Fixed strided subsample for the config-5-size tensors: C5_NSAMP indices with an ODD stride (visits every column)."""
+    stride = numel // C5_NSAMP
+    stride -= 1 - (stride & 1)
+    return np.arange(C5_NSAMP, dtype=np.int64) * max(stride, 1)
+
+
+def c5_waveform() -> np.ndarray:
+    """mono U(-0.5, 0.5) track of 44 100 * 600 samples, seed 7."""
+    return np.random.default_rng(7).random(44100 * 600, dtype=np.float32) - np.float32(0.5)
+
+
+def c5_spectrum(frames: int = C5_FRAMES) -> np.ndarray:
+    """complex64 (512, frames) input for stft_to_phase_magn whose bits do not depend on any FFT or math library, shaped like the
+    STFT of a stationary signal: bin k holds a fixed phasor A_k plus noise of about its size, advanced by k quarter turns per
+    frame (the phase advance of bin k's centre frequency at hop = n_fft / 4).  Quarter turns are exact (swap / negate) and every
+    other step is one IEEE float32 add of PCG64 uniforms (seed 705), so every machine builds the same bits -- and the unwrapped
+    phase of the odd bins runs to +-1.6e5 rad like a real 10-minute track's (ulp 2^-7), which is what this fixture is for."""
+    rng = np.random.default_rng(705)
+    a = (rng.random((512, 1, 2), dtype=np.float32) - np.float32(0.5))
+    n = (rng.random((512, frames, 2), dtype=np.float32) - np.float32(0.5))
+    v = a + n
+    re, im = v[..., 0], v[..., 1]
+    q = (np.arange(512, dtype=np.int64)[:, None] * np.arange(frames, dtype=np.int64)[None, :]) & 3
+    out_re = np.select([q == 0, q == 1, q == 2], [re, -im, -re], im)
+    out_im = np.select([q == 0, q == 1, q == 2], [im, re, -im], -re)
+    out = np.empty((512, frames), dtype=np.complex64)
+    out.real, out.imag = out_re, out_im
+    return out
+
+
+def c5_inverse_input(chunks: int = 40) -> np.ndarray:
+    """(chunks, 2, 512, 512) float32 in [-1, 1), seed 706: 20 480 frames for magn_phase_to_wav."""
+    return (np.random.default_rng(706).random((chunks, 2, 512, 512), dtype=np.float32) * np.float32(2.0)
+            - np.float32(1.0))
+
+
+def c5_phase_stats(g, case, phase):
+    """Deviation of a (201, 512, 512) phase output from the reference's on the fixture's subsample + full rows.
+
+    The codec's phase image is a discontinuous function of its input in two places, so a max-norm bound is meaningless at this
+    length and the comparison is distributional:
+      * `unwrapped = phi + cumsum` is rounded to float32 at magnitudes up to `unwrapped_maxabs` (1.1e5 rad: ulp 2^-7), so a
+        1-ulp difference in atan2 (different libm) moves an output by 0 or by one such ulp;
+      * a frame-to-frame difference within an ulp of +-pi wraps to the other sign: the output flips between -1 and +1.
+    Returns (fraction within `tight`, max deviation outside flips in units of the ulp bound, number of flips, n)."""
+    flat = np.asarray(phase, dtype=np.float32).reshape(-1)
+    got = np.concatenate([flat[c5_sample_idx(flat.size)],
+                          np.asarray(phase)[[0, 0, 0, -1, -1, -1], [0, 255, 511, 0, 255, 511], :].reshape(-1)])
+    ref = np.concatenate([g[f"{case}|phase|samp"], g[f"{case}|phase|rows"].reshape(-1)])
+    d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+    rng_ = float(g[f"{case}|delta_max"]) - float(g[f"{case}|delta_min"])
+    ulp = float(np.spacing(np.float32(g[f"{case}|unwrapped_maxabs"])))
+    bound = 2.0 * ulp / rng_ * 2.0  # two ulps of the unwrapped phase, mapped to the [-1, 1] output range
+    flips = d > 1.9
+    return float(np.mean(d <= 1e-6)), float(d[~flips].max() / bound), int(flips.sum()), d.size

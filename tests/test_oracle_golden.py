@@ -229,6 +229,73 @@ def test_audio_oracle_inverse_matches_reference():
     assert np.max(np.abs(wav - ref)) <= 2e-3 * np.max(np.abs(ref))
 
 
+def _c5(case):
+    import hashlib
+    from golden_util import c5_inverse_input, c5_spectrum, c5_waveform
+    g = load("audio_config5.npz")
+    x = {"wav": c5_waveform, "spec": c5_spectrum, "inv": c5_inverse_input}[case]()
+    key = "wav|sha256" if case == "wav" else f"{case}|sha256"
+    assert hashlib.sha256(np.ascontiguousarray(x).view(np.float32).tobytes()).hexdigest() == str(g[key]), \
+        "the regenerated config-5 input is not the one the reference was given"
+    return g, x
+
+
+def _c5_check_magn(g, case, magn, tol):
+    from golden_util import c5_sample_idx
+    got = magn.reshape(-1)[c5_sample_idx(magn.size)]
+    assert float(np.abs(got - g[f"{case}|magn|samp"]).max()) <= tol
+    assert float(np.abs(magn[[0, 0, 0, -1, -1, -1], [0, 255, 511, 0, 255, 511], :] - g[f"{case}|magn|rows"]).max()) <= tol
+    assert abs(float(magn.astype(np.float64).sum()) - float(g[f"{case}|magn|sum"])) <= tol * magn.size * 0.05
+
+
+def test_audio_oracle_config5_codec_is_the_references_bit_for_bit():
+    """BASELINE config 5's size (10-minute track, 103 360 frames -> 201 images; create_dataset.py:34-64, functions.py:65-94) on
+    the library-independent STFT-like input: with torch's own abs / angle the oracle IS the reference, every sampled element and
+    both full-row sets, deviation exactly 0 -- this pins `unwrap`'s float64 running sum (functions.py:23, torch.cumsum).  With a
+    float32 running sum (the round-1/2 oracle) 0.05 % of the elements are within 1e-6 (tools/diag_unwrap_lengths.py)."""
+    from golden_util import c5_phase_stats
+    g, x = _c5("spec")
+    magn, phase = OA.stft_to_phase_magn(x, lib="torch")
+    assert magn.shape == phase.shape == (201, 512, 512)
+    frac, worst, flips, n = c5_phase_stats(g, "spec", phase)
+    assert (frac, worst, flips) == (1.0, 0.0, 0), (frac, worst, flips, n)
+    assert abs(float(phase.astype(np.float64).sum()) - float(g["spec|phase|sum"])) <= 1e-9 * phase.size
+    _c5_check_magn(g, "spec", magn, 1e-6)  # (the bark vector is numpy's asinh / norm: 1 ulp from torch's)
+    # the same with numpy's atan2f / hypotf: 1-ulp library differences, amplified by the exact sum, stay inside the bound
+    magn, phase = OA.stft_to_phase_magn(x)
+    frac, worst, flips, n = c5_phase_stats(g, "spec", phase)
+    assert frac >= 0.90 and worst <= 1.0 and flips <= 3, (frac, worst, flips, n)
+    _c5_check_magn(g, "spec", magn, 2e-6)
+
+
+def test_audio_oracle_config5_waveform_to_codec():
+    """The seed-7 U(-0.5, 0.5) 44 100 x 600-sample track of SURVEY 8(d) through the oracle's STFT (float64 FFT) and codec against
+    the reference's wav_to_stft + stft_to_phase_magn: the bins agree to 1e-6 of max|X|, which moves the phase of weak bins by more
+    than an ulp, so the bound on the phase image is distributional (golden_util.c5_phase_stats)."""
+    from golden_util import c5_phase_stats, c5_sample_idx
+    g, wav = _c5("wav")
+    c = OA.stft(wav)
+    assert c.shape == (512, 103360)
+    cs = np.ascontiguousarray(c).view(np.float32).reshape(-1)[c5_sample_idx(2 * c.size)]
+    assert float(np.abs(cs - g["wav|stft_samp"]).max()) <= 1e-6 * float(g["wav|stft_maxabs"])
+    magn, phase = OA.stft_to_phase_magn(c, lib="torch")
+    frac, worst, flips, n = c5_phase_stats(g, "wav", phase)
+    assert frac >= 0.85 and worst <= 1.0 and flips <= 3, (frac, worst, flips, n)
+    _c5_check_magn(g, "wav", magn, 2e-6)
+
+
+def test_audio_oracle_config5_inverse():
+    """magn_phase_to_wav over 20 480 frames (functions.py:97-139; its cumulative phase is a sequential float32 loop, :117-118)."""
+    from golden_util import c5_sample_idx
+    g, mp = _c5("inv")
+    wav = OA.magn_phase_to_wav(mp)
+    assert wav.shape == (256 * (20480 - 1),)
+    scale = float(g["inv|wav|maxabs"])
+    assert float(np.abs(wav[c5_sample_idx(wav.size)] - g["inv|wav|samp"]).max()) <= 2e-3 * scale
+    assert float(np.abs(wav[:4096] - g["inv|wav|head"]).max()) <= 2e-3 * scale
+    assert float(np.abs(wav[-4096:] - g["inv|wav|tail"]).max()) <= 2e-3 * scale
+
+
 def test_stft_known_shape_30s():
     # notebook cell 7: 30 s mono at 44.1 kHz -> [513, 5168] before the Nyquist drop
     assert OA.stft(np.zeros(44100 * 30, dtype=np.float32)).shape == (512, 5168)

@@ -16,6 +16,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from ref_loader import load_audio, load_networks, load_utils, wav_store  # noqa: E402
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from golden_util import c5_inverse_input, c5_sample_idx, c5_spectrum, c5_waveform  # noqa: E402  (the inputs the GPU box regenerates)
+
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 FULL_MAX = 4096
 NSAMP = 509
@@ -423,6 +426,69 @@ def audio_case():
     assert tuple(audio.wav_to_stft("k.wav").shape) == (512, 5168)
 
 
+def c5_put(store, name, t: torch.Tensor):
+    """Strided subsample + sum + l2 + maxabs, plus full rows (bins 0, 255, 511) of the first and the last image."""
+    flat = t.detach().contiguous().reshape(-1)
+    store[name + "|samp"] = flat.numpy()[c5_sample_idx(flat.numel())]
+    store[name + "|sum"] = np.float64(flat.double().sum().item())
+    store[name + "|l2"] = np.float64(flat.double().norm().item())
+    store[name + "|maxabs"] = np.float64(flat.abs().max().item())
+    if t.dim() == 3:
+        store[name + "|rows"] = t[[0, 0, 0, -1, -1, -1], [0, 255, 511, 0, 255, 511], :].numpy()
+
+
+def audio_config5_case():
+    """BASELINE config 5 at its stated size (create_dataset.py:34-64 -> functions.py:38-94): the reference's own wav_to_stft +
+    stft_to_phase_magn on a 10-minute track (103 360 frames -> 201 images), its stft_to_phase_magn on a library-independent
+    complex input of the same size, and its magn_phase_to_wav (functions.py:97-139) over 20 480 frames."""
+    audio = load_audio()
+    fn = sys.modules["music_gan.audio.functions"]
+    sr = 44100
+    store = {}
+    # (1) waveform -> STFT -> codec
+    wav = c5_waveform()
+    store["wav|sha256"] = hashlib.sha256(wav.tobytes()).hexdigest()
+    wav_store()["c5.wav"] = (torch.from_numpy(wav)[None, :], sr)
+    c = audio.wav_to_stft("c5.wav")
+    assert tuple(c.shape) == (512, 103360)
+    store["wav|stft_sha256"] = sha(torch.view_as_real(c))
+    store["wav|stft_maxabs"] = np.float64(c.abs().max().item())
+    cs = torch.view_as_real(c).reshape(-1)
+    store["wav|stft_samp"] = cs.numpy()[c5_sample_idx(cs.numel())]
+    magn, phase = audio.stft_to_phase_magn(c, nb_vec=512)
+    assert tuple(magn.shape) == tuple(phase.shape) == (201, 512, 512)
+    c5_put(store, "wav|magn", magn)
+    c5_put(store, "wav|phase", phase)
+    u = fn.unwrap(torch.angle(c))
+    d = u[:, 1:] - u[:, :-1]
+    store["wav|unwrapped_maxabs"] = np.float64(u.abs().max().item())
+    store["wav|delta_min"], store["wav|delta_max"] = np.float32(d.min().item()), np.float32(d.max().item())
+    del c, cs, magn, phase, u, d
+    # (2) library-independent complex input -> codec
+    x = torch.from_numpy(c5_spectrum())
+    store["spec|sha256"] = sha(torch.view_as_real(x))
+    magn, phase = audio.stft_to_phase_magn(x, nb_vec=512)
+    c5_put(store, "spec|magn", magn)
+    c5_put(store, "spec|phase", phase)
+    u = fn.unwrap(torch.angle(x))
+    d = u[:, 1:] - u[:, :-1]
+    store["spec|unwrapped_maxabs"] = np.float64(u.abs().max().item())
+    store["spec|delta_min"], store["spec|delta_max"] = np.float32(d.min().item()), np.float32(d.max().item())
+    del x, magn, phase, u, d
+    # (3) inverse over 20 480 frames
+    mp = torch.from_numpy(c5_inverse_input())
+    store["inv|sha256"] = sha(mp)
+    audio.magn_phase_to_wav(mp.clone(), "c5_out.wav", sr)
+    out, _ = wav_store()["c5_out.wav"]
+    out = out.reshape(-1)
+    assert out.numel() == 256 * (20480 - 1)
+    c5_put(store, "inv|wav", out)
+    store["inv|wav|head"], store["inv|wav|tail"] = out[:4096].numpy(), out[-4096:].numpy()
+    path = os.path.join(OUT, "audio_config5.npz")
+    np.savez_compressed(path, **store)
+    print("wrote", path, f"({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 KINK_MARGIN = 3e-6
 
 
@@ -445,6 +511,9 @@ def scan_seed(tag, seed0, target_norm=None, **kw):
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if "--config5-only" in sys.argv:
+        audio_config5_case()
+        sys.exit(0)
     scan_seed("l0_rc8", 11, rand_channels=8, n_grow=0, alpha=1.0, batch=3)
     scan_seed("l1_rc8_fade", 12, rand_channels=8, n_grow=1, alpha=0.37, batch=3)
     scan_seed("l3_rc32_fade", 13, rand_channels=32, n_grow=3, alpha=0.37, batch=2)
@@ -459,3 +528,4 @@ if __name__ == "__main__":
     transforms_case()
     progan_shapes_case()
     audio_case()
+    audio_config5_case()
