@@ -264,10 +264,17 @@ int mg_stft_1024(const float* wav, float* out_re, float* out_im, int64_t L, mg_s
  * mg_codec_fwd: stft_to_phase_magn [audio/functions.py:65-94].  stft_c64: interleaved complex64 [512][T] (mg_stft_1024 output);
  * bark_scale: [512] unit-norm bark vector (functions.py:26-35); outputs [S][512][nb_vec], S = (T-1)/nb_vec, both in [-1,1].
  * mg_codec_inv: magn_phase_to_wav [audio/functions.py:97-139] without the file write.  magn_phase: [N][2][512][W];
- * wav_out: [256*(N*W-1)].  The unwrap / cumulative sums run sequentially per frequency row in fp32 like torch.cumsum. */
+ * wav_out: [256*(N*W-1)].  The forward unwrap's cumulative sum [functions.py:23] is torch.cumsum's: a float64 running sum
+ * rounded to float32 per frame, evaluated as an exact blocked scan (T <= 2^24); the inverse's cumulative phase
+ * [functions.py:117-118] is the reference's sequential float32 loop.
+ * mg_codec_fwd_strided: the same with consecutive images `img_stride` floats apart (>= 512*nb_vec): with
+ * phase_out = magn_out + 512*nb_vec and img_stride = 2*512*nb_vec the outputs ARE the (S, 2, 512, nb_vec) tensor that
+ * create_dataset stacks [create_dataset.py:52-58], written once. */
 size_t mg_codec_fwd_ws_bytes(int T);
 int mg_codec_fwd(const float* stft_c64, const float* bark_scale, float* magn_out, float* phase_out, void* ws,
                  size_t ws_bytes, int T, int nb_vec, mg_stream_t stream);
+int mg_codec_fwd_strided(const float* stft_c64, const float* bark_scale, float* magn_out, float* phase_out, size_t img_stride,
+                         void* ws, size_t ws_bytes, int T, int nb_vec, mg_stream_t stream);
 size_t mg_codec_inv_ws_bytes(int N, int W);
 int mg_codec_inv(const float* magn_phase, const float* bark_scale, float* wav_out, void* ws, size_t ws_bytes, int N, int W,
                  mg_stream_t stream);

@@ -106,6 +106,7 @@ SIGNATURES = {
     "mg_stft_1024": (c_int, [_P, _P, _P, c_int64, _P]),
     "mg_codec_fwd_ws_bytes": (c_size_t, [c_int]),
     "mg_codec_fwd": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, _P]),
+    "mg_codec_fwd_strided": (c_int, [_P, _P, _P, _P, c_size_t, _P, c_size_t, c_int, c_int, _P]),
     "mg_codec_inv_ws_bytes": (c_size_t, [c_int, c_int]),
     "mg_codec_inv": (c_int, [_P, _P, _P, _P, c_size_t, c_int, c_int, _P]),
 }

@@ -3,11 +3,13 @@
 //            global min/max -> [-1,1], drop the leading remainder, split into nb_vec-frame images)
 //   inverse  functions.py:97-139 (un-bark, /(max-min), phase -> [-pi,pi], cumulative sum, mod 2pi, polar -> complex,
 //            zero Nyquist row, inverse_spectrogram == window * irfft, overlap-add / window envelope, centre trim)
-// The unwrap / cumulative sums are evaluated SEQUENTIALLY per frequency row in fp32, exactly as torch.cumsum does on the CPU:
-// the running sum reaches hundreds of radians, so any re-association would change the low bits the reference produces.
-// One lane per row walks time (the forward unwrap tiles it through LDS so that only the running sum itself is serial);
-// everything else is embarrassingly parallel and HBM-bound (8 B in + 8 B out per bin).
+// The forward unwrap's cumulative sum (functions.py:23, torch.cumsum: DOUBLE running sum, float32 outputs) is an exact blocked
+// scan over the whole chip (codec_row_pass); the inverse's cumulative phase (functions.py:117-118) is a Python loop of float32
+// adds in the reference, so it runs SEQUENTIALLY per frequency row in fp32 here too (inv_phase_cumsum: one lane per row walks
+// time through LDS tiles).  Everything else is embarrassingly parallel and HBM-bound (8 B in + 8 B out per bin).
 #include "mg_common.h"
+
+#include <cstdint>
 
 namespace {
 
@@ -42,53 +44,27 @@ __device__ __forceinline__ void block_minmax(float& mn, float& mx, float* red) {
   }
 }
 
-// ---- forward pass 1: magn = |X| * s[k], phi = atan2(im, re); per-block min/max of magn over t >= 1
-__global__ void __launch_bounds__(256) codec_abs_angle(const float2* __restrict__ X, const float* __restrict__ scale,
-                                                       float* __restrict__ magn, float* __restrict__ phi,
-                                                       float* __restrict__ part, int T) {
-  __shared__ float red[32];
-  const int k = blockIdx.y;
-  const float s = scale[k];
-  float mn = INFINITY, mx = -INFINITY;
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
-    const float2 v = X[(size_t)k * T + t];
-    const float m = hypotf(v.x, v.y) * s;
-    magn[(size_t)k * T + t] = m;
-    phi[(size_t)k * T + t] = atan2f(v.y, v.x);
-    if (t >= 1) {
-      mn = fminf(mn, m);
-      mx = fmaxf(mx, m);
-    }
-  }
-  block_minmax(mn, mx, red);
-  if (threadIdx.x == 0) {
-    part[2 * (blockIdx.y * gridDim.x + blockIdx.x)] = mn;
-    part[2 * (blockIdx.y * gridDim.x + blockIdx.x) + 1] = mx;
-  }
-}
-
-// ---- forward pass 2: per row, sequential unwrap (np.unwrap semantics incl. the -pi -> +pi fix), first difference of the
-// unwrapped phase -> delta[k][t-1], t = 1..T-1; partial min/max.
-// Only the running sum of the adjustments is sequential (c_t = c_{t-1} + adj_t, one fp32 add per frame, in frame order, exactly
-// as torch.cumsum does it); everything else is parallel.  A workgroup owns 64 frequency rows and walks time in tiles of 64
-// frames through LDS: 8 loader waves fetch a tile coalesced along t, compute the adjustments (wrap test, remainder, the
-// -pi -> +pi fix) and write phi / adj tiles; ONE scanner wave (lane = row) runs the sequential part of the tile before --
-// 3 adds per frame, operands by 16-byte LDS reads; 4 storer waves write the finished delta tile coalesced.  Loads and stores
-// sit in different waves on purpose: gfx950 retires a wave's vector-memory operations in order, so a wave that interleaves
-// them waits for a store round trip before every tile (measured: 5.8 us per tile instead of < 1).  One barrier per tile; all
-// tiles double-buffered.
-constexpr int UT = 64;     // frames per tile
-constexpr int USTR = 68;   // LDS row stride (floats): rows 16-byte aligned, 16-byte reads of 16 lanes hit 16 distinct slots
-constexpr int UTILE = 64 * USTR;
-constexpr size_t UNWRAP_LDS = (size_t)6 * UTILE * sizeof(float);
-constexpr int NLW = 8;             // loader waves
-constexpr int RPL = 64 / NLW;      // rows per loader lane
-constexpr int UNWRAP_THREADS = 64 * (1 + NLW + 4);
+// ---- forward pass 1 (codec_row_pass): one workgroup per frequency row walks the whole track.
+//   magn = |X| * s[k], phi = atan2(im, re); unwrap (np.unwrap semantics incl. the -pi -> +pi fix, functions.py:17-23); first
+//   difference of the unwrapped phase; both written UN-normalised straight into the chunked output images; per-row min / max.
+// The reference's `phi_adj.cumsum(1)` is torch.cumsum on a CPU float32 tensor: the running sum is kept in DOUBLE
+// (at::acc_type<float, false>) and every output is rounded to float32.  The adjustments are float32 values of magnitude
+// 2 pi (multiples of 2^-22, below 16), so a double holds any partial sum of up to 2^24 of them EXACTLY: the sum does not depend
+// on its association, and a blocked scan -- per-lane sums, a DPP scan over the wave, an 8-entry scan over the waves, a carry
+// per 2048-frame block -- returns bit for bit the doubles of the sequential loop.  (Rounds 1-2 kept a float32 running sum in one
+// scanner lane per row: 2.0 ms per 10-minute track on 8 workgroups, and 5e-3 off the reference at that length.)
+// A lane owns RQ = 4 consecutive OUTPUT columns (16-byte aligned stores into the images); a wave 256, the workgroup 2048 per
+// iteration; samples are requested three iterations ahead in three register sets.  ONE barrier per iteration: each wave
+// publishes (sum of its adjustments, its first and last phase) and then every wave redoes the 8-entry scan over the waves.
+constexpr int RW = 8;           // waves per row workgroup
+constexpr int RT = RW * 64;     // threads
+constexpr int RQ = 4;           // consecutive output columns per lane
+constexpr int RSPAN = RT * RQ;  // columns per workgroup iteration
 
 // torch.remainder(a, 2 pi) for a = dphi + pi.  Both phases come from atan2f, so a lies in [-pi, 3 pi] and fmodf reduces to at most
 // one exact subtraction (Sterbenz: a - b is exact for b <= a <= 2b) or, for negative a, the single rounded add of py_mod: the
 // three-way select below returns the same bits as the library call at a few instructions instead of a few hundred.
-// (phi is this file's own atan2f output, codec_abs_angle above; outside [-2 pi, 4 pi) the select would not be a remainder.)
+// (phi is this file's own atan2f output; outside [-2 pi, 4 pi) the select would not be a remainder.)
 __device__ __forceinline__ float py_mod_2pi_near(float a) {
   return a >= TWO_PI_F ? a - TWO_PI_F : (a < 0.f ? a + TWO_PI_F : a);
 }
@@ -102,118 +78,199 @@ __device__ __forceinline__ float unwrap_adj(float cur, float prev) {
   return adj;
 }
 
-__global__ void __launch_bounds__(UNWRAP_THREADS) codec_unwrap_delta(const float* __restrict__ phi, float* __restrict__ delta,
-                                                          float* __restrict__ part, int T) {
-  extern __shared__ __attribute__((aligned(16))) float usm[];
-  float* phi_s = usm;               // [2][64][USTR]
-  float* adj_s = usm + 2 * UTILE;   // [2][64][USTR]
-  float* out_s = usm + 4 * UTILE;   // [2][64][USTR]
+template <int CTRL, int RMASK>
+__device__ __forceinline__ double dpp_f64(double v) {  // lanes without a source (row edge, masked row) read 0.0
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, RMASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, RMASK, 0xf, false);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+
+__device__ __forceinline__ double wave_incl_scan_f64(double v) {
+  v += dpp_f64<0x111, 0xf>(v);  // row_shr:1
+  v += dpp_f64<0x112, 0xf>(v);  // row_shr:2
+  v += dpp_f64<0x114, 0xf>(v);  // row_shr:4
+  v += dpp_f64<0x118, 0xf>(v);  // row_shr:8   -> inclusive scan inside each row of 16
+  v += dpp_f64<0x142, 0xa>(v);  // row_bcast15 -> rows 1, 3 add the total of the row below
+  v += dpp_f64<0x143, 0xc>(v);  // row_bcast31 -> rows 2, 3 add the total of rows 0-1
+  return v;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {  // l wave-uniform
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+
+__global__ void __launch_bounds__(RT) codec_row_pass(const float2* __restrict__ X, const float* __restrict__ scale,
+                                                     float* __restrict__ magn_out, float* __restrict__ phase_out,
+                                                     float* __restrict__ part, int T, int nb_signed, int rem,
+                                                     size_t img_stride) {
+  __shared__ double tot_s[2][RW];
+  __shared__ float first_s[2][RW], last_s[2][RW];
   __shared__ float red[32];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int k0 = blockIdx.x * 64;
-  const int ntile = (T - 1 + UT - 1) / UT;  // tile q covers frames t = 1 + 64 q + col
-  const bool scanner = wave == 0, loader = wave >= 1 && wave <= NLW, storer = wave > NLW;
-  // producer geometry: column = lane (coalesced along t), 16 rows each.  Three register sets keep tiles q+1 .. q+3 in flight
-  // (two full iterations of latency cover); phi[t-1] comes from the neighbour lane, for lane 0 from the previous tile's
-  // last column (kept in scalars)
-  const int pcol = lane, prow0 = loader ? (wave - 1) * RPL : (storer ? (wave - 1 - NLW) * 16 : 0);
-  float r0[RPL], r1[RPL], r2[RPL];
-  float lastcol[RPL];  // wave-uniform: column 63 of the tile staged last
-  float mn = INFINITY, mx = -INFINITY;
+  const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float sc = scale[k];
+  const float2* __restrict__ Xr = X + (size_t)k * T;
+  const int lead = 1 + rem;               // frames in front of output column 0 (frame 0 + the dropped remainder)
+  const int J0 = -((lead + 3) & ~3);      // first column processed: 4-aligned, <= -lead (frames < 0 are masked)
+  const int nout = T - lead;              // stored columns = S * nb
+  const int niter = (nout - J0 + RSPAN - 1) / RSPAN;
+  const bool vec = nb_signed > 0;         // host: a lane's 4 columns never straddle an image and are 16-byte aligned
+  const int nb = vec ? nb_signed : -nb_signed;
+  float mnm = INFINITY, mxm = -INFINITY, mnp = INFINITY, mxp = -INFINITY;
+  double carry = 0.0;                     // running sum of the adjustments of all frames before this iteration's block
 
-  auto load_tile = [&](int q, float (&r)[RPL]) {
-    // unconditional (frames past the end re-read frame T-1; their adjustment is forced to 0 and their delta never stored):
-    // with divergent loads hipcc waits vmcnt(0) at every use and the three-tile prefetch collapses
-    const long long tq = 1ll + (long long)q * UT + pcol;
-    const int t = tq < T ? (int)tq : T - 1;
+  auto load = [&](int it, float2 (&x)[RQ]) {  // unconditional, clamped: frames outside [0, T) re-read an edge frame and are masked
+    const long long j = (long long)J0 + (long long)it * RSPAN + tid * RQ + lead;
 #pragma unroll
-    for (int i = 0; i < RPL; ++i) r[i] = phi[(size_t)(k0 + prow0 + i) * T + t];
-  };
-  auto stage_tile = [&](int q, const float (&r)[RPL]) {  // registers -> phi / adj tiles of buffer q & 1 (past the end: adj 0)
-    float* ph = phi_s + (q & 1) * UTILE;
-    float* ad = adj_s + (q & 1) * UTILE;
-    const bool ok = (1 + q * UT + pcol) < T;
-#pragma unroll
-    for (int i = 0; i < RPL; ++i) {
-      const float left = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r[i]), 0x138, 0xf, 0xf, false));
-      const float prev = pcol == 0 ? lastcol[i] : left;
-      ph[(prow0 + i) * USTR + pcol] = r[i];
-      ad[(prow0 + i) * USTR + pcol] = ok ? unwrap_adj(r[i], prev) : 0.f;
-      lastcol[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r[i]), 63));
+    for (int e = 0; e < RQ; ++e) {
+      long long t = j + e;
+      t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+      x[e] = Xr[t];
     }
   };
-  auto store_tile = [&](int q) {  // finished delta tile -> global, coalesced along t; min/max on the way
-    const float* o = out_s + (q & 1) * UTILE;
-    const int t = 1 + q * UT + pcol;
-    if (t < T) {
+  auto body = [&](int it, float2 (&x)[RQ]) {
+    const int p = it & 1;
+    const int jw = J0 + it * RSPAN;        // column of the workgroup's first element
+    const int j0 = jw + tid * RQ;          // this lane's first column; frame t = column + lead
+    float m[RQ], ph[RQ];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float v = o[(prow0 + i) * USTR + pcol];
-        delta[(size_t)(k0 + prow0 + i) * (T - 1) + (t - 1)] = v;
-        mn = fminf(mn, v);
-        mx = fmaxf(mx, v);
-      }
+    for (int e = 0; e < RQ; ++e) {
+      m[e] = hypotf(x[e].x, x[e].y) * sc;
+      ph[e] = atan2f(x[e].y, x[e].x);
     }
-  };
-
-  float c = 0.f, prev_u = 0.f;  // scanner state of row k0 + lane: running sum of adjustments, previous unwrapped value
-  if (scanner) {
-    prev_u = phi[(size_t)(k0 + lane) * T];  // unwrapped[0] = phi[0]
-  } else if (loader) {
+    load(it + 3, x);
+    auto valid = [&](int col) { return col + lead >= 1 && col < nout; };  // 1 <= t <= T-1
+    // adjustments; the wave's very first element (lane 0) needs the previous wave's last phase: after the barrier
+    const float left = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ph[RQ - 1]), 0x138, 0xf, 0xf, false));
+    float adj[RQ];
+    adj[0] = (lane > 0 && valid(j0)) ? unwrap_adj(ph[0], left) : 0.f;
 #pragma unroll
-    for (int i = 0; i < RPL; ++i) lastcol[i] = phi[(size_t)(k0 + prow0 + i) * T];  // phi[0]: left neighbour of frame 1
-    load_tile(0, r0);
-    load_tile(1, r1);
-    load_tile(2, r2);
-    stage_tile(0, r0);
-    load_tile(3, r0);
-  }
-  __syncthreads();
-  auto scan_tile = [&](int q) {
-    const float* ph = phi_s + (q & 1) * UTILE + lane * USTR;
-    const float* ad = adj_s + (q & 1) * UTILE + lane * USTR;
-    float* o = out_s + (q & 1) * UTILE + lane * USTR;
-#pragma unroll 4
-    for (int j = 0; j < UT; j += 4) {
-      const f32x4 pv = *reinterpret_cast<const f32x4*>(ph + j);
-      const f32x4 av = *reinterpret_cast<const f32x4*>(ad + j);
-      f32x4 ov;
+    for (int e = 1; e < RQ; ++e) adj[e] = valid(j0 + e) ? unwrap_adj(ph[e], ph[e - 1]) : 0.f;
+    double sl[RQ];
+    sl[0] = (double)adj[0];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        c += av[e];
-        const float u = pv[e] + c;
-        ov[e] = u - prev_u;
-        prev_u = u;
-      }
-      *reinterpret_cast<f32x4*>(o + j) = ov;
+    for (int e = 1; e < RQ; ++e) sl[e] = sl[e - 1] + (double)adj[e];
+    const double incl = wave_incl_scan_f64(sl[RQ - 1]);
+    if (lane == 63) {
+      tot_s[p][wave] = incl;
+      last_s[p][wave] = ph[RQ - 1];
     }
-  };
-  // iteration q: the scanner runs tile q; the storers write tile q-1; the loaders stage tile q+1 (registers loaded two
-  // iterations ago) and re-load that register set with tile q+4
-  auto iteration = [&](int q, float (&r)[RPL]) {
-    if (scanner) {
-      if (q < ntile) scan_tile(q);
-    } else if (loader) {
-      stage_tile(q + 1, r);
-      load_tile(q + 4, r);
-    } else {
-      if (q > 0 && q - 1 < ntile) store_tile(q - 1);
-    }
+    if (lane == 0) first_s[p][wave] = ph[0];
     __syncthreads();
+    // scan over the waves, redone by every wave in its lanes 0..RW-1 (entry l = wave l; lanes >= RW mirror the last entry)
+    const int l = lane < RW ? lane : RW - 1;
+    const float lp = l > 0 ? last_s[p][l - 1] : last_s[p ^ 1][RW - 1];  // (first iteration: unwritten, masked by valid())
+    const float af = valid(jw + l * 64 * RQ) ? unwrap_adj(first_s[p][l], lp) : 0.f;
+    const double tl = tot_s[p][l];
+    double v = (double)af + tl;
+    v += dpp_f64<0x111, 0xf>(v);
+    v += dpp_f64<0x112, 0xf>(v);
+    v += dpp_f64<0x114, 0xf>(v);
+    const double off = carry + (readlane_f64(v, wave) - readlane_f64(tl, wave));  // everything before this wave + its own first adj
+    const float af_w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, af), wave));
+    const float lp_w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lp), wave));
+    carry += readlane_f64(v, RW - 1);
+    const double base = off + (incl - sl[RQ - 1]);
+    float d[RQ];
+#pragma unroll
+    for (int e = 0; e < RQ; ++e) {
+      const double c = base + sl[e];                       // cumulative adjustment up to and including this frame (exact)
+      const float a = e == 0 ? (lane > 0 ? adj[0] : af_w) : adj[e];
+      const float pv = e == 0 ? (lane > 0 ? left : lp_w) : ph[e - 1];
+      const float u = ph[e] + (float)c;                    // unwrapped[t]   = phi[t]   + float32(cumsum[t])
+      const float up = pv + (float)(c - (double)a);        // unwrapped[t-1] = phi[t-1] + float32(cumsum[t-1])
+      d[e] = u - up;
+      if (valid(j0 + e)) {
+        mnm = fminf(mnm, m[e]);
+        mxm = fmaxf(mxm, m[e]);
+        mnp = fminf(mnp, d[e]);
+        mxp = fmaxf(mxp, d[e]);
+      }
+    }
+    if (vec) {
+      if (j0 >= 0 && j0 < nout) {
+        const unsigned img = (unsigned)j0 / (unsigned)nb, col = (unsigned)j0 - img * (unsigned)nb;
+        const size_t o = (size_t)img * img_stride + (size_t)k * nb + col;
+        *reinterpret_cast<f32x4*>(magn_out + o) = f32x4{m[0], m[1], m[2], m[3]};
+        *reinterpret_cast<f32x4*>(phase_out + o) = f32x4{d[0], d[1], d[2], d[3]};
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < RQ; ++e) {
+        const int j = j0 + e;
+        if (j >= 0 && j < nout) {
+          const unsigned img = (unsigned)j / (unsigned)nb, col = (unsigned)j - img * (unsigned)nb;
+          const size_t o = (size_t)img * img_stride + (size_t)k * nb + col;
+          magn_out[o] = m[e];
+          phase_out[o] = d[e];
+        }
+      }
+    }
   };
-  for (int q = 0; q < ntile; q += 3) {
-    iteration(q, r1);
-    iteration(q + 1, r2);
-    iteration(q + 2, r0);
+
+  float2 xa[RQ], xb[RQ], xc[RQ];
+  load(0, xa);
+  load(1, xb);
+  load(2, xc);
+  for (int it = 0; it < niter; it += 3) {  // (iterations past niter only touch masked columns)
+    body(it, xa);
+    body(it + 1, xb);
+    body(it + 2, xc);
   }
-  if (storer) {
-    const int qe = ((ntile + 2) / 3) * 3;  // iterations run: tiles up to qe-2 are stored inside the loop
-    if (qe - 1 < ntile) store_tile(qe - 1);
-  }
-  block_minmax(mn, mx, red);
+  block_minmax(mnm, mxm, red);
+  float a0 = mnm, a1 = mxm;
+  block_minmax(mnp, mxp, red);
   if (tid == 0) {
-    part[2 * blockIdx.x] = mn;
-    part[2 * blockIdx.x + 1] = mx;
+    part[4 * k] = a0;
+    part[4 * k + 1] = a1;
+    part[4 * k + 2] = mnp;
+    part[4 * k + 3] = mxp;
+  }
+}
+
+// ---- forward pass 2: global min / max from the 512 row records, then both images to [-1, 1] in place:
+// (v - min) / (max - min) * 2 - 1 (functions.py:84-87).  blockIdx.y walks the images (plane = 512 * nb floats each, img_stride apart).
+__global__ void __launch_bounds__(256) codec_normalize_inplace(float* __restrict__ magn, float* __restrict__ phase,
+                                                               const float* __restrict__ part, int S, size_t plane,
+                                                               size_t img_stride, int vec) {
+  __shared__ float red[32];
+  float mnm = INFINITY, mxm = -INFINITY, mnp = INFINITY, mxp = -INFINITY;
+  for (int r = threadIdx.x; r < NB; r += 256) {
+    const f32x4 q = *reinterpret_cast<const f32x4*>(part + 4 * r);
+    mnm = fminf(mnm, q[0]);
+    mxm = fmaxf(mxm, q[1]);
+    mnp = fminf(mnp, q[2]);
+    mxp = fmaxf(mxp, q[3]);
+  }
+  block_minmax(mnm, mxm, red);
+  block_minmax(mnp, mxp, red);
+  const float rm = mxm - mnm, rp = mxp - mnp;
+  const size_t stride = (size_t)gridDim.x * blockDim.x, first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int img = blockIdx.y; img < S; img += gridDim.y) {
+    float* mi = magn + (size_t)img * img_stride;
+    float* pi = phase + (size_t)img * img_stride;
+    if (vec) {
+      f32x4* m4 = reinterpret_cast<f32x4*>(mi);
+      f32x4* p4 = reinterpret_cast<f32x4*>(pi);
+      for (size_t i = first; i < plane / 4; i += stride) {
+        f32x4 a = m4[i], b = p4[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a[e] = (a[e] - mnm) / rm * 2.f - 1.f;
+          b[e] = (b[e] - mnp) / rp * 2.f - 1.f;
+        }
+        m4[i] = a;
+        p4[i] = b;
+      }
+    } else {
+      for (size_t i = first; i < plane; i += stride) {
+        mi[i] = (mi[i] - mnm) / rm * 2.f - 1.f;
+        pi[i] = (pi[i] - mnp) / rp * 2.f - 1.f;
+      }
+    }
   }
 }
 
@@ -229,23 +286,6 @@ __global__ void __launch_bounds__(256) minmax_final(const float* __restrict__ pa
   if (threadIdx.x == 0) {
     out[0] = mn;
     out[1] = mx;
-  }
-}
-
-// ---- forward pass 3: normalise to [-1,1], drop the leading remainder, chunk: out[s][k][j] = f(src[k][off + s*nb + j])
-__global__ void __launch_bounds__(256) codec_normalize_chunk(const float* __restrict__ src, int row_stride, int off,
-                                                             const float* __restrict__ mm, float* __restrict__ out, int S,
-                                                             int nb) {
-  const float mn = mm[0], mx = mm[1];
-  const float range = mx - mn;
-  const size_t total = (size_t)S * NB * nb;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int j = (int)(i % nb);
-    const size_t r = i / nb;
-    const int k = (int)(r % NB);
-    const int s = (int)(r / NB);
-    const float v = src[(size_t)k * row_stride + off + (size_t)s * nb + j];
-    out[i] = (v - mn) / range * 2.f - 1.f;
   }
 }
 
@@ -276,6 +316,10 @@ __global__ void __launch_bounds__(256) inv_unbark(const float* __restrict__ mp, 
 // fp32 cumsum per frequency row), mod 2 pi, polar -> complex.  Only the running sum is serial: inv_phase_cumsum tiles it through
 // LDS exactly like codec_unwrap_delta (4 loader waves, ONE scanner wave with lane = row, 4 storer waves; loads and stores in
 // different waves) and writes the running phase; inv_polar then does the remainder / sincos / scaling on the whole chip.
+constexpr int UT = 64;     // frames per tile
+constexpr int USTR = 68;   // LDS row stride (floats): rows 16-byte aligned, 16-byte reads of 16 lanes hit 16 distinct slots
+constexpr int UTILE = 64 * USTR;
+
 __global__ void __launch_bounds__(576) inv_phase_cumsum(const float* __restrict__ mp, float* __restrict__ acc_out, int N,
                                                         int W) {
   extern __shared__ __attribute__((aligned(16))) float usm[];
@@ -430,54 +474,47 @@ __global__ void __launch_bounds__(256) inv_overlap_add(const float* __restrict__
 }  // namespace
 
 extern "C" size_t mg_codec_fwd_ws_bytes(int T) {
-  // magn[512*T] + phi[512*T] + delta[512*(T-1)] + partials
-  return ((size_t)NB * T * 3 + 2 * (size_t)NB * 64 + 2 * NB + 16) * sizeof(float);
+  (void)T;  // the per-row (min, max) records only: nothing of the track's size is staged any more
+  return ((size_t)4 * NB + 16) * sizeof(float);
 }
 
-extern "C" int mg_codec_fwd(const float* stft_c64, const float* bark_scale, float* magn_out, float* phase_out, void* ws,
-                            size_t ws_bytes, int T, int nb_vec, mg_stream_t stream) {
+extern "C" int mg_codec_fwd_strided(const float* stft_c64, const float* bark_scale, float* magn_out, float* phase_out,
+                                    size_t img_stride, void* ws, size_t ws_bytes, int T, int nb_vec, mg_stream_t stream) {
   MG_CHECK_ARG(stft_c64 && bark_scale && magn_out && phase_out && ws, "mg_codec_fwd: bad arguments");
   MG_CHECK_ARG(nb_vec > 0 && T - 1 >= nb_vec, "mg_codec_fwd: needs T-1 >= nb_vec (T=%d, nb_vec=%d)", T, nb_vec);
+  MG_CHECK_ARG(T <= (1 << 24), "mg_codec_fwd: T=%d frames; the exact blocked scan is specified up to 2^24", T);
+  MG_CHECK_ARG(img_stride >= (size_t)NB * nb_vec, "mg_codec_fwd: image stride smaller than an image");
+  MG_CHECK_ARG(reinterpret_cast<uintptr_t>(ws) % 16 == 0 && reinterpret_cast<uintptr_t>(stft_c64) % 8 == 0,
+               "mg_codec_fwd: the workspace must be 16-byte aligned, the input 8-byte aligned");
   if (ws_bytes < mg_codec_fwd_ws_bytes(T)) {
     mg_set_error("mg_codec_fwd: workspace too small");
     return MG_EWORKSPACE;
   }
   hipStream_t s = (hipStream_t)stream;
-  float* magn = reinterpret_cast<float*>(ws);
-  float* phi = magn + (size_t)NB * T;
-  float* delta = phi + (size_t)NB * T;
-  float* part_m = delta + (size_t)NB * (T - 1);
-  float* part_p = part_m + 2 * (size_t)NB * 64;
-  float* mm = part_p + 2 * NB;  // [mn_m, mx_m, mn_p, mx_p]
-  int gx = (T + 255) / 256;
-  if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(codec_abs_angle, dim3(gx, NB), dim3(256), 0, s, reinterpret_cast<const float2*>(stft_c64),
-                     bark_scale, magn, phi, part_m, T);
-  static MgPerDevice once;  // the LDS limit is a per-device function attribute
-  if (mg_first_use_on_device(once)) {
-    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&codec_unwrap_delta),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-    if (ea != hipSuccess) {
-      mg_set_error("mg_codec_fwd: hipFuncSetAttribute: %s", hipGetErrorString(ea));
-      return MG_ELAUNCH;
-    }
-  }
-  MG_CHECK_LAUNCH("mg_codec_fwd(abs_angle)");
-  hipLaunchKernelGGL(codec_unwrap_delta, dim3(NB / 64), dim3(UNWRAP_THREADS), UNWRAP_LDS, s, phi, delta, part_p, T);
-  MG_CHECK_LAUNCH("mg_codec_fwd(unwrap)");
-  hipLaunchKernelGGL(minmax_final, dim3(1), dim3(256), 0, s, part_m, gx * NB, mm);
-  hipLaunchKernelGGL(minmax_final, dim3(1), dim3(256), 0, s, part_p, NB / 64, mm + 2);
+  float* part = reinterpret_cast<float*>(ws);  // [512][mn_magn, mx_magn, mn_phase, mx_phase]
   const int S = (T - 1) / nb_vec;
   const int rem = (T - 1) % nb_vec;
-  const size_t total = (size_t)S * NB * nb_vec;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
-  // magn[:, 1:] then drop `rem` leading frames: column offset 1 + rem in the T-wide rows; delta rows are (T-1) wide
-  hipLaunchKernelGGL(codec_normalize_chunk, dim3(blocks), dim3(256), 0, s, magn, T, 1 + rem, mm, magn_out, S, nb_vec);
-  hipLaunchKernelGGL(codec_normalize_chunk, dim3(blocks), dim3(256), 0, s, delta, T - 1, rem, mm + 2, phase_out, S,
-                     nb_vec);
-  MG_CHECK_LAUNCH("mg_codec_fwd");
+  // 16-byte stores need 4-column groups that never straddle an image and aligned image bases; anything else: scalar stores
+  const int vec = (nb_vec % 4 == 0 && img_stride % 4 == 0 &&
+                   (reinterpret_cast<uintptr_t>(magn_out) | reinterpret_cast<uintptr_t>(phase_out)) % 16 == 0)
+                      ? 1 : 0;
+  hipLaunchKernelGGL(codec_row_pass, dim3(NB), dim3(RT), 0, s, reinterpret_cast<const float2*>(stft_c64), bark_scale,
+                     magn_out, phase_out, part, T, vec ? nb_vec : -nb_vec, rem, img_stride);
+  MG_CHECK_LAUNCH("mg_codec_fwd(row pass)");
+  const size_t plane = (size_t)NB * nb_vec;
+  int bx = (int)((plane / (vec ? 4 : 1) + 1023) / 1024);  // ~4 items per thread
+  if (bx < 1) bx = 1;
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(codec_normalize_inplace, dim3(bx, S > 1024 ? 1024 : S), dim3(256), 0, s, magn_out, phase_out, part, S,
+                     plane, img_stride, vec);
+  MG_CHECK_LAUNCH("mg_codec_fwd(normalize)");
   return MG_OK;
+}
+
+extern "C" int mg_codec_fwd(const float* stft_c64, const float* bark_scale, float* magn_out, float* phase_out, void* ws,
+                            size_t ws_bytes, int T, int nb_vec, mg_stream_t stream) {
+  return mg_codec_fwd_strided(stft_c64, bark_scale, magn_out, phase_out, (size_t)NB * (nb_vec > 0 ? nb_vec : 0), ws, ws_bytes,
+                              T, nb_vec, stream);
 }
 
 extern "C" size_t mg_codec_inv_ws_bytes(int N, int W) {

@@ -582,8 +582,9 @@ def stft_1024(wav_mono: torch.Tensor) -> torch.Tensor:
     return torch.view_as_complex(out)
 
 
-def codec_fwd(stft_c: torch.Tensor, bark_scale: torch.Tensor, nb_vec: int):
-    """complex64 [512, T] -> (magn, phase) each [S, 512, nb_vec] in [-1, 1]  (audio/functions.py:65-94)."""
+def codec_fwd(stft_c: torch.Tensor, bark_scale: torch.Tensor, nb_vec: int, stacked: bool = False):
+    """complex64 [512, T] -> (magn, phase) each [S, 512, nb_vec] in [-1, 1]  (audio/functions.py:65-94).
+    `stacked`: one [S, 2, 512, nb_vec] tensor instead (what create_dataset.py:52-58 stacks), written in place by the kernel."""
     assert stft_c.is_complex() and stft_c.shape[0] == 512
     xr = torch.view_as_real(stft_c.contiguous())
     _chk(xr, bark_scale)
@@ -591,6 +592,11 @@ def codec_fwd(stft_c: torch.Tensor, bark_scale: torch.Tensor, nb_vec: int):
     s = (t - 1) // nb_vec
     lib = _lib.load()
     ws = workspace(lib.mg_codec_fwd_ws_bytes(t), xr.device)
+    if stacked:
+        both = torch.empty((s, 2, 512, nb_vec), dtype=torch.float32, device=xr.device)
+        check(lib.mg_codec_fwd_strided(_p(xr), _p(bark_scale), _p(both), both.data_ptr() + 4 * 512 * nb_vec, 2 * 512 * nb_vec,
+                                       _p(ws), ws.numel(), t, nb_vec, _s()), "mg_codec_fwd_strided")
+        return both
     magn = torch.empty((s, 512, nb_vec), dtype=torch.float32, device=xr.device)
     phase = torch.empty_like(magn)
     check(lib.mg_codec_fwd(_p(xr), _p(bark_scale), _p(magn), _p(phase), _p(ws), ws.numel(), t, nb_vec, _s()),

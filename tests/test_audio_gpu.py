@@ -61,8 +61,116 @@ def test_inverse_codec_matches_reference_golden(tmp_path):
             audio.magn_phase_to_waveform(bad.to(DEV))
 
 
+def _c5(case):
+    import hashlib
+    from golden_util import c5_inverse_input, c5_spectrum, c5_waveform
+    g = load("audio_config5.npz")
+    x = {"wav": c5_waveform, "spec": c5_spectrum, "inv": c5_inverse_input}[case]()
+    key = "wav|sha256" if case == "wav" else f"{case}|sha256"
+    assert hashlib.sha256(np.ascontiguousarray(x).view(np.float32).tobytes()).hexdigest() == str(g[key]), \
+        "the regenerated config-5 input is not the one the reference was given"
+    return g, x
+
+
+def _c5_check_magn(g, case, magn, tol):
+    from golden_util import c5_sample_idx
+    got = magn.reshape(-1)[torch.from_numpy(c5_sample_idx(magn.numel())).to(magn.device)].cpu().numpy()
+    assert float(np.abs(got - g[f"{case}|magn|samp"]).max()) <= tol
+    rows = magn[[0, 0, 0, -1, -1, -1], [0, 255, 511, 0, 255, 511], :].cpu().numpy()
+    assert float(np.abs(rows - g[f"{case}|magn|rows"]).max()) <= tol
+    assert abs(float(magn.double().sum()) - float(g[f"{case}|magn|sum"])) <= tol * magn.numel() * 0.05
+
+
+def test_codec_at_config5_size_against_the_reference():
+    """BASELINE config 5 at its stated size: stft_to_phase_magn (functions.py:65-94) on 103 360 frames -> 201 images against the
+    REFERENCE's output on the same bits (library-independent STFT-like input whose unwrapped phase reaches 1.6e5 rad).
+    The phase image is discontinuous in its input (golden_util.c5_phase_stats): the GPU's atan2f differs from torch's by an ulp on
+    part of the bins, the exact running sum (torch.cumsum: float64 accumulator) turns that into one ulp(1e5 rad) on ~0.1 % of the
+    elements.  Bounds: >= 90 % of the sampled elements within 1e-6, NONE beyond two ulps of the unwrapped phase, <= 3 wrap flips
+    (the numpy oracle, same sum with numpy's atan2f, sits at 94 %; a float32 running sum -- rounds 1-2 -- at 0.05 %).
+    Second, the scan itself with the math library taken out: the oracle's codec fed the device's own |X| and angle(X) must
+    reproduce the kernel's images bit for bit."""
+    from golden_util import c5_phase_stats
+    from musicgan_amd import audio
+    from oracle import audio as OA
+    g, x = _c5("spec")
+    xd = torch.from_numpy(x).to(DEV)
+    magn, phase = audio.stft_to_phase_magn(xd)
+    assert tuple(magn.shape) == tuple(phase.shape) == (201, 512, 512)
+    frac, worst, flips, n = c5_phase_stats(g, "spec", phase.cpu().numpy())
+    print(f"config-5 codec vs reference: {frac:.4%} of {n} within 1e-6, worst {worst:.3f} of the 2-ulp bound, {flips} flips")
+    assert frac >= 0.90 and worst <= 1.0 and flips <= 3, (frac, worst, flips, n)
+    _c5_check_magn(g, "spec", magn, 2e-6)
+    assert float(magn.min()) == -1.0 and float(magn.max()) == 1.0 and float(phase.min()) == -1.0 and float(phase.max()) == 1.0
+    # the stacked form create_dataset uses is the same bits in one (S, 2, 512, 512) tensor
+    from musicgan_amd import ops
+    both = ops.codec_fwd(xd, audio.functions._bark_vector(512, xd.device), 512, stacked=True)
+    assert torch.equal(both[:, 0], magn) and torch.equal(both[:, 1], phase)
+    del both
+    # scan isolated from the math library
+    m_dev = (torch.abs(xd)).cpu().numpy()
+    p_dev = torch.angle(xd).cpu().numpy()
+    m_or, p_or = OA.stft_to_phase_magn(x, lib=(m_dev, p_dev))
+    same = float(np.mean(p_or == phase.cpu().numpy()))
+    print(f"scan vs oracle on the device's own angle(X): {same:.6%} bit-identical")
+    assert same >= 0.999, same
+
+
+def test_waveform_to_codec_at_config5_size_against_the_reference():
+    """The seed-7 10-minute track of SURVEY 8(d) through mg_stft_1024 + mg_codec_fwd against the reference's wav_to_stft +
+    stft_to_phase_magn (create_dataset.py:34-64).  The bins agree to 1e-5 of max|X| (float32 FFTs of different factorisations),
+    so weak bins' phases differ by more than an ulp and the phase bound is the distributional one with a lower share of
+    1e-6-exact elements (the oracle's float64 FFT: 92 %)."""
+    from golden_util import c5_phase_stats, c5_sample_idx
+    from musicgan_amd import audio
+    g, wav = _c5("wav")
+    c = audio.functions.stft_from_waveform(torch.from_numpy(wav).to(DEV))
+    assert tuple(c.shape) == (512, 103360)
+    cs = torch.view_as_real(c).reshape(-1)[torch.from_numpy(c5_sample_idx(2 * c.numel())).to(DEV)].cpu().numpy()
+    assert float(np.abs(cs - g["wav|stft_samp"]).max()) <= 1e-5 * float(g["wav|stft_maxabs"])
+    magn, phase = audio.stft_to_phase_magn(c)
+    frac, worst, flips, n = c5_phase_stats(g, "wav", phase.cpu().numpy())
+    print(f"config-5 wav -> codec vs reference: {frac:.4%} of {n} within 1e-6, worst {worst:.3f} of the 2-ulp bound, {flips} flips")
+    assert frac >= 0.75 and worst <= 1.0 and flips <= 3, (frac, worst, flips, n)
+    _c5_check_magn(g, "wav", magn, 5e-6)
+
+
+def test_inverse_codec_over_20480_frames_against_the_reference():
+    """magn_phase_to_wav (functions.py:97-139) on 40 images = 20 480 frames, the length `generate` runs it at."""
+    from golden_util import c5_sample_idx
+    from musicgan_amd import audio
+    g, mp = _c5("inv")
+    wav = audio.magn_phase_to_waveform(torch.from_numpy(mp).to(DEV))
+    assert wav.numel() == 256 * (20480 - 1)
+    scale = float(g["inv|wav|maxabs"])
+    idx = torch.from_numpy(c5_sample_idx(wav.numel())).to(DEV)
+    errs = [float(np.abs(wav[idx].cpu().numpy() - g["inv|wav|samp"]).max()),
+            float(np.abs(wav[:4096].cpu().numpy() - g["inv|wav|head"]).max()),
+            float(np.abs(wav[-4096:].cpu().numpy() - g["inv|wav|tail"]).max())]
+    print("inverse over 20 480 frames: max error / max|wav| =", [e / scale for e in errs])
+    assert max(errs) <= 1e-5 * scale, errs  # measured 2e-7: the cumulative phase is the same sequential float32 sum
+
+
+def test_codec_odd_sizes_against_oracle():
+    """Ragged shapes: track lengths around the 2048-column block of the scan, nb_vec that is not a multiple of 4 (scalar stores)
+    and one that does not divide the track (leading remainder dropped, functions.py:89-90)."""
+    from musicgan_amd import audio
+    from oracle import audio as OA
+    rng = np.random.default_rng(11)
+    for frames, nb in ((513, 512), (2049, 512), (2050, 512), (4097, 512), (6151, 512), (1000, 250), (777, 333), (130, 7)):
+        x = ((rng.random((512, frames), dtype=np.float32) - 0.5) + 1j * (rng.random((512, frames), dtype=np.float32) - 0.5))
+        x = x.astype(np.complex64)
+        xd = torch.from_numpy(x).to(DEV)
+        magn, phase = audio.stft_to_phase_magn(xd, nb_vec=nb)
+        m_or, p_or = OA.stft_to_phase_magn(x, nb_vec=nb, lib=(torch.abs(xd).cpu().numpy(), torch.angle(xd).cpu().numpy()))
+        assert tuple(magn.shape) == m_or.shape == ((frames - 1) // nb, 512, nb), (frames, nb)
+        assert float(np.abs(magn.cpu().numpy() - m_or).max()) <= 2e-6, (frames, nb)
+        assert float(np.mean(phase.cpu().numpy() == p_or)) >= 0.999, (frames, nb)
+        assert float(np.abs(phase.cpu().numpy() - p_or).max()) <= 1e-4, (frames, nb)
+
+
 def test_codec_long_track_against_oracle():
-    """2 000 frames: the sequential fp32 unwrap must track the oracle's torch.cumsum-style running sum."""
+    """2 000 frames: the unwrap must track the oracle's torch.cumsum-style (float64 accumulator) running sum."""
     from musicgan_amd import audio
     from oracle import audio as OA
     rng = np.random.default_rng(3)
