@@ -7,9 +7,9 @@ from .dataset import AudioDataset, PackedAudioDataset, PackedLoader, has_packed,
 from .transforms import ChangeRange, ChannelMinMaxNorm
 
 for _name in ("wav_to_stft", "stft_to_phase_magn", "magn_phase_to_wav", "bark_magn_scale", "stft_from_waveform",
-              "magn_phase_to_waveform"):
+              "magn_phase_to_waveform", "stft_to_stacked_phase_magn"):
     globals()[_name] = getattr(_functions, _name)
 del _name
 
 __all__ = ["wav_to_stft", "stft_to_phase_magn", "magn_phase_to_wav", "bark_magn_scale", "stft_from_waveform",
-           "magn_phase_to_waveform", "AudioDataset", "PackedAudioDataset", "PackedLoader", "has_packed", "write_packed", "ChannelMinMaxNorm", "ChangeRange", *_constant.__all__]
+           "magn_phase_to_waveform", "stft_to_stacked_phase_magn", "AudioDataset", "PackedAudioDataset", "PackedLoader", "has_packed", "write_packed", "ChannelMinMaxNorm", "ChangeRange", *_constant.__all__]

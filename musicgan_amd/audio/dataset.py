@@ -59,40 +59,70 @@ def write_packed(dataset_path: str) -> int:
     if not names:
         return 0
     path = os.path.join(dataset_path, PACKED_BIN)
-    mm = np.memmap(path + ".tmp", dtype=np.float32, mode="w+", shape=(len(names),) + _SAMPLE_SHAPE)
-    for i, n in enumerate(names):
-        x = torch.load(os.path.join(dataset_path, n))
-        assert tuple(x.shape) == _SAMPLE_SHAPE, f"{n}: shape {tuple(x.shape)}"
-        f = x.to(torch.float32)
-        assert torch.equal(f.to(x.dtype), x), f"{n}: values are not float32-representable"
-        mm[i] = f.numpy()
-    mm.flush()
-    del mm
+    try:
+        os.remove(os.path.join(dataset_path, PACKED_META))  # never leave a meta file describing a half-written array
+    except FileNotFoundError:
+        pass
+    try:
+        mm = np.memmap(path + ".tmp", dtype=np.float32, mode="w+", shape=(len(names),) + _SAMPLE_SHAPE)
+        for i, n in enumerate(names):
+            x = torch.load(os.path.join(dataset_path, n))
+            assert tuple(x.shape) == _SAMPLE_SHAPE, f"{n}: shape {tuple(x.shape)}"
+            f = x.to(torch.float32)
+            assert torch.equal(f.to(x.dtype), x), f"{n}: values are not float32-representable"
+            mm[i] = f.numpy()
+        mm.flush()
+        del mm
+    except BaseException:
+        try:
+            os.remove(path + ".tmp")
+        except FileNotFoundError:
+            pass
+        raise
     os.replace(path + ".tmp", path)
     with open(os.path.join(dataset_path, PACKED_META), "w") as fh:
-        json.dump({"count": len(names), "shape": list(_SAMPLE_SHAPE), "dtype": "float32", "files": list(names)}, fh)
+        json.dump({"count": len(names), "shape": list(_SAMPLE_SHAPE), "dtype": "float32", "files": list(names),
+                   "rows": list(range(len(names))), "sizes": [os.path.getsize(os.path.join(dataset_path, n)) for n in names]},
+                  fh)
     return len(names)
 
 
-def has_packed(dataset_path: str) -> bool:
-    """True when the side-car exists AND still matches the directory's .pt files (same names, same order)."""
+def _read_meta(dataset_path: str):
     meta = os.path.join(dataset_path, PACKED_META)
     if not (os.path.exists(meta) and os.path.exists(os.path.join(dataset_path, PACKED_BIN))):
-        return False
+        return None
     with open(meta) as fh:
-        m = json.load(fh)
-    return tuple(m.get("files", ())) == _sample_files(dataset_path)
+        return json.load(fh)
+
+
+def has_packed(dataset_path: str) -> bool:
+    """True when the side-car exists AND still matches the directory's .pt files: same names in the same order, the same file
+    sizes, and an array file of the recorded length.  (create_dataset removes the side-car before it rewrites any .pt file, so a
+    side-car never outlives the files it was built from; the size check catches files replaced behind its back.)"""
+    m = _read_meta(dataset_path)
+    if m is None:
+        return False
+    names = _sample_files(dataset_path)
+    if tuple(m.get("files", ())) != names:
+        return False
+    if "sizes" in m and list(m["sizes"]) != [os.path.getsize(os.path.join(dataset_path, n)) for n in names]:
+        return False
+    want = int(m["count"]) * int(np.prod(_SAMPLE_SHAPE)) * 4
+    return os.path.getsize(os.path.join(dataset_path, PACKED_BIN)) == want and sorted(m.get("rows", range(len(names)))) == \
+        list(range(len(names)))
 
 
 class PackedAudioDataset(Dataset):
-    """Same items, same order as AudioDataset, served from the memory-mapped float32 side-car (items are float32)."""
+    """Same items, same order as AudioDataset, served from the memory-mapped float32 side-car (items are float32).  Item i (file
+    names in the reference's plain string order) lives in row `rows[i]` of the array: create_dataset streams the rows out in the
+    order it produces them (idx 0, 1, 2, ...), which is not the string order of their names."""
 
     def __init__(self, dataset_path: str) -> None:
         super().__init__()
         assert has_packed(dataset_path), f"no valid {PACKED_BIN} in \"{dataset_path}\" (musicgan_amd.audio.dataset.write_packed)"
-        with open(os.path.join(dataset_path, PACKED_META)) as fh:
-            meta = json.load(fh)
+        meta = _read_meta(dataset_path)
         self._count = int(meta["count"])
+        self._rows = np.asarray(meta.get("rows", range(self._count)), dtype=np.int64)
         self._mm = np.memmap(os.path.join(dataset_path, PACKED_BIN), dtype=np.float32, mode="r",
                              shape=(self._count,) + _SAMPLE_SHAPE)
 
@@ -100,25 +130,32 @@ class PackedAudioDataset(Dataset):
         return self._count
 
     def __getitem__(self, index: int) -> torch.Tensor:
-        return torch.from_numpy(np.array(self._mm[index]))
+        return torch.from_numpy(np.array(self._mm[self._rows[index]]))
 
     def gather(self, indices: Sequence[int], out: torch.Tensor) -> torch.Tensor:
         """out[k] = sample indices[k]; `out` is a (len(indices), 2, 512, 512) float32 host tensor (pinned for async upload)."""
         dst = out.numpy()
         for k, i in enumerate(indices):
-            dst[k] = self._mm[i]
+            dst[k] = self._mm[self._rows[i]]
         return out
 
 
 class PackedLoader:
     """Batches of a PackedAudioDataset already on the device: a background thread gathers batch b+1 into one of `depth` pinned
     buffers and queues its upload on a side stream while the caller trains on batch b.  Iterating yields float32 device tensors
-    (B, 2, 512, 512) in sampler order with the tail dropped (the reference's drop_last=True)."""
+    (B, 2, 512, 512) in sampler order with the tail dropped (the reference's drop_last=True).
+
+    Buffer life cycle (slot s = pinned[s] + dev[s]):  the consumer frees a slot with STREAM-level ordering only (its kernels on
+    dev[s] are queued, not finished), so the upload into dev[s] waits on that event on the loader stream -- and therefore may sit
+    in the queue long after the producer got the slot back.  The producer must not gather into pinned[s] while an EARLIER upload
+    out of pinned[s] is still pending: it waits on the HOST for that upload's event first (a training loop under graph replay
+    has no host synchronisation of its own and runs many steps ahead of the GPU)."""
 
     def __init__(self, dataset: PackedAudioDataset, batch_size: int, sampler, device, depth: int = 3):
         self.ds, self.bs, self.sampler, self.device, self.depth = dataset, batch_size, sampler, torch.device(device), depth
         self._pinned = [torch.empty((batch_size,) + _SAMPLE_SHAPE, dtype=torch.float32).pin_memory() for _ in range(depth)]
         self._dev = [torch.empty((batch_size,) + _SAMPLE_SHAPE, dtype=torch.float32, device=self.device) for _ in range(depth)]
+        self._uploaded: List[Optional[torch.cuda.Event]] = [None] * depth  # last upload out of pinned[s] (kept across epochs)
         self._stream = torch.cuda.Stream(device=self.device)
 
     def __len__(self) -> int:
@@ -133,19 +170,35 @@ class PackedLoader:
             free.put(s)
         stop = threading.Event()
 
+        def post(item) -> bool:  # ready.put that gives up when the consumer has left
+            while not stop.is_set():
+                try:
+                    ready.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
         def producer():
-            torch.cuda.set_device(self.device)
-            for b in range(nb):
-                slot = free.get()
-                if stop.is_set():
-                    return
-                self.ds.gather(idx[b * self.bs:(b + 1) * self.bs], self._pinned[slot])
-                with torch.cuda.stream(self._stream):
-                    self._dev[slot].copy_(self._pinned[slot], non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record(self._stream)
-                ready.put((slot, ev))
-            ready.put(None)
+            try:
+                torch.cuda.set_device(self.device)
+                for b in range(nb):
+                    slot = free.get()
+                    if stop.is_set() or slot < 0:
+                        return
+                    if self._uploaded[slot] is not None:
+                        self._uploaded[slot].synchronize()  # HOST wait: the previous upload has read pinned[slot]
+                    self.ds.gather(idx[b * self.bs:(b + 1) * self.bs], self._pinned[slot])
+                    with torch.cuda.stream(self._stream):
+                        self._dev[slot].copy_(self._pinned[slot], non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(self._stream)
+                    self._uploaded[slot] = ev
+                    if not post((slot, ev)):
+                        return
+                post(None)
+            except BaseException as e:  # noqa: BLE001  (I/O error on the memmap, HIP error: re-raised by the consumer)
+                post(e)
 
         th = threading.Thread(target=producer, daemon=True)
         th.start()
@@ -155,6 +208,8 @@ class PackedLoader:
                 item = ready.get()
                 if item is None:
                     break
+                if isinstance(item, BaseException):
+                    raise item
                 slot, ev = item
                 torch.cuda.current_stream(self.device).wait_event(ev)
                 if prev is not None:  # the consumer moved on: its buffer may be refilled once the work queued on it has run
@@ -167,4 +222,9 @@ class PackedLoader:
         finally:
             stop.set()
             free.put(-1)
+            while True:  # a producer blocked in ready.put returns as soon as there is room or it sees `stop`
+                try:
+                    ready.get_nowait()
+                except queue.Empty:
+                    break
             th.join(timeout=5)

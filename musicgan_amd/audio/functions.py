@@ -59,6 +59,14 @@ def stft_to_phase_magn(complex_values: th.Tensor, nb_vec: int = constant.N_VEC) 
     return ops.codec_fwd(c, _bark_vector(c.shape[0], dev), nb_vec)
 
 
+def stft_to_stacked_phase_magn(complex_values: th.Tensor, nb_vec: int = constant.N_VEC) -> th.Tensor:
+    """`th.stack(stft_to_phase_magn(c), dim=1)` -- the (S, 2, 512, nb_vec) tensor create_dataset.py:52-58 builds -- written once by
+    the codec kernel instead of two images and a concatenation pass."""
+    dev = complex_values.device if complex_values.is_cuda else _device()
+    c = complex_values.to(dev, th.complex64)
+    return ops.codec_fwd(c, _bark_vector(c.shape[0], dev), nb_vec, stacked=True)
+
+
 def magn_phase_to_waveform(magn_phase: th.Tensor) -> th.Tensor:
     assert len(magn_phase.size()) == 4, \
         f"(N, 2, H, W), actual = {magn_phase.size()}"

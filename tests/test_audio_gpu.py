@@ -403,3 +403,97 @@ def test_packed_loader_serves_the_same_batches_and_the_same_training_run(tmp_pat
     for f in ("gen_0.pt", "disc_0.pt"):
         a, b = torch.load(str(tmp_path / "packed" / f)), torch.load(str(tmp_path / "plain" / f))
         assert all(torch.equal(a[k], b[k]) for k in a), f
+
+
+def test_packed_loader_with_a_gpu_that_lags_behind_the_host(tmp_path):
+    """the consumer frees a loader slot with stream-level ordering only, so under graph replay (no host sync
+    per iteration) the host runs many batches ahead of the GPU and an upload can still be QUEUED when the producer gets its pinned
+    buffer back.  Every batch here has ~10 ms of GPU time queued in front of its use and the host never waits: the 13 batches must
+    arrive with their own contents (the round-2 loader served later batches' samples / torn batches here)."""
+    from musicgan_amd import audio
+    data = _tiny_dataset(tmp_path, n=26)
+    assert audio.write_packed(str(data)) == 26
+    ds = audio.PackedAudioDataset(str(data))
+    order = [int(i) for i in torch.randperm(26, generator=torch.Generator().manual_seed(3))]
+    loader = audio.PackedLoader(ds, 2, order, DEV)
+    got = torch.empty((13, 2, 2, 512, 512), device=DEV)
+    for epoch in range(2):  # the second epoch re-uses the slots (and their pending uploads) of the first
+        nb = 0
+        for b, batch in enumerate(loader):
+            torch.cuda._sleep(20_000_000)
+            got[b].copy_(batch)
+            nb += 1
+        assert nb == 13
+        torch.cuda.synchronize()
+        for b in range(13):
+            want = torch.stack([ds[i] for i in order[2 * b:2 * b + 2]])
+            assert torch.equal(got[b].cpu(), want), f"epoch {epoch}, batch {b}"
+
+
+def test_packed_loader_propagates_producer_failures_and_stops_cleanly(tmp_path):
+    """an exception in the producer thread (I/O error on the memory map, HIP error) must surface in the
+    consumer instead of leaving it blocked in `ready.get()` for ever; an early `break` must not leave the thread behind."""
+    import threading
+    from musicgan_amd import audio
+    data = _tiny_dataset(tmp_path, n=12)
+    audio.write_packed(str(data))
+    ds = audio.PackedAudioDataset(str(data))
+    real_gather, calls = ds.gather, []
+
+    def failing_gather(indices, out):
+        calls.append(list(indices))
+        if len(calls) == 3:
+            raise OSError("simulated read error on the side-car")
+        return real_gather(indices, out)
+
+    ds.gather = failing_gather
+    loader = audio.PackedLoader(ds, 2, list(range(12)), DEV)
+    seen = 0
+    with pytest.raises(OSError, match="simulated read error"):
+        for _ in loader:
+            seen += 1
+    assert seen == 2
+    ds.gather = real_gather
+    before = threading.active_count()
+    for b, _ in enumerate(audio.PackedLoader(ds, 2, list(range(12)), DEV)):
+        if b == 1:
+            break  # producer is ahead of us, possibly blocked on the full queue
+    import time
+    t0 = time.time()
+    while threading.active_count() > before and time.time() - t0 < 5:
+        time.sleep(0.05)
+    assert threading.active_count() <= before, "the loader's producer thread outlived the iteration"
+
+
+def test_create_dataset_sidecar_is_rebuilt_not_reused(tmp_path):
+    """create_dataset over a directory that already holds a side-car of OTHER data with the same file names must
+    not leave that side-car valid; the side-car it writes (streamed in idx order, indexed in file-NAME order) serves exactly the
+    .pt files, also past 10 samples where the two orders differ (magn_phase_10.pt < magn_phase_2.pt)."""
+    import musicgan_amd
+    from musicgan_amd import audio
+    from musicgan_amd.audio import wavio
+    rng = torch.Generator().manual_seed(21)
+    wav_a, wav_b, out = tmp_path / "a", tmp_path / "b", tmp_path / "data"
+    wav_a.mkdir()
+    wav_b.mkdir()
+    wavio.save(str(wav_a / "x.wav"), torch.rand(1, 256 * (512 * 12 + 40), generator=rng) - 0.5, 44100)  # 12 samples
+    wavio.save(str(wav_b / "x.wav"), torch.rand(1, 256 * (512 * 12 + 40), generator=rng) - 0.5, 44100)  # 12 other samples
+    musicgan_amd.create_dataset(str(wav_a / "*.wav"), str(out))
+    assert audio.has_packed(str(out))
+    first = audio.PackedAudioDataset(str(out))[3].clone()
+    stats = {}
+    musicgan_amd.create_dataset(str(wav_b / "*.wav"), str(out), stats=stats)
+    assert stats["files"] == 1 and stats["samples"] == 12 and stats["pt_bytes"] == 12 * 4 * 2 ** 20
+    assert audio.has_packed(str(out))
+    ref_ds, ds = audio.AudioDataset(str(out)), audio.PackedAudioDataset(str(out))
+    assert len(ds) == len(ref_ds) == 12 and not torch.equal(ds[3], first)
+    for i in range(12):
+        assert torch.equal(ds[i].double(), ref_ds[i]), i
+    # multi-rank runs write no side-car -- and must not leave the old one behind
+    os.environ["RANK"], os.environ["WORLD_SIZE"], os.environ["LOCAL_RANK"] = "0", "2", "0"
+    try:
+        musicgan_amd.create_dataset(str(wav_a / "*.wav"), str(out))
+    finally:
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            del os.environ[k]
+    assert not audio.has_packed(str(out)) and not os.path.exists(str(out / "magn_phase_f32.bin"))

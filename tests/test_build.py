@@ -20,7 +20,7 @@ HOT = [
     (r"upconv3x3_mfma", 0),
     (r"downconv4x4s2_mfma", 0),
     (r"stft1024_kernel", 0),
-    (r"codec_unwrap_delta", 0),
+    (r"codec_row_pass", 0),
 ]
 
 
