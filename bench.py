@@ -67,6 +67,7 @@ def executed_flops_per_image(level: int, rand_channels: int, batch: int) -> floa
     choice predicates of musicgan_amd.ops, evaluated for the batch each pass really sees: 3N in the fused critic step, N
     elsewhere) and 1 where it takes the direct implicit GEMM.  Static arithmetic; padding of odd channel counts not counted."""
     from musicgan_amd import ops
+    from musicgan_amd.networks.engine import gen_conv_executes_reduced
     tail = [128, 112, 96, 80, 64, 48, 32, 16]
     ins = [rand_channels] + tail[:-1]
     dch = [(16, 32), (32, 48), (48, 64), (64, 80), (80, 96), (96, 112), (112, 128), (128, 144), (144, 160)]
@@ -83,9 +84,9 @@ def executed_flops_per_image(level: int, rand_channels: int, batch: int) -> floa
         f, s = 0.0, 2
         for i in range(level + 1):
             ci, co = ins[i], tail[i]
-            f += conv(n, ci, ci, s, s, pixnorm=True)
-            sub = ops.upconv3x3_supported(co, s, n * ci * s * s)
-            f += 18.0 * ci * co * 4 * s * s * n * (W if sub else 1.0)
+            # the two PixelNorm convs of a block: the form the engine really runs (engine.gen_conv_form, shared with PackCache)
+            f += 18.0 * ci * ci * s * s * n * (W if gen_conv_executes_reduced(n, ci, ci, s, s, False) else 1.0)
+            f += 18.0 * ci * co * 4 * s * s * n * (W if gen_conv_executes_reduced(n, ci, co, s, s, True) else 1.0)
             if backward:
                 f += wgrad(n, ci, co, 2 * s, 2 * s, ups=True) + wgrad(n, ci, ci, s, s)
                 f += 18.0 * ci * co * 4 * s * s * n * (W if ops.upconv3x3_dgrad_supported(s, s, n * co * 4 * s * s, n) else 1.0)
@@ -179,23 +180,20 @@ def time_step(level: int, batch: int, rand_channels: int, device, steps: int, wa
     return e0.elapsed_time(e1) / steps
 
 
-def config2_record(device, rand_channels: int, cpu: bool):
-    """BASELINE.json configs[1]: ProGAN 2x64x64 (level 4), batch 32, one MI355X -- same step, same accounting as the headline."""
-    level, batch = 4, 32
-    # (long enough to be past the transient that follows the level-5 run: measured straight after it, the first 30 level-4
-    # steps take 5.3 ms, a run on its own -- 50 or 3 000 steps -- 4.58)
-    ms = time_step(level, batch, rand_channels, device, steps=100, warmup=60)
+def level_record(device, rand_channels: int, level: int, batch: int, steps: int, warmup: int, what: str):
+    """One more (level, batch) with the headline's step and accounting: BASELINE.json configs[0..1] and the levels a real run of
+    the reference lives at -- it trains at batch 6 (train.py:43) and spends 65 % of its scheduled FLOPs at level 6 and everything
+    after 1.4 M samples at level 7 (train.py:101-109)."""
+    ms = time_step(level, batch, rand_channels, device, steps=steps, warmup=warmup)
     ips = batch / ms * 1e3
+    side = LEVEL_SIDE[level]
     fpi, xfpi = flops_per_image(level, rand_channels), executed_flops_per_image(level, rand_channels, batch)
-    rec = {"workload": "ProGAN level 4 WGAN-GP D+G step, 2x64x64, batch 32, alpha 0.5", "value": ips, "unit": "images/s",
-           "ms_per_step": ms, "steps": 100, "warmup": 60,
-           "roofline": {"bound": "mfma", "achieved": fpi * ips / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": fpi * ips / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                        "executed_frac": xfpi * ips / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                        "basis": f"{fpi / 1e9:.2f} algorithmic / {xfpi / 1e9:.2f} executed GFLOP per image"}}
-    if cpu:
-        rec["cpu_baseline"] = cpu_baseline(level, rand_channels, batch, iters=1)
-    return rec
+    return {"workload": f"ProGAN level {level} WGAN-GP D+G step, 2x{side}x{side}, batch {batch}, alpha 0.5 ({what})",
+            "value": ips, "unit": "images/s", "ms_per_step": ms, "steps": steps, "warmup": warmup,
+            "roofline": {"bound": "mfma", "achieved": fpi * ips / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": fpi * ips / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                         "executed_frac": xfpi * ips / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                         "basis": f"{fpi / 1e9:.2f} algorithmic / {xfpi / 1e9:.2f} executed GFLOP per image"}}
 
 
 def stft_record(device, cpu: bool):
@@ -235,7 +233,8 @@ def stft_record(device, cpu: bool):
         if b >= 4 and settled >= 2:
             break
     ms_stft = timeit(lambda: ops.stft_1024(wav), 200, warm=0)
-    ms_both = timeit(lambda: audio.stft_to_phase_magn(ops.stft_1024(wav)), 10)
+    ms_both = timeit(lambda: audio.stft_to_phase_magn(ops.stft_1024(wav)), 50, warm=10)
+    c_keep = ops.stft_1024(wav)
     mp = torch.stack(audio.stft_to_phase_magn(ops.stft_1024(wav)), dim=1)[:8].contiguous()  # 8 samples = 4 096 frames
     fps = T / (ms_stft * 1e-3)
     rec = {"workload": "10 min mono 44.1 kHz synthetic file, n_fft 1024 hop 256: 103 360 frames -> 201 samples (2x512x512)",
@@ -243,14 +242,100 @@ def stft_record(device, cpu: bool):
            "stft_plus_codec": {"ms_per_file": ms_both, "frames_per_s": T / (ms_both * 1e-3),
                                "samples_per_s": ((T - 1) // 512) / (ms_both * 1e-3)},
            "roofline": {"bound": "hbm", "achieved": 5120.0 * fps / 1e9, "peak": 8000.0, "unit": "GB/s",
-                        "frac": 5120.0 * fps / 8e12, "traffic": None,
-                        "basis": "5 120 algorithmic bytes per frame x frames per launch / HIP-event launch time"}}
+                        "frac": 5120.0 * fps / 8e12, "traffic": stft_traffic(),
+                        "algorithmic_bytes": 5120.0 * T,
+                        "basis": "5 120 algorithmic bytes per frame x frames per launch / HIP-event launch time; traffic = "
+                                 "HBM bytes per launch from rocprofv3 PMC passes (tools/measure_traffic.sh stft)"}}
+    ms_codec = timeit(lambda: audio.stft_to_phase_magn(c_keep), 50, warm=10)
+    rec["codec"] = {"workload": "stft_to_phase_magn (functions.py:65-94) of that file's 512 x 103 360 bins -> 201 images",
+                    "ms_per_file": ms_codec,
+                    "roofline": {"bound": "hbm", "achieved": 16.0 * 512 * T / ms_codec / 1e6, "peak": 8000.0, "unit": "GB/s",
+                                 "frac": 16.0 * 512 * T / (ms_codec * 1e-3) / 8e12,
+                                 "basis": "16 algorithmic bytes per bin (8 B complex in, 2 x 4 B out; SURVEY 8a S2); the global "
+                                          "min/max forces a second pass, so the kernels move 32 B per bin"}}
     ms_inv = timeit(lambda: audio.functions.magn_phase_to_waveform(mp), 10)
     rec["inverse"] = {"workload": "8 samples (4 096 frames) -> waveform, mg_codec_inv (functions.py:97-139)",
                       "ms": ms_inv, "frames_per_s": 4096 / (ms_inv * 1e-3)}
     if cpu:
         rec["cpu_baseline"] = stft_cpu_baseline(wav)
     return rec
+
+
+def stft_traffic():
+    """HBM bytes one stft1024_kernel launch moves (FETCH_SIZE x 2 + WRITE_SIZE from separate rocprofv3 --pmc passes, collected
+    by `bash tools/measure_traffic.sh stft` and committed under profiles/)."""
+    tpath = os.path.join(ROOT, "profiles", "traffic_stft_kernel.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            return json.load(f).get("bytes_per_launch")
+    return None
+
+
+def create_dataset_and_train_records(device, rand_channels: int):
+    """BASELINE.json configs[4] end to end, and the real training loop on what it wrote.
+
+    `create_dataset_e2e`: musicgan_amd.create_dataset (reference create_dataset.py:34-64) on three synthetic 10-minute mono
+    44.1 kHz wav files in a scratch directory: files/s, samples/s and where the wall time goes -- the GPU part is ~0.5 ms per file,
+    the loop is bound by the 843 MB of float64 `.pt` files per file that the reference's format demands.
+    `train_loop`: musicgan_amd.train.train (reference train.py:131-272) on that dataset -- packed loader, device input transform,
+    metric window, the reference's 5 critic : 1 generator cadence -- with the growth schedule overridden so that it grows to level 5
+    in its first five iterations and stays there, batch 64; 200 iterations timed between two synchronised marks (all graphs
+    captured by the first mark).  Comparable with `secondary` (the same cadence on resident synthetic tensors)."""
+    import glob
+    import shutil
+    import tempfile
+    from musicgan_amd import create_dataset
+    from musicgan_amd.audio import wavio
+    from musicgan_amd.train import train
+    tmp = tempfile.mkdtemp(prefix="mg_bench_")
+    out = {}
+    try:
+        wav_dir, data = os.path.join(tmp, "wav"), os.path.join(tmp, "data")
+        os.mkdir(wav_dir)
+        g = torch.Generator().manual_seed(7)
+        nfiles = 3
+        for i in range(nfiles):
+            wavio.save(os.path.join(wav_dir, f"track_{i}.wav"), torch.rand(1, 44100 * 600, generator=g) - 0.5, 44100)
+        stats = {}
+        t0 = time.perf_counter()
+        create_dataset(os.path.join(wav_dir, "*.wav"), data, stats=stats)
+        wall = time.perf_counter() - t0
+        out["create_dataset_e2e"] = {
+            "workload": f"create_dataset on {nfiles} synthetic 10-minute mono 44.1 kHz float32 wav files -> "
+                        f"{stats['samples']} float64 (2,512,512) .pt files + float32 side-car, scratch dir {tmp}",
+            "files_per_s": nfiles / wall, "samples_per_s": stats["samples"] / wall, "wall_s": wall,
+            "pt_MB_per_s": stats["pt_bytes"] / wall / 1e6,
+            "split_s": {"wav_read_upload_stft": stats["load_stft_s"], "codec_d2h_submit_sidecar": stats["codec_copy_submit_s"],
+                        "of_which_waiting_for_a_free_pinned_chunk": stats["ring_wait_s"],
+                        "writer_threads": stats["writer_threads"], "writer_busy_thread_s": stats["writer_busy_s"]}}
+        shutil.rmtree(wav_dir)
+        marks = {}
+        first, last = 30, 230
+
+        def hook(it):
+            if it in (first, last):
+                torch.cuda.synchronize()
+                marks[it] = time.perf_counter()
+
+        big = 10 ** 9
+        devnull = open(os.devnull, "w")
+        stderr, stdout, sys.stderr, sys.stdout = sys.stderr, sys.stdout, devnull, devnull  # tqdm's bar and its "Next layer" lines
+        try:
+            train("bench", data, os.path.join(tmp, "out"), nb_epoch=1000, batch_size=64, max_iters=last, save_every=big,
+                  rand_channels=rand_channels, fadein_lengths=[1, 1, 1, 1, 1, 10 ** 7, big, big],
+                  train_lengths=[1, 1, 1, 1, 1, big, big], progress_hook=hook)
+        finally:
+            sys.stderr, sys.stdout = stderr, stdout
+            devnull.close()
+        dt = marks[last] - marks[first]
+        out["train_loop"] = {
+            "workload": "musicgan_amd.train.train parked at level 5 (2x128x128), batch 64: packed loader + device input transform + "
+                        "5 critic : 1 generator updates + metric window, 200 iterations between synchronised marks",
+            "iterations": last - first, "ms_per_iteration": 1e3 * dt / (last - first),
+            "images_per_s": 64 * (last - first) / dt, "dataset_samples": stats["samples"]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
 
 
 def stft_cpu_baseline(wav):
@@ -298,7 +383,7 @@ def cpu_baseline(level: int, rand_channels: int, batch: int, iters: int):
     side = LEVEL_SIDE[level]
     rng = torch.Generator().manual_seed(1234)
     x_real = torch.rand(batch, 2, side, side, generator=rng) * 2 - 1
-    best = None
+    times = []
     for it in range(iters + 1):
         z = torch.randn(batch, rand_channels, 2, 2, generator=rng)
         z2 = torch.randn(batch, rand_channels, 2, 2, generator=rng)
@@ -308,9 +393,10 @@ def cpu_baseline(level: int, rand_channels: int, batch: int, iters: int):
         O.g_step(gs, ds, z2, 0.5)
         dt = time.perf_counter() - t0
         if it > 0:
-            best = dt if best is None else min(best, dt)
-    return {"value": batch / best, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"level {level} 2x{side}x{side}, batch {batch}, min of {iters} D+G steps after 1 warm-up "
+            times.append(dt)
+    best, med = min(times), sorted(times)[len(times) // 2]
+    return {"value": batch / best, "median": batch / med, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"level {level} 2x{side}x{side}, batch {batch}, min (and median) of {iters} D+G steps after 1 warm-up "
                       f"(forward/backward only, reference-as-executed work incl. its non-detached D step)"}
 
 
@@ -323,7 +409,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--rand-channels", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the config-2 (L4 bs32) and STFT records")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the other levels' records, the STFT / codec / create_dataset records and the train-loop record")
     ap.add_argument("--cpu-batch", type=int, default=64)
     args = ap.parse_args()
 
@@ -470,8 +557,10 @@ def main():
                          "basis": f"whole step, per GPU: {fpi / 1e9:.2f} algorithmic GFLOP/image (4*Gf+12*Df) x images/s; "
                                   f"executed_frac: {xfpi / 1e9:.2f} GFLOP/image actually issued to the MFMA pipe "
                                   f"(Winograd / sub-pixel passes count 1/2.25)",
-                         "dominant_kernel": {**dom, "frac": dom["tflops"] / MFMA_F32_PEAK_TFLOPS,
-                                             "executed_frac": dom["executed_tflops"] / MFMA_F32_PEAK_TFLOPS}},
+                         # frac = FLOPs the kernel EXECUTES over the peak (a fraction of the machine); algorithmic_frac counts the
+                         # direct-convolution FLOPs it replaces (2.25x as many) and may exceed 1
+                         "dominant_kernel": {**dom, "frac": dom["executed_tflops"] / MFMA_F32_PEAK_TFLOPS,
+                                             "algorithmic_frac": dom["tflops"] / MFMA_F32_PEAK_TFLOPS}},
         }
         if cadence is not None:
             line["secondary"] = cadence
@@ -483,12 +572,20 @@ def main():
             # measurement comes before the first CPU baseline: the oracle's OpenMP workers keep spinning for a while after their
             # last parallel region and, inside the box's 16-CPU quota, starve the launching thread (the 450 STFT launches then
             # run host-bound at 0.33 ms each instead of 0.12)
-            line["l4_bs32"] = config2_record(device, args.rand_channels, cpu=False)
+            # (l4: long enough to be past the transient that follows the level-5 run -- measured straight after it, the first 30
+            # level-4 steps take 5.3 ms, a run on its own, 50 or 3 000 steps, 4.58)
+            line["l4_bs32"] = level_record(device, args.rand_channels, 4, 32, 100, 60, "BASELINE.json configs[1]")
+            line["l6_bs6"] = level_record(device, args.rand_channels, 6, 6, 40, 10, "the reference's batch, train.py:43")
+            line["l7_bs6"] = level_record(device, args.rand_channels, 7, 6, 30, 10, "the reference's batch, train.py:43")
+            line["l7_bs16"] = level_record(device, args.rand_channels, 7, 16, 20, 6, "final level, larger batch")
+            line["l3_bs8"] = level_record(device, args.rand_channels, 3, 8, 100, 30, "BASELINE.json configs[0], on the GPU")
             line["stft"] = stft_record(device, cpu=False)
+            line.update(create_dataset_and_train_records(device, args.rand_channels))
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.level, args.rand_channels, args.cpu_batch, iters=2)
+            line["cpu_baseline"] = cpu_baseline(args.level, args.rand_channels, args.cpu_batch, iters=3)
             if extra:
-                line["l4_bs32"]["cpu_baseline"] = cpu_baseline(4, args.rand_channels, 32, iters=1)
+                line["l4_bs32"]["cpu_baseline"] = cpu_baseline(4, args.rand_channels, 32, iters=3)
+                line["l3_bs8"]["cpu_baseline"] = cpu_baseline(3, args.rand_channels, 8, iters=3)
                 wav = torch.rand(44100 * 600, device=device, generator=torch.Generator(device=device).manual_seed(7)) - 0.5
                 line["stft"]["cpu_baseline"] = stft_cpu_baseline(wav)
         print(json.dumps(line), flush=True)

@@ -27,6 +27,34 @@ import torch
 from .. import _lib, ops
 
 
+def gen_conv_form(n: int, cin: int, cout: int, h: int, wd: int, ups: bool) -> str:
+    """Which kernels a generator `(Upsample ->) Conv3x3 -> LeakyReLU -> PixelNorm` (generator.py:9-40) runs as, for an input
+    (n, cin, h, wd).  The ONE place that decides it: `PackCache.conv_lrelu_pixnorm` executes the answer and bench.py's
+    executed-FLOP count reads it (returns (form, winograd?) through `gen_conv_is_wino`)."""
+    ho, wo = (2 * h, 2 * wd) if ups else (h, wd)
+    if n * ho * wo < int(os.environ.get("MG_PN_FUSE_MIN_PIXELS", "16384")):
+        return "conv+pixnorm"
+    if ups and n * h * wd < int(os.environ.get("MG_UPCONV_MIN_LOWRES_PIXELS", "32768")) and \
+            ops.wino3x3_supported(n, cout, ho, wo, cin=cin):
+        return "upsample+wino+pixnorm"
+    if not ups and cout > 64 and os.environ.get("MG_PN_WIDE_UNFUSED", "1") == "1" and \
+            ops.wino3x3_supported(n, cout, h, wd, cin=cin):
+        return "wino+pixnorm"
+    if ups and ops.upconv3x3_supported(cout, wd, n * cin * h * wd):
+        return "subpixel-fused"
+    return "fused"
+
+
+def gen_conv_executes_reduced(n: int, cin: int, cout: int, h: int, wd: int, ups: bool) -> bool:
+    """True when that convolution's forward issues 1/2.25 of the direct-convolution multiplies (Winograd or sub-pixel form)."""
+    form = gen_conv_form(n, cin, cout, h, wd, ups)
+    if form in ("upsample+wino+pixnorm", "wino+pixnorm", "subpixel-fused"):
+        return True
+    if form == "fused":
+        return ops.wino3x3_supported(n, cout, h, wd, ups=ups, pixnorm=True, cin=cin)
+    return ops.wino3x3_supported(n, cout, h, wd, ups=ups, cin=cin)  # "conv+pixnorm": PackCache.conv's own choice
+
+
 class PackCache:
     """Packed (LDS-image) conv3x3 weights.  A layout is packed when first asked for; afterwards its buffer is REFRESHED IN PLACE
     whenever the parameter's storage or version has changed -- one by one on demand, or all stale ones of the cache in a single
@@ -80,27 +108,22 @@ class PackCache:
         GFLOP).  There the convolution runs sliced over out-channels (many short workgroups) and PixelNorm as its own pass over
         the (tiny) result."""
         n, cin, h, wd = x.shape
-        ho, wo = (2 * h, 2 * wd) if ups else (h, wd)
-        if n * ho * wo >= int(os.environ.get("MG_PN_FUSE_MIN_PIXELS", "16384")):
+        form = gen_conv_form(n, cin, cout, h, wd, ups)
+        if form == "upsample+wino+pixnorm":
             # an under-filled sub-pixel launch (one 4-wave workgroup per 64 low-res pixels, all channels in a wave): the up-sampled
             # tensor written out once + the Winograd conv sliced over out-channels + PixelNorm as its own pass fill the chip
-            if ups and n * h * wd < int(os.environ.get("MG_UPCONV_MIN_LOWRES_PIXELS", "32768")) and \
-                    ops.wino3x3_supported(n, cout, ho, wo, cin=cin):
-                y = self.conv(ops.upsample2x_fwd(x), w, False, bias, cout, lrelu=True)
-                return ops.pixelnorm_fwd(y)
+            return ops.pixelnorm_fwd(self.conv(ops.upsample2x_fwd(x), w, False, bias, cout, lrelu=True))
+        if form == "wino+pixnorm":
             # more than 64 channels cannot take the Winograd kernel's fused PixelNorm (all channels of a pixel in one workgroup)
             # and the direct kernel's fused form puts 5-8 channel tiles on one wave: the Winograd conv + a PixelNorm pass is faster
-            if not ups and cout > 64 and os.environ.get("MG_PN_WIDE_UNFUSED", "1") == "1" and \
-                    ops.wino3x3_supported(n, cout, h, wd, cin=cin):
-                y = self.conv(x, w, False, bias, cout, lrelu=True)
-                return ops.pixelnorm_fwd(y)
-            if ups and ops.upconv3x3_supported(cout, wd, x.numel()):  # sub-pixel form: 2.25x fewer MFMAs
-                _, p, rn = ops.upconv3x3(x, self.get_up(w), bias, cout, lrelu=True, pixnorm=True, want_y=False)
-            else:
-                _, p, rn = self.conv(x, w, False, bias, cout, ups=ups, lrelu=True, pixnorm=True, want_y=False)
+            return ops.pixelnorm_fwd(self.conv(x, w, False, bias, cout, lrelu=True))
+        if form == "subpixel-fused":  # sub-pixel form: 2.25x fewer MFMAs
+            _, p, rn = ops.upconv3x3(x, self.get_up(w), bias, cout, lrelu=True, pixnorm=True, want_y=False)
             return p, rn
-        y = self.conv(x, w, False, bias, cout, ups=ups, lrelu=True)
-        return ops.pixelnorm_fwd(y)
+        if form == "fused":
+            _, p, rn = self.conv(x, w, False, bias, cout, ups=ups, lrelu=True, pixnorm=True, want_y=False)
+            return p, rn
+        return ops.pixelnorm_fwd(self.conv(x, w, False, bias, cout, ups=ups, lrelu=True))  # "conv+pixnorm"
 
     def get_up(self, w: torch.Tensor) -> torch.Tensor:
         """Effective sub-pixel weights of Upsample(x2) -> Conv3x3 (ops.upconv3x3)."""

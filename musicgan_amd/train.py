@@ -108,11 +108,12 @@ def _latest_state(resume_from: str) -> str:
 def train(run_name: str, input_dataset_path: str, output_dir: str, *, nb_epoch: int = 1000, batch_size: int = 6,
           num_workers: int = 6, metric_every: int = 20, max_iters: int = 0, save_every: int = 1000,
           resume_from: str = None, fadein_lengths=None, train_lengths=None, rand_channels: int = 32,
-          use_packed_loader: bool = True) -> None:
+          use_packed_loader: bool = True, progress_hook=None) -> None:
     """Reference signature plus keyword-only extensions (all defaulting to the reference's literals).  `resume_from`: a
     directory written by a previous run; its newest `train_state_k.pt` / `gen_k.pt` / `disc_k.pt` / `optim_*_k.pt` set is
     loaded (growth level, Grower counters, weights, Adam state, noise stream, position in the epoch, checkpoint numbering), after
-    which the run continues exactly as the uninterrupted one would (tests/test_audio_gpu.py::test_resume_is_bit_identical)."""
+    which the run continues exactly as the uninterrupted one would (tests/test_audio_gpu.py::test_resume_is_bit_identical).
+    `progress_hook(iter_idx)`: called at the end of every iteration (bench.py's `train_loop` record takes its time stamps there)."""
     assert isdir(input_dataset_path), f"\"{input_dataset_path}\" doesn't exist or is not a directory"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -265,6 +266,8 @@ def train(run_name: str, input_dataset_path: str, output_dir: str, *, nb_epoch: 
                     saver.tick()
             else:
                 saver.tick()
+            if progress_hook is not None:
+                progress_hook(iter_idx)
             if max_iters and iter_idx >= max_iters:
                 break
         else:

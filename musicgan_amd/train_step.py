@@ -16,7 +16,10 @@ of a fade-in, is read by the captured kernels from device memory, so one graph p
 
 With torch.distributed initialised (one process per GPU, backend "nccl" = RCCL) the per-rank gradients are summed with one
 flat all-reduce per network on a side stream, the fused Adam runs behind it on that stream, and the main stream meanwhile
-runs the next forward pass that does not depend on the updated weights (G forward of the G step; D(x_real) of the next D step).
+runs the next forward pass that does not depend on the updated weights: every update starts with a forward pass through G (the
+fake batch of a critic update, the generator update's own forward), which needs G's weights only, so the critic's exchange + Adam
+of the previous update overlap it -- eagerly by where the waits sit, under graph replay by capturing each update as two graphs
+with the wait between them.
 """
 from __future__ import annotations
 
@@ -97,25 +100,34 @@ class ProGANStepper:
         return {"disc_loss": disc_loss.detach(), "grad_pen": grad_pen.detach(),
                 "out_real_mean": out_real.detach().mean(), "out_fake_mean": out_fake.detach().mean()}
 
-    def _d_step_fused(self, x_real, alpha, z, eps, update_in_line: bool = True) -> Dict[str, torch.Tensor]:
+    def _d_step_fused(self, x_real, alpha, z, eps, update_in_line: bool = True, split=None) -> Dict[str, torch.Tensor]:
         """Same update as the module path above through `engine.disc_step_fused`: one batched critic pass over
-        [real | fake | interpolated] instead of three, one weight-gradient launch per layer."""
+        [real | fake | interpolated] instead of three, one weight-gradient launch per layer.
+        Data-parallel: the update has two halves -- the generator's forward pass for the fake batch, which needs G's weights only,
+        and the critic's passes -- so the critic's gradient exchange + Adam of the PREVIOUS update (side stream) overlap the
+        first half: eagerly the waits sit exactly there; under graph capture `split()` is called between the halves (it ends the
+        first graph and begins the second, `_graphed`)."""
         from .networks import engine
         n = x_real.shape[0]
         dev = x_real.device
         if eps is None:
             eps = torch.rand(n, 1, 1, 1, device=dev, generator=self.noise)
-        if self.dp and not update_in_line:
-            pass  # (graph replay: the caller has joined the side streams before the replay)
-        elif self.dp:
-            self.bucket_d.wait()
-            self.bucket_g.wait()
+        eager_dp = self.dp and update_in_line
+        force = torch.cuda.is_current_stream_capturing()
+        if eager_dp:
+            self.bucket_g.wait()  # G's weights final; the critic's exchange + Adam may still be running
         xcat = torch.empty((3 * n,) + tuple(x_real.shape[1:]), dtype=torch.float32, device=dev)
         xcat[:n].copy_(x_real)
-        self._refresh_packs()
+        self.gen._pack_cache.refresh(force)
         with torch.no_grad():
             engine.gen_forward(self.gen._weights(), z.contiguous(), alpha, self.gen._pack_cache, save=False,
                                out=xcat[n:2 * n])
+        if eager_dp:
+            self.bucket_d.wait()  # the critic's weights final
+        if split is not None:
+            split()
+        self.disc._pack_cache.refresh(torch.cuda.is_current_stream_capturing())
+        with torch.no_grad():
             W = self.disc._weights()
             sink = engine.GradSink(*self.bucket_d.flat_sink(W.tensors())) if self.dp else engine.GradSink()
             disc_loss, grad_pen, out, stats = engine.disc_step_fused(W, xcat[:n], xcat[n:2 * n], eps, alpha,
@@ -156,15 +168,21 @@ class ProGANStepper:
         self._update(self.bucket_g, self.gen, self.optim_gen)
         return {"gen_loss": gen_loss.detach(), "out_fake_mean": out_fake.detach().mean()}
 
-    def _g_step_fused(self, z, alpha, update_in_line: bool = True) -> Dict[str, torch.Tensor]:
-        """The generator update through `engine.gen_step_fused` (no autograd graph, no critic weight gradients)."""
+    def _g_step_fused(self, z, alpha, update_in_line: bool = True, split=None) -> Dict[str, torch.Tensor]:
+        """The generator update through `engine.gen_step_fused` (no autograd graph, no critic weight gradients).  Data-parallel:
+        G's forward runs while the critic's gradient exchange + Adam are still on the side stream; the critic's weights (and their
+        packed layouts) are only touched behind `bucket_d.wait()` -- eagerly through the waits below, under graph capture
+        through `split()` between the two graphs of the update (`_graphed`)."""
         from .networks import engine
         before_disc = None
         if self.dp and not update_in_line:
-            self._refresh_packs()  # (graph replay: the caller has joined the side streams before the replay)
+            self.gen._pack_cache.refresh(torch.cuda.is_current_stream_capturing())
+
+            def before_disc():
+                if split is not None:
+                    split()
+                self.disc._pack_cache.refresh(torch.cuda.is_current_stream_capturing())
         elif self.dp:
-            # G's forward runs while the critic's gradient exchange + Adam are still on the side stream; the critic's weights
-            # (and their packed layouts) are only touched behind bucket_d.wait()
             self.bucket_g.wait()
             self.gen._pack_cache.refresh()
 
@@ -204,9 +222,11 @@ class ProGANStepper:
         # behind it stay outside, so a replay is bracketed by "join the side streams" and "launch the exchange".
         in_line = not self.dp
 
-        def run(fade, *a, captured=False):
+        def run(fade, *a, captured=False, split=None):
             upd = in_line or not captured
-            return self._d_step_fused(a[0], fade, a[1], a[2], upd) if kind == "D" else self._g_step_fused(a[0], fade, upd)
+            if kind == "D":
+                return self._d_step_fused(a[0], fade, a[1], a[2], upd, split)
+            return self._g_step_fused(a[0], fade, upd, split)
         ent = self._graphs.get(key)
         if ent is None:
             # growth or a new batch shape: graphs of other levels (and their private memory pools, GBs at the large levels)
@@ -233,11 +253,35 @@ class ProGANStepper:
                 self._fade = torch.zeros(2, dtype=torch.float32, device=inputs[0].device)
             from .networks.engine import FadeIn
             graph = torch.cuda.CUDAGraph()
-            # thread_local: loader threads (pinned-memory staging, uploads on their own stream) keep working during the capture
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                m = run(FadeIn(alpha, dev=self._fade), *ent["inputs"], captured=True)
-                ent["names"] = list(m.keys())
-                ent["out"] = torch.stack([m[k].reshape(()) for k in ent["names"]])
+            if in_line:
+                # thread_local: loader threads (pinned-memory staging, uploads on their own stream) keep working during the capture
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    m = run(FadeIn(alpha, dev=self._fade), *ent["inputs"], captured=True)
+                    ent["names"] = list(m.keys())
+                    ent["out"] = torch.stack([m[k].reshape(()) for k in ent["names"]])
+            else:
+                # data-parallel: TWO graphs sharing one memory pool -- [generator forward] | [everything that reads the critic's
+                # weights] -- so that a replay can wait for the critic's exchange + Adam between them instead of in front
+                first, pool = torch.cuda.CUDAGraph(), torch.cuda.graph_pool_handle()
+                cap = torch.cuda.Stream(device=inputs[0].device)
+                cap.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(cap):
+                    first.capture_begin(pool, capture_error_mode="thread_local")
+                    state = {"open": first}
+
+                    def split():
+                        first.capture_end()
+                        graph.capture_begin(pool, capture_error_mode="thread_local")
+                        state["open"] = graph
+                    try:
+                        m = run(FadeIn(alpha, dev=self._fade), *ent["inputs"], captured=True, split=split)
+                        assert state["open"] is graph, "the update never reached its split point"
+                        ent["names"] = list(m.keys())
+                        ent["out"] = torch.stack([m[k].reshape(()) for k in ent["names"]])
+                    finally:
+                        state["open"].capture_end()
+                torch.cuda.current_stream().wait_stream(cap)
+                ent["first"] = first
             ent["graph"] = graph
             ent["grads"] = [(p, p.grad) for p in net.parameters() if p.grad is not None]
             opt = self.optim_disc if kind == "D" else self.optim_gen
@@ -251,9 +295,12 @@ class ProGANStepper:
             self._fade[0:1].fill_(float(alpha))
             self._fade[1:2].fill_(1.0 - float(alpha))
             self._fade_value = float(alpha)
-        if self.dp:  # both networks' weights final before the replay reads them
-            self.bucket_d.wait()
+        if self.dp:
+            # G's weights final -> [generator forward] -> the critic's weights final -> [the rest]: the critic's exchange + Adam of
+            # the previous update (RCCL + one kernel on the side stream) run under the generator's forward pass
             self.bucket_g.wait()
+            ent["first"].replay()
+            self.bucket_d.wait()
         ent["graph"].replay()
         self.gen.zero_grad()
         self.disc.zero_grad()

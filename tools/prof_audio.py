@@ -12,7 +12,6 @@ dev = torch.device("cuda", 0)
 wav = torch.rand(44100 * 600, device=dev, generator=torch.Generator(device=dev).manual_seed(7)) - 0.5
 for _ in range(iters):
     c = ops.stft_1024(wav)
-    magn, phase = audio.stft_to_phase_magn(c)
-    mp = torch.stack([magn, phase], dim=1)[:8].contiguous()
+    mp = audio.stft_to_stacked_phase_magn(c)[:8].contiguous()
     audio.functions.magn_phase_to_waveform(mp)
 torch.cuda.synchronize()

@@ -30,6 +30,10 @@ elif case == "wino":   # Winograd conv 48->64 @128 + lrelu + fused pool
 elif case == "stft":
     wav = torch.rand(44100 * 600, device=dev) - 0.5
     fn = lambda: ops.stft_1024(wav)
+elif case == "codec":
+    from musicgan_amd import audio
+    c = ops.stft_1024(torch.rand(44100 * 600, device=dev) - 0.5)
+    fn = lambda: audio.stft_to_phase_magn(c)
 else:
     raise SystemExit("unknown case")
 for _ in range(iters):
