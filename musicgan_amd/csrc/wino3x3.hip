@@ -76,7 +76,8 @@ struct WinoArgs {
 constexpr int WF_BLEND = 1 << 8;      // y = coef[0] * result + coef[1] * other
 constexpr int WF_BLEND_BWD = 1 << 9;  // y = (coef[0] * acc) * lrelu'(mi),  p = (coef[1] * acc) * lrelu'(other)
 
-// WT = tile groups (16 tiles each) per workgroup: 2 (two workgroups per CU) or 4 (one 8..12-wave workgroup per CU)
+// WT = tile groups (16 tiles each) per workgroup: 2 (two workgroups per CU), 4 (one 8..12-wave workgroup per CU) or, for layers of
+// at most 16 out-channels (WC = 1: the 16-channel tensors at 512x512 of levels 6-7), 8 (one 8-wave workgroup of 128 tiles per CU)
 template <int NIW, int WC, int WT>
 __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(const WinoArgs a) {
   constexpr int TPB = WT * 16;  // tiles per workgroup
@@ -291,7 +292,7 @@ __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(co
   __syncthreads();
   store_chunk(a.nchunk - 1);
   __syncthreads();
-  if (WT == 4 && next < nblk) block_geometry(next);  // (the 32-tile form is never launched persistent: two workgroups share a CU)
+  if (WT >= 4 && next < nblk) block_geometry(next);  // (the 32-tile form is never launched persistent: two workgroups share a CU)
   load_chunk(0);
   compute_chunk();
 
@@ -623,7 +624,7 @@ __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(co
     else if (a.flags & MG_CONV_POOL_OUT) tail(I0_{}, T_{}, T_{}, F_{}, F_{});
     else tail(I0_{}, F_{}, T_{}, F_{}, F_{});
   }
-  if (WT != 4 || next >= nblk) break;
+  if (WT < 4 || next >= nblk) break;
   item = next;
   thread_coords();
   }
@@ -719,6 +720,11 @@ int wino_run(WinoArgs& a, bool pn, hipStream_t s) {
   if (mg_cdiv(nt, 3) * 3 < best) { cfg = 3; best = mg_cdiv(nt, 3) * 3; }
   if (mg_cdiv(nt, 2) * 2 < best) { cfg = 2; best = mg_cdiv(nt, 2) * 2; }
   if (pn) cfg = nt <= 2 ? 2 : (nt == 3 ? 3 : 4);
+  // at most 16 out-channels: ONE channel tile per workgroup and 128 tiles instead of a second, all-padding channel tile
+  // (the 32 -> 16 data gradient at 512x512 spent half its MFMAs on zero filters)
+  const bool narrow = nt == 1 && !pn && getenv("MG_WINO_CFG") == nullptr && getenv("MG_WINO_WT") == nullptr &&
+                      getenv("MG_WINO_NARROW") == nullptr;  // (MG_WINO_NARROW=0: measurement switch, the two-tile forms)
+  if (narrow) cfg = 1;
   {
     const char* e = getenv("MG_WINO_CFG");  // measurement override: 2, 3 or 4 out-channel tiles per workgroup
     if (e != nullptr && !pn) {
@@ -733,6 +739,10 @@ int wino_run(WinoArgs& a, bool pn, hipStream_t s) {
   // gives every CU two or more workgroups, else 32 (two workgroups per CU).
   const int n_cu = mg_cu_count();
   int wt = ((long long)N * Ht * Wt / 64) * mg_cdiv(nt, cfg) >= 2ll * n_cu ? 4 : 2;
+  if (narrow) {
+    if ((long long)N * Ht * Wt / 128 >= 2ll * n_cu) wt = 8;
+    else cfg = 2;  // too few tiles for 128-tile workgroups: the two-tile forms as before
+  }
   {
     const char* e = getenv("MG_WINO_WT");  // measurement override
     if (e != nullptr && (atoi(e) == 2 || atoi(e) == 4)) wt = atoi(e);
@@ -752,9 +762,10 @@ int wino_run(WinoArgs& a, bool pn, hipStream_t s) {
   dim3 grid(a.blocks_x * a.blocks_y * a.blocks_n, mg_cdiv(nt, cfg));
   {  // persistent launch of the 64-tile form: one workgroup per CU, each walking its tile blocks
     const char* e = getenv("MG_WINO_PERSIST");  // measurement switch: 0 = one workgroup per tile block
-    if (wt == 4 && (e == nullptr || atoi(e) != 0) && (int)grid.x > n_cu) grid.x = n_cu;
+    if (wt >= 4 && (e == nullptr || atoi(e) != 0) && (int)grid.x > n_cu) grid.x = n_cu;
   }
   switch (cfg * 10 + wt) {
+    case 18: return launch_wino<1, 1, 8>(a, grid, s);
     case 44: return launch_wino<2, 2, 4>(a, grid, s);
     case 42: return launch_wino<2, 2, 2>(a, grid, s);
     case 34: return launch_wino<1, 3, 4>(a, grid, s);

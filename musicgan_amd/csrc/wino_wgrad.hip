@@ -15,6 +15,7 @@
 // once the tile loop is done), and a second kernel sums the 9-tap slabs in a fixed order
 // (bitwise deterministic, no float atomics).  The bias gradient rides along in the gy staging threads.
 #include <cstdlib>
+#include <type_traits>
 
 #include "mg_common.h"
 
@@ -294,6 +295,306 @@ __global__ void __launch_bounds__(512) wino_wgrad_mfma(const WwArgs a) {
   if (cb == 0 && t == 0 && chs < OT * 16 && o0 + chs < a.CoutP) a.slab_b[(size_t)split * a.CoutP + o0 + chs] = bsum;
 }
 
+// ---- narrow blocks (CT + OT <= 4 channel tiles): same algorithm and LDS layout as wino_wgrad_mfma above, re-balanced for blocks
+// whose per-chunk work (8 tiles x a few dozen channels) is far below an HBM round trip -- see the comments inside.
+// UPS: x is (N, Cin, H/2, W/2) and the convolution input is its nearest x2 up-sampling (generator.py:24-25): the 4x4 patch of tile
+// (TY, TX) is then the 3x3 low-res neighbourhood with the centre row / column doubled -- one dword per row and lane.
+template <int CT, int OT, bool UPS>
+__global__ void __launch_bounds__(512) wino_wgrad_narrow_mfma(const WwArgs a) {
+  static_assert(CT + OT <= 4, "the narrow form: at most four channel tiles in all");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = component pair
+  const int col = lane & 15, rq = lane >> 4;
+  const int cb = blockIdx.y / a.nob, ob = blockIdx.y % a.nob;
+  const int c0 = cb * CT * 16, o0 = ob * OT * 16;
+  const int split = blockIdx.x;
+  const int HW = a.H * a.W;
+  const int Ht = a.H >> 1, Wt = a.W >> 1;
+
+  // staging item of this thread: tile t of the chunk and a channel slot -- x channel c0 + xs and gy channel o0 + ys.  With up to
+  // four channel tiles in all (CT + OT <= 4: the 16/32/48-channel layers at 256x256 and 512x512, where a run of the reference
+  // spends its time) the x slots and the gy slots sit on DIFFERENT waves (x: waves 0 .. 2CT-1, gy: the next 2OT), so the two
+  // transforms run side by side instead of one after the other on the first waves while the rest wait at the barrier; wider
+  // blocks use every wave for both (slot = tid / 8).  Waves without slots skip loads, transform and LDS writes (wave-uniform).
+  constexpr int YOFF = CT * 16;
+  const int t = tid & 7, xs = tid >> 3, ys = (tid >> 3) - YOFF;
+  const int txl = t & (a.TBW - 1);
+  const int tyl = (t >> a.lgTBW) & (a.TBH - 1);
+  const int nl = t >> (a.lgTBW + a.lgTBH);
+  const bool xch = (xs < CT * 16) && (c0 + xs < a.Cin);
+  const bool ych = (ys >= 0) && (ys < OT * 16) && (o0 + ys < a.Cout);
+  const bool ledge = txl == 0, redge = txl == a.TBW - 1;
+  // (wider blocks keep wino_wgrad_mfma: every wave stages both operands, slots past the block read zeros through the bounds check;
+  // this kernel's structure costs the 48..64-channel layers of level 5 3-7 %, tools/ab_wgrad.py)
+  const bool xw = wave * 8 < CT * 16, yw = (wave * 8 >= YOFF) && (wave * 8 < YOFF + OT * 16);
+  const int HWx = UPS ? Ht * Wt : HW;
+  const int xlane = UPS ? (nl * a.Cin + c0 + xs) * HWx + tyl * Wt + txl             // low-res pixel (TY, TX)
+                        : (nl * a.Cin + c0 + xs) * HWx + (2 * tyl - 1) * a.W + 2 * txl;  // patch row 0, own pair
+  const int ylane = (nl * a.Cout + o0 + ys) * HW + (2 * tyl) * a.W + 2 * txl;
+  // LDS float offset of the item's first component pair: [cp][tile pair t>>1][swizzled channel][k-step t&1][parity]
+  const int ldst = ((t >> 1) * CH + (xs ^ ((t >> 1) << 1))) * 4 + (t & 1) * 2;
+  const int ldsty = ((t >> 1) * CH + ((ys & 63) ^ ((t >> 1) << 1))) * 4 + (t & 1) * 2;
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gy), 0, (int)a.gy_bytes, 0x00020000);
+
+  f32x4 acc[2][CT][OT];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+      for (int j = 0; j < OT; ++j) acc[p][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // Chunks in flight: a chunk is 8 tiles x (CT + OT) x 16 channels -- with one or two channel tiles that is a few hundred cycles
+  // of work, an order of magnitude less than an HBM round trip, so the loads of such a block run PD chunks ahead in PD register
+  // sets (16 registers each; measured on 16 x 32 channels at 512x512: 3 500 cycles per chunk with one set).
+  constexpr int PD = (CT * OT <= 2) ? 6 : 4;
+  struct Regs {
+    f32x2 rP[4], rG[2];
+    float rE[4];  // halo column of an edge lane (left OR right: a lane is at most one; a 1-tile-wide chunk has both outside)
+    bool bnext;   // whether the gy tile in flight counts for the bias gradient
+  };
+  Regs R[PD];
+  float bsum = 0.f;
+
+  // chunk `blk` (8 tiles): global loads into registers; tiles / rows / columns outside the image get an out-of-range offset and
+  // read back as 0.0
+  // chunks of a slab are consecutive tile blocks: the (bx, by, bn) of the next chunk to load is carried along instead of being
+  // divided out of the chunk index for every chunk (three integer divisions = ~80 scalar instructions per chunk and wave)
+  int nq = 0;  // chunks of this slab requested so far
+  int bx, by, bn;
+  {
+    const int blk = split * a.per;
+    bx = blk % a.blocks_x;
+    const int t2 = blk / a.blocks_x;
+    by = t2 % a.blocks_y;
+    bn = t2 / a.blocks_y;
+  }
+  auto load_chunk = [&](Regs& rr, auto role_) __attribute__((always_inline)) {  // the slab's next chunk (all-zero once past its end)
+    constexpr int ROLE = decltype(role_)::value;  // bit 0: this wave stages x slots, bit 1: gy slots
+    auto& rP = rr.rP; auto& rG = rr.rG; auto& rE = rr.rE; bool& bnext = rr.bnext;
+    const int blk = nq < a.per ? split * a.per + nq : a.nblk;
+    const int n = bn * a.TBN + nl, TY = by * a.TBH + tyl, TX = bx * a.TBW + txl;
+    const bool ok = (blk < a.nblk) && (n < a.N) && (TY < Ht) && (TX < Wt);
+    const int ux = UPS ? (bn * a.TBN * a.Cin) * HWx + (by * a.TBH) * Wt + bx * a.TBW
+                       : (bn * a.TBN * a.Cin) * HWx + (2 * by * a.TBH) * a.W + 2 * bx * a.TBW;
+    const int uy = (bn * a.TBN * a.Cout) * HW + (2 * by * a.TBH) * a.W + 2 * bx * a.TBW;
+    const unsigned xo = (unsigned)(xlane + ux) * 4u;
+    const bool xok = ok && xch;
+    if constexpr (!(ROLE & 1)) {
+    } else if constexpr (UPS) {
+#pragma unroll
+      for (int r3 = 0; r3 < 3; ++r3) {  // low-res rows TY-1, TY, TY+1 -> patch rows 0, (1, 2), 3
+        const bool rv = xok && (r3 == 1 || (r3 == 0 ? TY > 0 : TY < Ht - 1));
+        const unsigned o = xo + (unsigned)((r3 - 1) * Wt) * 4u;
+        const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)(rv ? o : 0x80000000u), 0, 0));
+        const unsigned oe = (rv && ledge && TX > 0) ? o - 4u : ((rv && redge && TX < Wt - 1) ? o + 4u : 0x80000000u);
+        const float ve = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)oe, 0, 0));
+        const int r = r3 == 0 ? 0 : (r3 == 1 ? 1 : 3);
+        rP[r] = f32x2{v, v};
+        rE[r] = ve;
+        if (r3 == 1) { rP[2] = f32x2{v, v}; rE[2] = ve; }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool rv = xok && (r == 1 || r == 2 || (r == 0 ? TY > 0 : TY < Ht - 1));
+        const unsigned o = xo + (unsigned)(r * a.W) * 4u;
+        rP[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrs, (int)(rv ? o : 0x80000000u), 0, 0));
+        const unsigned oe = (rv && ledge && TX > 0) ? o - 4u : ((rv && redge && TX < Wt - 1) ? o + 8u : 0x80000000u);
+        rE[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)oe, 0, 0));
+      }
+    }
+    if constexpr ((ROLE & 2) != 0) {
+      const unsigned yo = (unsigned)(ylane + uy) * 4u;
+      const bool yok = ok && ych;
+      rG[0] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(yrs, (int)(yok ? yo : 0x80000000u), 0, 0));
+      rG[1] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(yrs, (int)(yok ? yo + (unsigned)a.W * 4u : 0x80000000u), 0, 0));
+      bnext = n < a.bias_n;
+    }
+    ++nq;  // next tile block, branch-free (scalar selects)
+    ++bx;
+    const int wx = bx == a.blocks_x ? 1 : 0;
+    bx = wx ? 0 : bx;
+    by += wx;
+    const int wy = by == a.blocks_y ? 1 : 0;
+    by = wy ? 0 : by;
+    bn += wy;
+  };
+
+  // registers -> transformed operand images of one stage
+  auto store_chunk = [&](float* st, const Regs& rr, auto role_) __attribute__((always_inline)) {
+    constexpr int ROLE = decltype(role_)::value;
+    const auto& rP = rr.rP; const auto& rG = rr.rG; const auto& rE = rr.rE; const bool bnext = rr.bnext;
+    if constexpr ((ROLE & 1) != 0) {  // V = B^T d B, component slots of row i: [v0, v3 | v1, v2]  (see wino3x3.hip)
+      f32x2 E[4], P[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        P[r] = rP[r];
+        const float own_x = rP[r][0], own_y = rP[r][1];
+        const float fl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, own_y), 0x138, 0xf, 0xf, false));  // lane-1
+        const float fr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, own_x), 0x130, 0xf, 0xf, false));  // lane+1
+        E[r] = f32x2{ledge ? (a.TBW > 1 ? rE[r] : 0.f) : fl, redge ? (a.TBW > 1 ? rE[r] : 0.f) : fr};
+      }
+      // one v_pk_add_f32 per result pair, swaps and negations in the operand modifiers (hipcc builds them with v_mov / v_xor)
+      f32x2 UE[4], UP[4];
+      UE[0] = pk_sub(E[0], E[2]);  UP[0] = pk_sub(P[0], P[2]);
+      UE[1] = E[1] + E[2];         UP[1] = P[1] + P[2];
+      UE[2] = pk_sub(E[2], E[1]);  UP[2] = pk_sub(P[2], P[1]);
+      UE[3] = pk_sub(E[1], E[3]);  UP[3] = pk_sub(P[1], P[3]);
+      float* dst = st + ldst;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x2 v03, v12;
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(v03) : "v"(UE[i]), "v"(UP[i]));  // (e0 - p1, p0 - e1)
+        asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(v12) : "v"(UP[i]));             // (p0 + p1, p1 - p0)
+        *reinterpret_cast<f32x2*>(dst + (2 * i) * (4 * CH * 4)) = v03;
+        *reinterpret_cast<f32x2*>(dst + (2 * i + 1) * (4 * CH * 4)) = v12;
+      }
+    }
+    if constexpr ((ROLE & 2) != 0) {  // Y = A t A^T with A = [[1,0],[1,1],[1,-1],[0,-1]], same slot order: row i -> [y0, y3 | y1, y2]
+      const f32x2 t0 = rG[0], t1 = rG[1];
+      if (bnext) bsum += (t0[0] + t0[1]) + (t1[0] + t1[1]);
+      f32x2 R[4];
+      R[0] = t0;
+      R[1] = t0 + t1;
+      R[2] = pk_sub(t0, t1);
+      R[3] = t1;  // stands for -t1: the sign is folded into the modifiers below
+      float* dst = st + IMG + ldsty;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x2 y03, y12;
+        if (i < 3) {
+          asm("v_pk_mul_f32 %0, %1, %2 neg_hi:[1,0]" : "=v"(y03) : "v"(R[i]), "v"(f32x2{1.f, 1.f}));                               // (r0, -r1)
+          asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(y12) : "v"(R[i]));           // (r0 + r1, r0 - r1)
+        } else {
+          asm("v_pk_mul_f32 %0, %1, %2 neg_lo:[1,0]" : "=v"(y03) : "v"(R[i]), "v"(f32x2{1.f, 1.f}));                               // (-t0, t1)
+          asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[1,1] neg_hi:[1,0]" : "=v"(y12) : "v"(R[i]));           // (-t0 - t1, -t0 + t1)
+        }
+        *reinterpret_cast<f32x2*>(dst + (2 * i) * (4 * CH * 4)) = y03;
+        *reinterpret_cast<f32x2*>(dst + (2 * i + 1) * (4 * CH * 4)) = y12;
+      }
+    }
+  };
+
+  // The operand reads of a chunk are issued first (pinned by a scheduling fence), the next chunk's transform + LDS writes and
+  // the loads of the one after run while they are in flight, and the MFMAs come last: +1..3 % over reads placed directly in
+  // front of the MFMAs, where the matrix pipe waits out an LDS round trip per chunk.
+  f32x4 av[CT], bv[OT];  // {par0 k0, par1 k0, par0 k1, par1 k1}
+  auto read_operands = [&](const float* st) {
+    const float* vb = st + (wave * 4 + rq) * (CH * 4);
+    const float* yb = vb + IMG;
+#pragma unroll
+    for (int i = 0; i < CT; ++i) av[i] = *reinterpret_cast<const f32x4*>(vb + ((i * 16 + col) ^ (rq << 1)) * 4);
+#pragma unroll
+    for (int j = 0; j < OT; ++j) bv[j] = *reinterpret_cast<const f32x4*>(yb + ((j * 16 + col) ^ (rq << 1)) * 4);
+  };
+  auto mma_chunk = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+          for (int j = 0; j < OT; ++j)
+            acc[p][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][ks * 2 + p], bv[j][ks * 2 + p], acc[p][i][j], 0, 0, 0);
+  };
+
+  // pipeline: iteration q computes chunk q from stage q&1, writes chunk q+1 (registers) into the other stage and issues the
+  // loads of chunk q+2; chunks past the slab (or past the tensor) are all-zero and add nothing
+  // One copy of the tile loop per staging role, chosen ONCE per wave: inside a copy there is no control flow around the loads, so
+  // hipcc's s_waitcnt placement stays exact (vmcnt(N) for the oldest set only) and the PD sets really are in flight -- with
+  // `if (this wave stages x)` inside the loop it waited vmcnt(0)/(1) in front of every transform.
+  auto tile_loop = [&](auto role_) __attribute__((always_inline)) {
+    load_chunk(R[0], role_);
+    store_chunk(smem, R[0], role_);
+#pragma unroll
+    for (int i = 0; i < PD; ++i) load_chunk(R[i], role_);
+    __syncthreads();
+    for (int q0 = 0; q0 < a.per; q0 += PD) {  // (the last round may run up to PD-1 all-zero chunks)
+#pragma unroll
+      for (int i = 0; i < PD; ++i) {
+        const int q = q0 + i;
+        float* cur = smem + (q & 1) * STAGE;
+        float* nxt = smem + ((q + 1) & 1) * STAGE;
+        read_operands(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        store_chunk(nxt, R[i], role_);  // chunk q+1
+        load_chunk(R[i], role_);        // chunk q+1+PD takes its place
+        mma_chunk();
+        __syncthreads();
+      }
+    }
+  };
+  if (xw) tile_loop(std::integral_constant<int, 1>{});
+  else if (yw) tile_loop(std::integral_constant<int, 2>{});
+  else tile_loop(std::integral_constant<int, 0>{});
+
+  // Slab of this split: dW_split = G^T M G per (c, o), 9 planes [split][k][c][o] -- the transform is linear, so it is applied per
+  // split and the reduce kernel only sums (9/16 of the bytes, which is what the small-map layers' weight gradients cost: their
+  // slabs are larger than their inputs).  A (c, o) pair's 16 components sit in 8 different waves: they meet in LDS (the two
+  // stages are free now), 32 in-channels x 64 out-channels x 16 slots = exactly its 128 KB, in two passes over the in-channel
+  // tiles; the out-channel tile index is XOR-ed with the row group so that the four row groups of a wave hit disjoint banks.
+  float* G = smem;  // [slot 16][cc 32][o 64]
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    __syncthreads();  // MFMA loop / previous pass done with the buffer
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = 2 * h + ii;
+        if (i < CT) {
+#pragma unroll
+          for (int j = 0; j < OT; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              G[((2 * wave + p) * 32 + ii * 16 + rq * 4 + g) * 64 + ((j ^ rq) * 16 + col)] = acc[p][i][j][g];
+        }
+      }
+    __syncthreads();
+    constexpr int SL[4] = {0, 2, 3, 1};  // slot of column nu within a row of components
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const int cc = (tid >> 6) + 8 * k4;  // wave-uniform row of the half block
+      const int ol = tid & 63;
+      const int i = 2 * h + (cc >> 4);
+      const int c = c0 + i * 16 + (cc & 15), o = o0 + ol;
+      if (i < CT && ol < OT * 16 && c < a.CinP && o < a.CoutP) {
+        const int osw = ((ol >> 4) ^ ((cc >> 2) & 3)) * 16 + (ol & 15);
+        float M[4][4];
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+          for (int nu = 0; nu < 4; ++nu) M[xi][nu] = G[((4 * xi + SL[nu]) * 32 + cc) * 64 + osw];
+        float hh[3][4];  // G^T M
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+          hh[0][nu] = M[0][nu] + 0.5f * (M[1][nu] + M[2][nu]);
+          hh[1][nu] = 0.5f * (M[1][nu] - M[2][nu]);
+          hh[2][nu] = 0.5f * (M[1][nu] + M[2][nu]) + M[3][nu];
+        }
+        float* sl = a.slab + (size_t)split * 9 * a.CinP * a.CoutP + (size_t)c * a.CoutP + o;
+        const size_t plane = (size_t)a.CinP * a.CoutP;
+#pragma unroll
+        for (int aa = 0; aa < 3; ++aa) {
+          sl[(size_t)(aa * 3 + 0) * plane] = hh[aa][0] + 0.5f * (hh[aa][1] + hh[aa][2]);
+          sl[(size_t)(aa * 3 + 1) * plane] = 0.5f * (hh[aa][1] - hh[aa][2]);
+          sl[(size_t)(aa * 3 + 2) * plane] = 0.5f * (hh[aa][1] + hh[aa][2]) + hh[aa][3];
+        }
+      }
+    }
+  }
+  // bias gradient: the 8 tile lanes of a channel slot, then one value per (split, out-channel); in-channel block 0 only
+  bsum += __shfl_xor(bsum, 1);
+  bsum += __shfl_xor(bsum, 2);
+  bsum += __shfl_xor(bsum, 4);
+  if (cb == 0 && t == 0 && ys >= 0 && ys < OT * 16 && o0 + ys < a.CoutP) a.slab_b[(size_t)split * a.CoutP + o0 + ys] = bsum;
+}
+
 // Sum the split-K slabs (already transformed to the 9 taps by the partial kernel) in a fixed order.  Block = 64 consecutive (c, o)
 // pairs x 8 split-lanes (a thread sums every 8th split of the 9 taps: enough loads in flight for what is a pure latency problem),
 // LDS-combined as a fixed tree => deterministic.
@@ -378,8 +679,8 @@ void plan_ww(int N, int Cin, int Cout, int H, int W, WwPlan& pl) {
   const int ct = mg_cdiv(Cin, 16), ot = mg_cdiv(Cout, 16);
   pl.ncb = blocks_of(ct);
   a.nob = blocks_of(ot);
-  pl.CT = mg_cdiv(ct, pl.ncb) <= 3 ? 3 : 4;
-  pl.OT = mg_cdiv(ot, a.nob) <= 3 ? 3 : 4;
+  pl.CT = mg_cdiv(ct, pl.ncb);  // 1..4 channel tiles per block: the kernel is instantiated for each (no MFMAs on padding tiles)
+  pl.OT = mg_cdiv(ot, a.nob);
   a.CinP = ct * 16; a.CoutP = ot * 16;
   const int n_cu = mg_cu_count();
   const int ny = pl.ncb * a.nob;
@@ -394,13 +695,45 @@ template <int CT, int OT, bool UPS>
 int launch_ww(const WwArgs& a, dim3 grid, hipStream_t s) {
   constexpr size_t lds = (size_t)2 * STAGE * sizeof(float);
   static MgPerDevice once;  // the LDS limit is a per-device function attribute
-  if (mg_first_use_on_device(once)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_wgrad_mfma<CT, OT, UPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
+  if constexpr (CT + OT <= 4) {
+    if (mg_first_use_on_device(once)) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_wgrad_narrow_mfma<CT, OT, UPS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    hipLaunchKernelGGL((wino_wgrad_narrow_mfma<CT, OT, UPS>), grid, dim3(512), lds, s, a);
+  } else {
+    if (mg_first_use_on_device(once)) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_wgrad_mfma<CT, OT, UPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024);
+    }
+    hipLaunchKernelGGL((wino_wgrad_mfma<CT, OT, UPS>), grid, dim3(512), lds, s, a);
   }
-  hipLaunchKernelGGL((wino_wgrad_mfma<CT, OT, UPS>), grid, dim3(512), lds, s, a);
   MG_CHECK_LAUNCH("mg_wino3x3_wgrad");
   return MG_OK;
+}
+
+template <bool UPS>
+int dispatch_ww(int CT, int OT, const WwArgs& a, dim3 grid, hipStream_t s) {
+  switch (CT * 10 + OT) {
+    case 11: return launch_ww<1, 1, UPS>(a, grid, s);
+    case 12: return launch_ww<1, 2, UPS>(a, grid, s);
+    case 13: return launch_ww<1, 3, UPS>(a, grid, s);
+    case 14: return launch_ww<1, 4, UPS>(a, grid, s);
+    case 21: return launch_ww<2, 1, UPS>(a, grid, s);
+    case 22: return launch_ww<2, 2, UPS>(a, grid, s);
+    case 23: return launch_ww<2, 3, UPS>(a, grid, s);
+    case 24: return launch_ww<2, 4, UPS>(a, grid, s);
+    case 31: return launch_ww<3, 1, UPS>(a, grid, s);
+    case 32: return launch_ww<3, 2, UPS>(a, grid, s);
+    case 33: return launch_ww<3, 3, UPS>(a, grid, s);
+    case 34: return launch_ww<3, 4, UPS>(a, grid, s);
+    case 41: return launch_ww<4, 1, UPS>(a, grid, s);
+    case 42: return launch_ww<4, 2, UPS>(a, grid, s);
+    case 43: return launch_ww<4, 3, UPS>(a, grid, s);
+    case 44: return launch_ww<4, 4, UPS>(a, grid, s);
+  }
+  mg_set_error("mg_wino3x3_wgrad: internal tile error (CT=%d, OT=%d)", CT, OT);
+  return MG_EINVAL;
 }
 
 }  // namespace
@@ -435,18 +768,7 @@ extern "C" int mg_wino3x3_wgrad_partial(const float* x, const float* gy, float* 
   a.gy_bytes = (unsigned)((size_t)N * Cout * H * W * 4);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(pl.nsplit, pl.ncb * a.nob);
-  int rc;
-  if (ups) {
-    if (pl.CT == 3 && pl.OT == 3) rc = launch_ww<3, 3, true>(a, grid, s);
-    else if (pl.CT == 3) rc = launch_ww<3, 4, true>(a, grid, s);
-    else if (pl.OT == 3) rc = launch_ww<4, 3, true>(a, grid, s);
-    else rc = launch_ww<4, 4, true>(a, grid, s);
-  } else {
-    if (pl.CT == 3 && pl.OT == 3) rc = launch_ww<3, 3, false>(a, grid, s);
-    else if (pl.CT == 3) rc = launch_ww<3, 4, false>(a, grid, s);
-    else if (pl.OT == 3) rc = launch_ww<4, 3, false>(a, grid, s);
-    else rc = launch_ww<4, 4, false>(a, grid, s);
-  }
+  const int rc = ups ? dispatch_ww<true>(pl.CT, pl.OT, a, grid, s) : dispatch_ww<false>(pl.CT, pl.OT, a, grid, s);
   if (rc != MG_OK) return rc;
   job->slab = a.slab; job->slab_b = a.slab_b; job->gw = gw; job->gb = gb;
   job->nsplit = pl.nsplit; job->Cout = Cout; job->Cin = Cin; job->CoutP = a.CoutP; job->CinP = a.CinP; job->accumulate = accumulate;

@@ -26,6 +26,14 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
         self.grad_scale = 1.0  # multiplied into every gradient inside the kernel (data-parallel averaging)
+        self._state_epoch = 0  # bumped whenever the state tensors are replaced (load_state_dict)
+
+    def capture_signature(self) -> tuple:
+        """Everything a captured HIP graph of `step()` has baked in besides the parameters themselves: the hyper-parameters travel
+        as launch scalars and the moment / step-counter tensors by address.  ProGANStepper keys its graphs on this, so a changed
+        `param_group['lr']` (a scheduler) or a `load_state_dict` leads to a fresh capture instead of being silently ignored."""
+        return (self._state_epoch, float(self.grad_scale),
+                tuple((float(g["lr"]), tuple(float(b) for b in g["betas"]), float(g["eps"])) for g in self.param_groups))
 
     def _init_state(self, p: torch.Tensor) -> dict:
         st = self.state[p]
@@ -90,6 +98,7 @@ class FusedAdam(torch.optim.Optimizer):
 
     def load_state_dict(self, state_dict) -> None:
         super().load_state_dict(state_dict)
+        self._state_epoch += 1  # new exp_avg / exp_avg_sq / step_dev tensors: graphs holding the old addresses are stale
         for p, st in self.state.items():
             st["step"] = torch.as_tensor(st["step"]).detach().to("cpu", torch.float32).reshape(())
             st["step_dev"] = torch.full((), int(st["step"]), dtype=torch.int32, device=p.device)

@@ -216,7 +216,9 @@ class ProGANStepper:
 
     def _graphed(self, kind: str, inputs, alpha: float) -> Dict[str, torch.Tensor]:
         net, other = (self.disc, self.gen) if kind == "D" else (self.gen, self.disc)
-        key = (kind, self.gen.curr_layer, tuple(tuple(t.shape) for t in inputs), tuple(id(p) for p in net.parameters()))
+        opt_sig = (self.optim_disc if kind == "D" else self.optim_gen)
+        opt_sig = opt_sig.capture_signature() if hasattr(opt_sig, "capture_signature") else ()
+        key = (kind, self.gen.curr_layer, tuple(tuple(t.shape) for t in inputs), tuple(id(p) for p in net.parameters()), opt_sig)
 
         # Data-parallel: the graph ends with the gradients in the bucket's flat buffer; the exchange (RCCL, side stream) and Adam
         # behind it stay outside, so a replay is bracketed by "join the side streams" and "launch the exchange".
@@ -238,57 +240,24 @@ class ProGANStepper:
             ent = self._graphs[key] = {"calls": 0}
         if "graph" not in ent:
             ent["calls"] += 1
-            if ent["calls"] <= self._WARM_CALLS:
+            if ent["calls"] <= self._WARM_CALLS or ent.get("eager"):
                 return run(alpha, *inputs)
-            # capture: static copies of the inputs, every weight form re-packed inside the graph (caches emptied first), the
-            # gradients and the four scalars the caller reads live in the graph's pool
-            ent["inputs"] = [t.detach().clone().contiguous() for t in inputs]
-            if self.dp:
-                self.finish()
-            net.zero_grad()
-            other.zero_grad()
-            torch.cuda.synchronize()
-            # the fade-in coefficients live in device memory inside the graph: alpha changes every iteration of a fade-in
-            if self._fade is None:
-                self._fade = torch.zeros(2, dtype=torch.float32, device=inputs[0].device)
-            from .networks.engine import FadeIn
-            graph = torch.cuda.CUDAGraph()
-            if in_line:
-                # thread_local: loader threads (pinned-memory staging, uploads on their own stream) keep working during the capture
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    m = run(FadeIn(alpha, dev=self._fade), *ent["inputs"], captured=True)
-                    ent["names"] = list(m.keys())
-                    ent["out"] = torch.stack([m[k].reshape(()) for k in ent["names"]])
-            else:
-                # data-parallel: TWO graphs sharing one memory pool -- [generator forward] | [everything that reads the critic's
-                # weights] -- so that a replay can wait for the critic's exchange + Adam between them instead of in front
-                first, pool = torch.cuda.CUDAGraph(), torch.cuda.graph_pool_handle()
-                cap = torch.cuda.Stream(device=inputs[0].device)
-                cap.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(cap):
-                    first.capture_begin(pool, capture_error_mode="thread_local")
-                    state = {"open": first}
-
-                    def split():
-                        first.capture_end()
-                        graph.capture_begin(pool, capture_error_mode="thread_local")
-                        state["open"] = graph
-                    try:
-                        m = run(FadeIn(alpha, dev=self._fade), *ent["inputs"], captured=True, split=split)
-                        assert state["open"] is graph, "the update never reached its split point"
-                        ent["names"] = list(m.keys())
-                        ent["out"] = torch.stack([m[k].reshape(()) for k in ent["names"]])
-                    finally:
-                        state["open"].capture_end()
-                torch.cuda.current_stream().wait_stream(cap)
-                ent["first"] = first
-            ent["graph"] = graph
-            ent["grads"] = [(p, p.grad) for p in net.parameters() if p.grad is not None]
             opt = self.optim_disc if kind == "D" else self.optim_gen
-            if in_line:
-                for p, _ in ent["grads"]:  # the captured optimizer step advanced the host mirrors, but nothing ran yet
-                    opt.state[p]["step"] -= 1
-            # the captured run itself did not execute: fall through to the first replay with the caller's inputs
+            mirrors = [(st, st["step"].clone()) for st in opt.state.values() if "step" in st]
+            try:
+                self._capture(ent, kind, net, other, inputs, alpha, in_line, run)
+            except (RuntimeError, torch.cuda.OutOfMemoryError) as e:
+                # e.g. the graph's private activation pool does not fit next to the other update's: run this update eagerly
+                # from now on rather than fail the training run (the eager path is the same kernels, launched one by one)
+                import warnings
+                warnings.warn(f"HIP-graph capture of the {kind} update failed ({e}); it runs eagerly from here on")
+                for k in ("graph", "first", "inputs", "out", "grads", "names"):
+                    ent.pop(k, None)
+                ent["eager"] = True
+                torch.cuda.synchronize()
+                for st, v in mirrors:  # a captured-but-never-run optimizer step may have advanced the host step mirrors
+                    st["step"].copy_(v)
+                return run(alpha, *inputs)
         for dst, src in zip(ent["inputs"], inputs):
             dst.copy_(src)
         if self._fade_value != float(alpha):
@@ -312,6 +281,57 @@ class ProGANStepper:
             self._update(self.bucket_d if kind == "D" else self.bucket_g, net, self.optim_disc if kind == "D" else self.optim_gen)
         out = ent["out"].clone()
         return {k: out[i] for i, k in enumerate(ent["names"])}
+
+    def _capture(self, ent, kind, net, other, inputs, alpha, in_line, run) -> None:
+        # capture: static copies of the inputs, every weight form re-packed inside the graph (caches emptied first), the
+        # gradients and the four scalars the caller reads live in the graph's pool
+        ent["inputs"] = [t.detach().clone().contiguous() for t in inputs]
+        if self.dp:
+            self.finish()
+        net.zero_grad()
+        other.zero_grad()
+        torch.cuda.synchronize()
+        # the fade-in coefficients live in device memory inside the graph: alpha changes every iteration of a fade-in
+        if self._fade is None:
+            self._fade = torch.zeros(2, dtype=torch.float32, device=inputs[0].device)
+        from .networks.engine import FadeIn
+        graph = torch.cuda.CUDAGraph()
+        if in_line:
+            # thread_local: loader threads (pinned-memory staging, uploads on their own stream) keep working during the capture
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                m = run(FadeIn(alpha, dev=self._fade), *ent["inputs"], captured=True)
+                ent["names"] = list(m.keys())
+                ent["out"] = torch.stack([m[k].reshape(()) for k in ent["names"]])
+        else:
+            # data-parallel: TWO graphs sharing one memory pool -- [generator forward] | [everything that reads the critic's
+            # weights] -- so that a replay can wait for the critic's exchange + Adam between them instead of in front
+            first, pool = torch.cuda.CUDAGraph(), torch.cuda.graph_pool_handle()
+            cap = torch.cuda.Stream(device=inputs[0].device)
+            cap.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cap):
+                first.capture_begin(pool, capture_error_mode="thread_local")
+                state = {"open": first}
+
+                def split():
+                    first.capture_end()
+                    graph.capture_begin(pool, capture_error_mode="thread_local")
+                    state["open"] = graph
+                try:
+                    m = run(FadeIn(alpha, dev=self._fade), *ent["inputs"], captured=True, split=split)
+                    assert state["open"] is graph, "the update never reached its split point"
+                    ent["names"] = list(m.keys())
+                    ent["out"] = torch.stack([m[k].reshape(()) for k in ent["names"]])
+                finally:
+                    state["open"].capture_end()
+            torch.cuda.current_stream().wait_stream(cap)
+            ent["first"] = first
+        ent["graph"] = graph
+        ent["grads"] = [(p, p.grad) for p in net.parameters() if p.grad is not None]
+        opt = self.optim_disc if kind == "D" else self.optim_gen
+        if in_line:
+            for p, _ in ent["grads"]:  # the captured optimizer step advanced the host mirrors, but nothing ran yet
+                opt.state[p]["step"] -= 1
+        # the captured run itself did not execute: fall through to the first replay with the caller's inputs
 
     def finish(self) -> None:
         """Join the side streams (call before reading weights / checkpointing)."""

@@ -279,3 +279,64 @@ def test_graph_replay_is_bit_identical_to_eager_updates(monkeypatch):
     assert s_graph.keys() == s_eager.keys()
     for k in s_graph:
         assert torch.equal(s_graph[k], s_eager[k]), k
+
+
+def test_captured_graphs_follow_the_optimizer(monkeypatch):
+    """lr / betas / eps travel into a captured Adam launch as scalars and the moment tensors by address, so a graph
+    must not outlive a change of either.  (i) lr set to 0 in every param group after the critic graph exists: the following
+    updates (two eager ones, a fresh capture, replays) must leave every critic weight bit-identical -- the round-2 stepper kept
+    replaying the lr = 1e-3 graph.  (ii) `load_state_dict` replaces the moment tensors: the next updates must equal an eager
+    stepper's that loaded the same state, bit for bit."""
+    import bench
+    from musicgan_amd.optim import FusedAdam
+    from musicgan_amd.train_step import ProGANStepper
+    monkeypatch.setenv("MG_GRAPHS", "1")
+    gen, disc = bench.build_nets(2, 16, DEV)
+    og = FusedAdam(gen.parameters(), lr=LR, betas=BETAS)
+    od = FusedAdam(disc.parameters(), lr=LR, betas=BETAS)
+    st = ProGANStepper(gen, disc, og, od, 16)
+    rng = torch.Generator(device=DEV).manual_seed(4)
+
+    def d_step(stepper):
+        x = torch.rand(4, 2, 16, 16, device=DEV, generator=rng) * 2 - 1
+        z = torch.randn(4, 16, 2, 2, device=DEV, generator=rng)
+        eps = torch.rand(4, 1, 1, 1, device=DEV, generator=rng)
+        return stepper.d_step(x, 0.7, z=z, eps=eps)
+
+    for _ in range(4):
+        d_step(st)
+    assert sum("graph" in e for e in st._graphs.values()) == 1
+    frozen = {k: p.detach().clone() for k, p in disc.named_parameters()}
+    for group in od.param_groups:
+        group["lr"] = 0.0
+    for _ in range(5):
+        d_step(st)
+    torch.cuda.synchronize()
+    assert all(torch.equal(p, frozen[k]) for k, p in disc.named_parameters()), "a stale graph kept training with the old lr"
+    assert sum("graph" in e for e in st._graphs.values()) == 2  # the lr = 0 signature has its own graph
+    # (ii) load_state_dict
+    for group in od.param_groups:
+        group["lr"] = LR
+    sd = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in od.state_dict().items()}
+    import copy
+    sd = copy.deepcopy(od.state_dict())
+    weights = copy.deepcopy(disc.state_dict())
+    od.load_state_dict(copy.deepcopy(sd))
+    rng_state = rng.get_state()
+    for _ in range(4):
+        d_step(st)
+    st.finish()
+    got = {k: p.detach().clone() for k, p in disc.named_parameters()}
+    # the same four updates on an eager stepper from the same weights / optimizer state / inputs
+    monkeypatch.setenv("MG_GRAPHS", "0")
+    disc.load_state_dict(weights)
+    od2 = FusedAdam(disc.parameters(), lr=LR, betas=BETAS)
+    od2.load_state_dict(copy.deepcopy(sd))
+    st2 = ProGANStepper(gen, disc, og, od2, 16)
+    assert not st2.use_graphs
+    rng.set_state(rng_state)
+    for _ in range(4):
+        d_step(st2)
+    torch.cuda.synchronize()
+    for k, p in disc.named_parameters():
+        assert torch.equal(p, got[k]), k

@@ -70,5 +70,5 @@ for (ph, name, shapes, flags), (cnt, ms) in records.items():
     tot[ph] += ms / reps
 print(f"level {level} batch {batch}: per-call sum D step {tot['D']:.3f} ms, G step {tot['G']:.3f} ms (each call synchronised)")
 rows = sorted(records.items(), key=lambda kv: -kv[1][1])
-for (ph, name, shapes, flags), (cnt, ms) in rows[:70]:
+for (ph, name, shapes, flags), (cnt, ms) in rows[:int(sys.argv[4]) if len(sys.argv) > 4 else 70]:
     print(f"{ph} {name:22s} {shapes:34s} {flags:32s} calls/step {cnt / reps:5.1f}  ms/step {ms / reps:7.3f}  us/call {1e3 * ms / cnt:7.1f}")

@@ -30,6 +30,15 @@ elif case == "wino":   # Winograd conv 48->64 @128 + lrelu + fused pool
 elif case == "stft":
     wav = torch.rand(44100 * 600, device=dev) - 0.5
     fn = lambda: ops.stft_1024(wav)
+elif case == "ww16":   # level-7 critic, first conv: weight gradient 16 x 32 channels @512x512 over 3N = 18 images
+    x = R(18, 16, 512, 512); gy = R(18, 32, 512, 512); gw = torch.empty(32, 16, 3, 3, device=dev); gb = torch.empty(32, device=dev)
+    fn = lambda: ops.conv3x3_wgrad(x, gy, gw, gb)
+elif case == "dg16":   # level-7 critic, first conv: data gradient 32 -> 16 channels @512x512 over 18 images, LeakyReLU mask
+    x = R(18, 32, 512, 512); up = ops.pack_wino3x3(R(16, 32, 3, 3) * 0.05, False); aux = R(18, 16, 512, 512)
+    fn = lambda: ops.conv3x3(x, None, None, 16, mask_aux=aux, wino=up)
+elif case == "fw16":   # level-7 critic, first conv forward: 16 -> 32 @512x512 + lrelu + pool over 18 images
+    x = R(18, 16, 512, 512); up = ops.pack_wino3x3(R(32, 16, 3, 3) * 0.05, False); b = R(32)
+    fn = lambda: ops.conv3x3(x, None, b, 32, lrelu=True, pool=True, wino=up)
 elif case == "codec":
     from musicgan_amd import audio
     c = ops.stft_1024(torch.rand(44100 * 600, device=dev) - 0.5)
