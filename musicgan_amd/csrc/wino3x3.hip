@@ -76,8 +76,8 @@ struct WinoArgs {
 constexpr int WF_BLEND = 1 << 8;      // y = coef[0] * result + coef[1] * other
 constexpr int WF_BLEND_BWD = 1 << 9;  // y = (coef[0] * acc) * lrelu'(mi),  p = (coef[1] * acc) * lrelu'(other)
 
-// WT = tile groups (16 tiles each) per workgroup: 2 (two workgroups per CU), 4 (one 8..12-wave workgroup per CU) or, for layers of
-// at most 16 out-channels (WC = 1: the 16-channel tensors at 512x512 of levels 6-7), 8 (one 8-wave workgroup of 128 tiles per CU)
+// WT = tile groups (16 tiles each) per workgroup: 2 (several workgroups per CU) or 4 (one 8..12-wave workgroup per CU); layers of
+// at most 16 out-channels take WC = 1 (no all-padding second channel tile) with WT = 2 (4 and 8: measurement variants)
 template <int NIW, int WC, int WT>
 __global__ void __launch_bounds__(64 * WT * WC, WT == 2 ? 2 : 1) wino3x3_mfma(const WinoArgs a) {
   constexpr int TPB = WT * 16;  // tiles per workgroup
@@ -740,9 +740,18 @@ int wino_run(WinoArgs& a, bool pn, hipStream_t s) {
   const int n_cu = mg_cu_count();
   int wt = ((long long)N * Ht * Wt / 64) * mg_cdiv(nt, cfg) >= 2ll * n_cu ? 4 : 2;
   if (narrow) {
-    if ((long long)N * Ht * Wt / 128 >= 2ll * n_cu) wt = 8;
-    else cfg = 2;  // too few tiles for 128-tile workgroups: the two-tile forms as before
+    // 32 tiles per two-wave workgroup, ~6 of them per CU: with 16 out-channels a block is a few hundred cycles of MFMAs between
+    // memory round trips, and occupancy hides those where one 128-tile workgroup per CU (the first form of this variant) waited:
+    // 32->16@512, 18 images: 0.70 (two-tile form) -> 0.49 (128 tiles) -> 0.40 ms
+    wt = 2;
+    const char* e = getenv("MG_WINO_NARROW_WT");  // measurement override: 2, 4 or 8 tile groups per workgroup
+    if (e != nullptr && (atoi(e) == 4 || atoi(e) == 8)) wt = atoi(e);
+    if (wt == 8 && (long long)N * Ht * Wt / 128 < 2ll * n_cu) wt = 2;
   }
+  // two out-channel tiles (<= 32 channels): few MFMAs per staged item and per epilogue, so a block is mostly memory latency and
+  // vector work -- four-wave workgroups, several per CU, overlap that where one eight-wave workgroup per CU waits (measured
+  // 11-16 % on 16->32@512, 32->32@256, 48->32@256; the opposite of the 48- and 64-channel tilings, tools/bench_l67.py)
+  if (cfg == 2 && !narrow && !pn && getenv("MG_WINO_WT") == nullptr && getenv("MG_WINO_CFG") == nullptr) wt = 2;
   {
     const char* e = getenv("MG_WINO_WT");  // measurement override
     if (e != nullptr && (atoi(e) == 2 || atoi(e) == 4)) wt = atoi(e);
@@ -766,6 +775,8 @@ int wino_run(WinoArgs& a, bool pn, hipStream_t s) {
   }
   switch (cfg * 10 + wt) {
     case 18: return launch_wino<1, 1, 8>(a, grid, s);
+    case 14: return launch_wino<1, 1, 4>(a, grid, s);
+    case 12: return launch_wino<1, 1, 2>(a, grid, s);
     case 44: return launch_wino<2, 2, 4>(a, grid, s);
     case 42: return launch_wino<2, 2, 2>(a, grid, s);
     case 34: return launch_wino<1, 3, 4>(a, grid, s);

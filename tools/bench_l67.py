@@ -31,6 +31,16 @@ def conv_case(name, n, ci, co, h, mask=False, pool=False):
         else: os.environ["MG_WINO_NARROW"] = env
         res.append(timeit(lambda: ops.conv3x3(x, None, b, co, wino=up, **kw)))
     os.environ.pop("MG_WINO_NARROW", None)
+    os.environ["MG_WINO_WT"] = "4"
+    w2 = timeit(lambda: ops.conv3x3(x, None, b, co, wino=up, **kw))
+    os.environ.pop("MG_WINO_WT")
+    name = f"{name} [64-tile 1/CU {w2*1e3:.1f}]"
+    if co <= 16:
+        for v in ("2", "4"):
+            os.environ["MG_WINO_NARROW_WT"] = v
+            wv = timeit(lambda: ops.conv3x3(x, None, b, co, wino=up, **kw))
+            name += f" [narrow wt{v} {wv*1e3:.1f}]"
+        os.environ.pop("MG_WINO_NARROW_WT")
     md = timeit(lambda: ops.conv3x3(x, wp, b, co, **kw))
     print(f"{name:44s} two-tile {res[0]*1e3:8.1f} us  product {res[1]*1e3:8.1f} us  direct {md*1e3:8.1f} us | alg {fl/res[1]/1e9:6.1f} TF/s, "
           f"HBM floor {hbm/6e12*1e6:6.1f} us", flush=True)
