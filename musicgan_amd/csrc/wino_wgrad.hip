@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(512) wino_wgrad_mfma(const WwArgs a) {
 // UPS: x is (N, Cin, H/2, W/2) and the convolution input is its nearest x2 up-sampling (generator.py:24-25): the 4x4 patch of tile
 // (TY, TX) is then the 3x3 low-res neighbourhood with the centre row / column doubled -- one dword per row and lane.
 template <int CT, int OT, bool UPS>
-__global__ void __launch_bounds__(512) wino_wgrad_narrow_mfma(const WwArgs a) {
+__global__ void __launch_bounds__(512, 4) wino_wgrad_narrow_mfma(const WwArgs a) {
   static_assert(CT + OT <= 4, "the narrow form: at most four channel tiles in all");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -334,7 +334,9 @@ __global__ void __launch_bounds__(512) wino_wgrad_narrow_mfma(const WwArgs a) {
   const int ylane = (nl * a.Cout + o0 + ys) * HW + (2 * tyl) * a.W + 2 * txl;
   // LDS float offset of the item's first component pair: [cp][tile pair t>>1][swizzled channel][k-step t&1][parity]
   const int ldst = ((t >> 1) * CH + (xs ^ ((t >> 1) << 1))) * 4 + (t & 1) * 2;
-  const int ldsty = ((t >> 1) * CH + ((ys & 63) ^ ((t >> 1) << 1))) * 4 + (t & 1) * 2;
+  // ONE 64-slot operand image per stage holds both operands -- x in slots 0 .. 16CT-1, gy behind them (CT + OT <= 4) -- so a
+  // stage is 32 KB, the workgroup 64 KB, and TWO workgroups share a CU: with blocks this thin a workgroup spends most of a chunk
+  // waiting (barrier, LDS and memory round trips), and the second one fills those gaps
 
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gy), 0, (int)a.gy_bytes, 0x00020000);
@@ -350,7 +352,7 @@ __global__ void __launch_bounds__(512) wino_wgrad_narrow_mfma(const WwArgs a) {
   // Chunks in flight: a chunk is 8 tiles x (CT + OT) x 16 channels -- with one or two channel tiles that is a few hundred cycles
   // of work, an order of magnitude less than an HBM round trip, so the loads of such a block run PD chunks ahead in PD register
   // sets (16 registers each; measured on 16 x 32 channels at 512x512: 3 500 cycles per chunk with one set).
-  constexpr int PD = (CT * OT <= 2) ? 6 : 4;
+  constexpr int PD = CT * OT <= 1 ? 6 : (CT * OT <= 2 ? 5 : (CT * OT <= 3 ? 4 : 3));  // (128 registers: two workgroups per CU)
   struct Regs {
     f32x2 rP[4], rG[2];
     float rE[4];  // halo column of an edge lane (left OR right: a lane is at most one; a 1-tile-wide chunk has both outside)
@@ -462,7 +464,7 @@ __global__ void __launch_bounds__(512) wino_wgrad_narrow_mfma(const WwArgs a) {
       R[1] = t0 + t1;
       R[2] = pk_sub(t0, t1);
       R[3] = t1;  // stands for -t1: the sign is folded into the modifiers below
-      float* dst = st + IMG + ldsty;
+      float* dst = st + ldst;  // slot tid / 8 = 16 CT + ys
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         f32x2 y03, y12;
@@ -485,11 +487,10 @@ __global__ void __launch_bounds__(512) wino_wgrad_narrow_mfma(const WwArgs a) {
   f32x4 av[CT], bv[OT];  // {par0 k0, par1 k0, par0 k1, par1 k1}
   auto read_operands = [&](const float* st) {
     const float* vb = st + (wave * 4 + rq) * (CH * 4);
-    const float* yb = vb + IMG;
 #pragma unroll
     for (int i = 0; i < CT; ++i) av[i] = *reinterpret_cast<const f32x4*>(vb + ((i * 16 + col) ^ (rq << 1)) * 4);
 #pragma unroll
-    for (int j = 0; j < OT; ++j) bv[j] = *reinterpret_cast<const f32x4*>(yb + ((j * 16 + col) ^ (rq << 1)) * 4);
+    for (int j = 0; j < OT; ++j) bv[j] = *reinterpret_cast<const f32x4*>(vb + ((YOFF + j * 16 + col) ^ (rq << 1)) * 4);
   };
   auto mma_chunk = [&]() {
 #pragma unroll
@@ -518,8 +519,8 @@ __global__ void __launch_bounds__(512) wino_wgrad_narrow_mfma(const WwArgs a) {
 #pragma unroll
       for (int i = 0; i < PD; ++i) {
         const int q = q0 + i;
-        float* cur = smem + (q & 1) * STAGE;
-        float* nxt = smem + ((q + 1) & 1) * STAGE;
+        float* cur = smem + (q & 1) * IMG;
+        float* nxt = smem + ((q + 1) & 1) * IMG;
         read_operands(cur);
         __builtin_amdgcn_sched_barrier(0);
         store_chunk(nxt, R[i], role_);  // chunk q+1
@@ -538,38 +539,30 @@ __global__ void __launch_bounds__(512) wino_wgrad_narrow_mfma(const WwArgs a) {
   // slabs are larger than their inputs).  A (c, o) pair's 16 components sit in 8 different waves: they meet in LDS (the two
   // stages are free now), 32 in-channels x 64 out-channels x 16 slots = exactly its 128 KB, in two passes over the in-channel
   // tiles; the out-channel tile index is XOR-ed with the row group so that the four row groups of a wave hit disjoint banks.
-  float* G = smem;  // [slot 16][cc 32][o 64]
+  float* G = smem;  // [slot 16][cc 16][o 64] = the 64 KB of the two stages: one in-channel tile per pass
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < CT; ++h) {
     __syncthreads();  // MFMA loop / previous pass done with the buffer
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
-      for (int ii = 0; ii < 2; ++ii) {
-        const int i = 2 * h + ii;
-        if (i < CT) {
+      for (int j = 0; j < OT; ++j)
 #pragma unroll
-          for (int j = 0; j < OT; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-              G[((2 * wave + p) * 32 + ii * 16 + rq * 4 + g) * 64 + ((j ^ rq) * 16 + col)] = acc[p][i][j][g];
-        }
-      }
+        for (int g = 0; g < 4; ++g) G[((2 * wave + p) * 16 + rq * 4 + g) * 64 + ((j ^ rq) * 16 + col)] = acc[p][h][j][g];
     __syncthreads();
     constexpr int SL[4] = {0, 2, 3, 1};  // slot of column nu within a row of components
 #pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) {
-      const int cc = (tid >> 6) + 8 * k4;  // wave-uniform row of the half block
+    for (int k4 = 0; k4 < 2; ++k4) {
+      const int cc = (tid >> 6) + 8 * k4;  // wave-uniform row of the in-channel tile
       const int ol = tid & 63;
-      const int i = 2 * h + (cc >> 4);
-      const int c = c0 + i * 16 + (cc & 15), o = o0 + ol;
-      if (i < CT && ol < OT * 16 && c < a.CinP && o < a.CoutP) {
+      const int c = c0 + h * 16 + cc, o = o0 + ol;
+      if (ol < OT * 16 && c < a.CinP && o < a.CoutP) {
         const int osw = ((ol >> 4) ^ ((cc >> 2) & 3)) * 16 + (ol & 15);
         float M[4][4];
 #pragma unroll
         for (int xi = 0; xi < 4; ++xi)
 #pragma unroll
-          for (int nu = 0; nu < 4; ++nu) M[xi][nu] = G[((4 * xi + SL[nu]) * 32 + cc) * 64 + osw];
+          for (int nu = 0; nu < 4; ++nu) M[xi][nu] = G[((4 * xi + SL[nu]) * 16 + cc) * 64 + osw];
         float hh[3][4];  // G^T M
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) {
@@ -684,7 +677,10 @@ void plan_ww(int N, int Cin, int Cout, int H, int W, WwPlan& pl) {
   a.CinP = ct * 16; a.CoutP = ot * 16;
   const int n_cu = mg_cu_count();
   const int ny = pl.ncb * a.nob;
-  int ns = n_cu / ny > 0 ? n_cu / ny : 1;  // one 8-wave workgroup (128 KB of LDS) per CU
+  // one 8-wave workgroup (128 KB of LDS) per CU; the narrow form (64 KB) runs two
+  // (when that still leaves every workgroup >= 96 chunks: each slab costs a G^T M G pass and a share of the reduction)
+  const int per_cu = (pl.CT + pl.OT <= 4 && (long long)a.nblk * ny >= 96ll * 2 * n_cu) ? 2 : 1;
+  int ns = per_cu * n_cu / ny > 0 ? per_cu * n_cu / ny : 1;
   if (ns > a.nblk) ns = a.nblk;
   a.per = mg_cdiv(a.nblk, ns);
   pl.nsplit = mg_cdiv(a.nblk, a.per);
@@ -693,7 +689,7 @@ void plan_ww(int N, int Cin, int Cout, int H, int W, WwPlan& pl) {
 
 template <int CT, int OT, bool UPS>
 int launch_ww(const WwArgs& a, dim3 grid, hipStream_t s) {
-  constexpr size_t lds = (size_t)2 * STAGE * sizeof(float);
+  constexpr size_t lds = (size_t)2 * (CT + OT <= 4 ? IMG : STAGE) * sizeof(float);
   static MgPerDevice once;  // the LDS limit is a per-device function attribute
   if constexpr (CT + OT <= 4) {
     if (mg_first_use_on_device(once)) {
