@@ -719,6 +719,11 @@ int wino_run(WinoArgs& a, bool pn, hipStream_t s) {
   int cfg = 4, best = mg_cdiv(nt, 4) * 4;
   if (mg_cdiv(nt, 3) * 3 < best) { cfg = 3; best = mg_cdiv(nt, 3) * 3; }
   if (mg_cdiv(nt, 2) * 2 < best) { cfg = 2; best = mg_cdiv(nt, 2) * 2; }
+  // five or more channel tiles (80 .. 160 out-channels: the 64x64 .. 8x8 layers): two tiles per workgroup in the 32-tile form --
+  // four-wave workgroups, several per CU -- beat the 12- and 16-wave tilings by 6-8 % at 64x64 / 32x32 and by ~20 % at 16x16
+  // (tools/tune_wino.py, every (cfg, wt) per layer shape of a level-5 step); 48 and 64 out-channels stay on their one
+  // workgroup per CU (3x1 and 2x2 tiles)
+  if (nt >= 5) cfg = 2;
   if (pn) cfg = nt <= 2 ? 2 : (nt == 3 ? 3 : 4);
   // at most 16 out-channels: ONE channel tile per workgroup and 128 tiles instead of a second, all-padding channel tile
   // (the 32 -> 16 data gradient at 512x512 spent half its MFMAs on zero filters)
