@@ -274,7 +274,7 @@ def stft_traffic():
 def create_dataset_and_train_records(device, rand_channels: int):
     """BASELINE.json configs[4] end to end, and the real training loop on what it wrote.
 
-    `create_dataset_e2e`: musicgan_amd.create_dataset (reference create_dataset.py:34-64) on three synthetic 10-minute mono
+    `create_dataset_e2e`: musicgan_amd.create_dataset (reference create_dataset.py:34-64) on two synthetic 10-minute mono
     44.1 kHz wav files in a scratch directory: files/s, samples/s and where the wall time goes -- the GPU part is ~0.5 ms per file,
     the loop is bound by the 843 MB of float64 `.pt` files per file that the reference's format demands.
     `train_loop`: musicgan_amd.train.train (reference train.py:131-272) on that dataset -- packed loader, device input transform,
@@ -293,7 +293,7 @@ def create_dataset_and_train_records(device, rand_channels: int):
         wav_dir, data = os.path.join(tmp, "wav"), os.path.join(tmp, "data")
         os.mkdir(wav_dir)
         g = torch.Generator().manual_seed(7)
-        nfiles = 3
+        nfiles = 2  # (2.8 GB of scratch: 402 float64 samples + side-car + the wav files)
         for i in range(nfiles):
             wavio.save(os.path.join(wav_dir, f"track_{i}.wav"), torch.rand(1, 44100 * 600, generator=g) - 0.5, 44100)
         stats = {}
