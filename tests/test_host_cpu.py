@@ -125,3 +125,61 @@ def test_kernel_selection_predicates_respect_index_limits():
     assert not ops.upconv3x3_supported(96, 64, 1024)
     assert ops.wino_wgrad_supported(192, 48, 64, 128, 128) and not ops.wino_wgrad_supported(192, 48, 64, 127, 128)
     assert not ops.wino_wgrad_supported(1024, 64, 64, 128, 128)         # > 2^29 elements
+
+
+def test_packed_sidecar_index_and_invalidation(tmp_path):
+    """The float32 side-car of the fast loader (audio/dataset.py) without a GPU: rows may sit in ANY order in the array (create_dataset
+    streams them out in write order, idx 0, 1, 2, ...) and are served in the reference's order -- `magn_phase_*.pt` names sorted as
+    plain strings, so magn_phase_10.pt comes before magn_phase_2.pt (audio/dataset.py:14-44 of the reference); a side-car whose
+    files were replaced (other sizes), whose array is truncated, or whose directory gained a file is not valid any more."""
+    import json
+    import os
+    import importlib
+    cd = importlib.import_module("musicgan_amd.create_dataset")  # (the package attribute of that name is the function)
+    from musicgan_amd.audio import dataset as ds
+    folder = str(tmp_path)
+    shape = ds._SAMPLE_SHAPE
+    rng = torch.Generator().manual_seed(1)
+    n = 12
+    samples = [(torch.rand(*shape, generator=rng) * 2 - 1) for _ in range(n)]
+    for i, x in enumerate(samples):
+        torch.save(x.double(), os.path.join(folder, f"magn_phase_{i}.pt"))
+    # what create_dataset does: rows streamed in write order into .tmp, then _finish_sidecar
+    with open(os.path.join(folder, ds.PACKED_BIN + ".tmp"), "wb") as fh:
+        for x in samples:
+            fh.write(x.numpy().tobytes())
+    cd._finish_sidecar(folder, [f"magn_phase_{i}.pt" for i in range(n)])
+    assert ds.has_packed(folder)
+    packed, ref = ds.PackedAudioDataset(folder), ds.AudioDataset(folder)
+    names = sorted(f"magn_phase_{i}.pt" for i in range(n))
+    assert names[2] == "magn_phase_10.pt" and len(packed) == len(ref) == n
+    for i in range(n):
+        assert torch.equal(packed[i].double(), ref[i]), names[i]
+    out = torch.empty((3,) + shape)
+    packed.gather([2, 0, 11], out)
+    assert torch.equal(out[0].double(), ref[2]) and torch.equal(out[2].double(), ref[11])
+    # write_packed (rebuild from the .pt files) serves the same items
+    assert ds.write_packed(folder) == n and ds.has_packed(folder)
+    again = ds.PackedAudioDataset(folder)
+    assert all(torch.equal(again[i], packed[i]) for i in range(n))
+    meta = json.load(open(os.path.join(folder, ds.PACKED_META)))
+    assert meta["rows"] == list(range(n)) and len(meta["sizes"]) == n
+    # invalidation
+    torch.save(torch.zeros(2, 2), os.path.join(folder, "magn_phase_3.pt"))            # replaced behind the side-car's back
+    assert not ds.has_packed(folder)
+    torch.save(samples[3].double(), os.path.join(folder, "magn_phase_3.pt"))
+    assert ds.has_packed(folder)
+    with open(os.path.join(folder, ds.PACKED_BIN), "r+b") as fh:                       # truncated array
+        fh.truncate(100)
+    assert not ds.has_packed(folder)
+    ds.write_packed(folder)
+    torch.save(samples[0].double(), os.path.join(folder, "magn_phase_12.pt"))         # one more file
+    assert not ds.has_packed(folder)
+    # a run that wrote fewer files than the directory holds leaves no side-car (the loader then takes the reference path)
+    with open(os.path.join(folder, ds.PACKED_BIN + ".tmp"), "wb") as fh:
+        fh.write(samples[0].numpy().tobytes())
+    cd._remove_sidecar(folder)
+    with open(os.path.join(folder, ds.PACKED_BIN + ".tmp"), "wb") as fh:
+        fh.write(samples[0].numpy().tobytes())
+    cd._finish_sidecar(folder, ["magn_phase_0.pt"])
+    assert not ds.has_packed(folder) and not os.path.exists(os.path.join(folder, ds.PACKED_BIN + ".tmp"))
