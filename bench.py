@@ -305,7 +305,10 @@ def create_dataset_and_train_records(device, rand_channels: int):
                         f"{stats['samples']} float64 (2,512,512) .pt files + float32 side-car, scratch dir {tmp}",
             "files_per_s": nfiles / wall, "samples_per_s": stats["samples"] / wall, "wall_s": wall,
             "pt_MB_per_s": stats["pt_bytes"] / wall / 1e6,
-            "split_s": {"wav_read_upload_stft": stats["load_stft_s"], "codec_d2h_submit_sidecar": stats["codec_copy_submit_s"],
+            # the call's fixed cost (page-locking the 256 MiB chunk ring, starting the writers) is a third of a two-file run:
+            "files_per_s_after_setup": nfiles / (wall - stats["setup_s"]),
+            "split_s": {"setup_pinned_ring_and_threads": stats["setup_s"], "wav_read_upload_stft": stats["load_stft_s"],
+                        "codec_d2h_submit_sidecar": stats["codec_copy_submit_s"], "waiting_for_the_writers_at_the_end": stats["drain_s"],
                         "of_which_waiting_for_a_free_pinned_chunk": stats["ring_wait_s"],
                         "writer_threads": stats["writer_threads"], "writer_busy_thread_s": stats["writer_busy_s"]}}
         shutil.rmtree(wav_dir)

@@ -127,6 +127,7 @@ def create_dataset(audio_path: str, dataset_output_dir: str, *, packed: bool = T
         for p in w_p:
             _, data = wavfile.read(p, mmap=True)
             counts.append(_nb_samples(data.shape[0], nb_vec))
+    t_setup = time.perf_counter()
     n_thr = writer_threads or max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4))
     ring: "queue.Queue" = queue.Queue()
     for _ in range(4):
@@ -137,7 +138,8 @@ def create_dataset(audio_path: str, dataset_output_dir: str, *, packed: bool = T
     if packed and world == 1:
         side = open(join(dataset_output_dir, _ds.PACKED_BIN + ".tmp"), "wb")
     t_start = time.perf_counter()
-    t_gpu = t_load = t_wait = 0.0
+    t_setup = t_start - t_setup  # pinned ring (4 x 64 MiB page-locked) + writer threads: paid once per call
+    t_gpu = t_load = t_wait = t_drain = 0.0
     idx = n_files = 0
     ok = False
     try:
@@ -171,7 +173,9 @@ def create_dataset(audio_path: str, dataset_output_dir: str, *, packed: bool = T
                     side.write(memoryview(chunk.host[:n].numpy()).cast("B"))
                 chunk.release()
             t_gpu += time.perf_counter() - t1
-        writers.close()
+        t_drain = time.perf_counter()
+        writers.close()  # the writers finish what is queued
+        t_drain = time.perf_counter() - t_drain
         ok = True
     finally:
         if not ok:
@@ -187,7 +191,8 @@ def create_dataset(audio_path: str, dataset_output_dir: str, *, packed: bool = T
         _finish_sidecar(dataset_output_dir, names)
     if stats is not None:
         wall = time.perf_counter() - t_start
-        stats.update({"files": n_files, "samples": len(names), "wall_s": wall, "load_stft_s": t_load,
+        stats.update({"files": n_files, "samples": len(names), "wall_s": wall, "setup_s": t_setup, "drain_s": t_drain,
+                      "load_stft_s": t_load,
                       "codec_copy_submit_s": t_gpu, "ring_wait_s": t_wait, "writer_threads": n_thr,
                       "writer_busy_s": writers.busy_s, "pt_bytes": len(names) * 2 * (audio.N_FFT // 2) * nb_vec * 8})
 
