@@ -23,5 +23,5 @@ int mg_cu_count() {
   return cus[d];
 }
 
-extern "C" int mg_version(void) { return 100; }
+extern "C" int mg_version(void) { return 101; }  // 101: + mg_codec_fwd_strided (round 3)
 extern "C" const char* mg_last_error(void) { return g_err; }
