@@ -151,7 +151,9 @@ def create_dataset(audio_path: str, dataset_output_dir: str, *, packed: bool = T
             complex_values = audio.wav_to_stft(wav_p, nperseg=audio.N_FFT, stride=audio.STFT_STRIDE)
             t1 = time.perf_counter()
             t_load += t1 - t0
-            if complex_values.size()[1] < nb_vec:
+            # create_dataset.py:41-42 skips files of fewer than nb_vec frames; a file of EXACTLY nb_vec frames has nb_vec - 1 phase
+            # differences, i.e. no complete image either (the reference would write one degenerate (2, 512, 0) tensor for it)
+            if complex_values.size()[1] - 1 < nb_vec:
                 continue
             both = audio.stft_to_stacked_phase_magn(complex_values, nb_vec=nb_vec)  # (S, 2, 512, nb_vec) float32, on the device
             n_files += 1
