@@ -96,11 +96,18 @@ __global__ void __launch_bounds__(512) wino_wgrad_mfma(const WwArgs a) {
 
   // chunk `blk` (8 tiles): global loads into registers; tiles / rows / columns outside the image get an out-of-range offset and
   // read back as 0.0
-  auto load_chunk = [&](int blk) {
-    const int bx = blk % a.blocks_x;
-    const int t2 = blk / a.blocks_x;
-    const int by = t2 % a.blocks_y;
-    const int bn = t2 / a.blocks_y;
+  // the chunks of a slab are consecutive tile blocks: (bx, by, bn) of the next chunk to request is carried along (scalar selects)
+  // instead of being divided out of the chunk index for every chunk (~80 scalar instructions per chunk and wave)
+  int nq = 0, bx, by, bn;
+  {
+    const int b0 = split * a.per;
+    bx = b0 % a.blocks_x;
+    const int t2 = b0 / a.blocks_x;
+    by = t2 % a.blocks_y;
+    bn = t2 / a.blocks_y;
+  }
+  auto load_chunk = [&]() {  // the slab's next chunk (all-zero once past its end)
+    const int blk = nq < a.per ? split * a.per + nq : a.nblk;
     const int n = bn * a.TBN + nl, TY = by * a.TBH + tyl, TX = bx * a.TBW + txl;
     const bool ok = (blk < a.nblk) && (n < a.N) && (TY < Ht) && (TX < Wt);
     const int ux = UPS ? (bn * a.TBN * a.Cin) * HWx + (by * a.TBH) * Wt + bx * a.TBW
@@ -136,6 +143,14 @@ __global__ void __launch_bounds__(512) wino_wgrad_mfma(const WwArgs a) {
     rG[0] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(yrs, (int)(yok ? yo : 0x80000000u), 0, 0));
     rG[1] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(yrs, (int)(yok ? yo + (unsigned)a.W * 4u : 0x80000000u), 0, 0));
     bnext = n < a.bias_n;
+    ++nq;
+    ++bx;
+    const int wx = bx == a.blocks_x ? 1 : 0;
+    bx = wx ? 0 : bx;
+    by += wx;
+    const int wy = by == a.blocks_y ? 1 : 0;
+    by = wy ? 0 : by;
+    bn += wy;
   };
 
   // registers -> transformed operand images of one stage
@@ -217,10 +232,9 @@ __global__ void __launch_bounds__(512) wino_wgrad_mfma(const WwArgs a) {
 
   // pipeline: iteration q computes chunk q from stage q&1, writes chunk q+1 (registers) into the other stage and issues the
   // loads of chunk q+2; chunks past the slab (or past the tensor) are all-zero and add nothing
-  const int blk0 = split * a.per;
-  load_chunk(blk0);
+  load_chunk();
   store_chunk(smem);
-  load_chunk(blk0 + 1 < blk0 + a.per ? blk0 + 1 : a.nblk);
+  load_chunk();
   __syncthreads();
   for (int q = 0; q < a.per; ++q) {
     float* cur = smem + (q & 1) * STAGE;
@@ -228,7 +242,7 @@ __global__ void __launch_bounds__(512) wino_wgrad_mfma(const WwArgs a) {
     read_operands(cur);
     __builtin_amdgcn_sched_barrier(0);
     store_chunk(nxt);
-    load_chunk(q + 2 < a.per ? blk0 + q + 2 : a.nblk);
+    load_chunk();
     mma_chunk();
     __syncthreads();
   }
