@@ -52,6 +52,16 @@ class AudioDataset(Dataset):
 
 
 # ---------------------------------------------------------------------------------------------------------------- packed side-car
+def file_probe(path: str) -> int:
+    """CRC-32 of 4 KiB from the middle of a sample file (tensor payload).  Every valid sample has the same size, so sizes alone
+    cannot tell a regenerated dataset from the one the side-car was built from; this does, at one small read per file."""
+    import zlib
+    size = os.path.getsize(path)
+    with open(path, "rb") as fh:
+        fh.seek(max(0, size // 2 - 2048))
+        return zlib.crc32(fh.read(4096))
+
+
 def write_packed(dataset_path: str) -> int:
     """(Re)build the side-car from the `magn_phase_{idx}.pt` files of a dataset directory, rows in AudioDataset order (so index i
     of either dataset is the same sample).  Returns the number of samples."""
@@ -82,8 +92,8 @@ def write_packed(dataset_path: str) -> int:
     os.replace(path + ".tmp", path)
     with open(os.path.join(dataset_path, PACKED_META), "w") as fh:
         json.dump({"count": len(names), "shape": list(_SAMPLE_SHAPE), "dtype": "float32", "files": list(names),
-                   "rows": list(range(len(names))), "sizes": [os.path.getsize(os.path.join(dataset_path, n)) for n in names]},
-                  fh)
+                   "rows": list(range(len(names))), "sizes": [os.path.getsize(os.path.join(dataset_path, n)) for n in names],
+                   "probes": [file_probe(os.path.join(dataset_path, n)) for n in names]}, fh)
     return len(names)
 
 
@@ -97,8 +107,9 @@ def _read_meta(dataset_path: str):
 
 def has_packed(dataset_path: str) -> bool:
     """True when the side-car exists AND still matches the directory's .pt files: same names in the same order, the same file
-    sizes, and an array file of the recorded length.  (create_dataset removes the side-car before it rewrites any .pt file, so a
-    side-car never outlives the files it was built from; the size check catches files replaced behind its back.)"""
+    sizes, the same CRC of a 4 KiB probe from the middle of every file, and an array file of the recorded length.  (create_dataset
+    removes the side-car before it rewrites any .pt file, so a side-car never outlives the files it was built from; every valid
+    sample has the same size, so it is the probe that catches files replaced behind its back by another tool.)"""
     m = _read_meta(dataset_path)
     if m is None:
         return False
@@ -106,6 +117,8 @@ def has_packed(dataset_path: str) -> bool:
     if tuple(m.get("files", ())) != names:
         return False
     if "sizes" in m and list(m["sizes"]) != [os.path.getsize(os.path.join(dataset_path, n)) for n in names]:
+        return False
+    if "probes" in m and list(m["probes"]) != [file_probe(os.path.join(dataset_path, n)) for n in names]:
         return False
     want = int(m["count"]) * int(np.prod(_SAMPLE_SHAPE)) * 4
     return os.path.getsize(os.path.join(dataset_path, PACKED_BIN)) == want and sorted(m.get("rows", range(len(names)))) == \

@@ -217,4 +217,5 @@ def _finish_sidecar(folder: str, names_in_write_order) -> None:
     os.replace(tmp, join(folder, _ds.PACKED_BIN))
     with open(join(folder, _ds.PACKED_META), "w") as fh:
         json.dump({"count": len(files), "shape": list(_ds._SAMPLE_SHAPE), "dtype": "float32", "files": files, "rows": order,
-                   "sizes": [os.path.getsize(join(folder, f)) for f in files]}, fh)
+                   "sizes": [os.path.getsize(join(folder, f)) for f in files],
+                   "probes": [_ds.file_probe(join(folder, f)) for f in files]}, fh)

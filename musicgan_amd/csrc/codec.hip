@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(RT) codec_row_pass(const float2* __restrict__ 
                                                      float* __restrict__ part, int T, int nb_signed, int rem,
                                                      size_t img_stride) {
   __shared__ double tot_s[2][RW];
-  __shared__ float first_s[2][RW], last_s[2][RW];
+  __shared__ float first_s[2][RW], last_s[3][RW];  // last_s: three deep, see body()
   __shared__ float red[32];
   const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(RT) codec_row_pass(const float2* __restrict__ 
       x[e] = Xr[t];
     }
   };
-  auto body = [&](int it, float2 (&x)[RQ]) {
+  auto body = [&](int it, int q, float2 (&x)[RQ]) {  // q = it % 3
     const int p = it & 1;
     const int jw = J0 + it * RSPAN;        // column of the workgroup's first element
     const int j0 = jw + tid * RQ;          // this lane's first column; frame t = column + lead
@@ -156,13 +156,15 @@ __global__ void __launch_bounds__(RT) codec_row_pass(const float2* __restrict__ 
     const double incl = wave_incl_scan_f64(sl[RQ - 1]);
     if (lane == 63) {
       tot_s[p][wave] = incl;
-      last_s[p][wave] = ph[RQ - 1];
+      last_s[q][wave] = ph[RQ - 1];
     }
     if (lane == 0) first_s[p][wave] = ph[0];
     __syncthreads();
     // scan over the waves, redone by every wave in its lanes 0..RW-1 (entry l = wave l; lanes >= RW mirror the last entry)
     const int l = lane < RW ? lane : RW - 1;
-    const float lp = l > 0 ? last_s[p][l - 1] : last_s[p ^ 1][RW - 1];  // (first iteration: unwritten, masked by valid())
+    // The previous block's last phase is read AFTER this block's barrier while the last wave may already be writing the next
+    // block's: with two slots that write could overtake a slow reader (nothing orders them), so this array has three.
+    const float lp = l > 0 ? last_s[q][l - 1] : last_s[q == 0 ? 2 : q - 1][RW - 1];  // (first iteration: unwritten, masked by valid())
     const float af = valid(jw + l * 64 * RQ) ? unwrap_adj(first_s[p][l], lp) : 0.f;
     const double tl = tot_s[p][l];
     double v = (double)af + tl;
@@ -216,9 +218,9 @@ __global__ void __launch_bounds__(RT) codec_row_pass(const float2* __restrict__ 
   load(1, xb);
   load(2, xc);
   for (int it = 0; it < niter; it += 3) {  // (iterations past niter only touch masked columns)
-    body(it, xa);
-    body(it + 1, xb);
-    body(it + 2, xc);
+    body(it, 0, xa);
+    body(it + 1, 1, xb);
+    body(it + 2, 2, xc);
   }
   block_minmax(mnm, mxm, red);
   float a0 = mnm, a1 = mxm;

@@ -86,6 +86,11 @@ class PackCache:
         for _, ent in stale:
             ent[0] = self._tag(ent[2])
 
+    def invalidate(self) -> None:
+        """Mark every layout stale (its buffer is kept and re-packed on next use / refresh)."""
+        for ent in self._c.values():
+            ent[0] = None
+
     def get(self, w: torch.Tensor, dgrad: bool) -> torch.Tensor:
         return self._get(w, _lib.MG_PACK_CONV3X3, dgrad)
 

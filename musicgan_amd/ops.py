@@ -315,6 +315,10 @@ class WgradDefer:
     def add(self, job, direct: bool = False) -> None:
         (self._jobs_d if direct else self._jobs).append(job)
 
+    def reset(self) -> None:
+        """Drop collected jobs without running them (an aborted graph capture: their pointers died with the capture's pool)."""
+        self._jobs, self._jobs_d = [], []
+
     def flush(self) -> None:
         lib = _lib.load()
         for jobs, fn, what in ((self._jobs, lib.mg_wino3x3_wgrad_reduce, "mg_wino3x3_wgrad_reduce"),

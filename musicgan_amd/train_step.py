@@ -233,7 +233,9 @@ class ProGANStepper:
         if ent is None:
             # growth or a new batch shape: graphs of other levels (and their private memory pools, GBs at the large levels)
             # are never replayed again
-            for k in [k for k in self._graphs if k[1] != key[1]]:
+            # -- and neither are graphs of this update captured under other optimizer hyper-parameters (a scheduler that moves
+            # lr would otherwise keep one private activation pool alive per value)
+            for k in [k for k in self._graphs if k[1] != key[1] or (k[:4] == key[:4] and k[4] != key[4])]:
                 del self._graphs[k]
             if len(self._graphs) > 8:
                 self._graphs.clear()
@@ -255,6 +257,12 @@ class ProGANStepper:
                     ent.pop(k, None)
                 ent["eager"] = True
                 torch.cuda.synchronize()
+                # host state the aborted capture already changed: the pack caches recorded every layout as fresh although the
+                # pack kernels were only captured, never run; deferred weight-gradient reductions point into the discarded pool
+                self._defer_d.reset()
+                self._defer_g.reset()
+                self.gen._pack_cache.invalidate()
+                self.disc._pack_cache.invalidate()
                 for st, v in mirrors:  # a captured-but-never-run optimizer step may have advanced the host step mirrors
                     st["step"].copy_(v)
                 return run(alpha, *inputs)

@@ -86,7 +86,7 @@ def test_codec_at_config5_size_against_the_reference():
     REFERENCE's output on the same bits (library-independent STFT-like input whose unwrapped phase reaches 1.6e5 rad).
     The phase image is discontinuous in its input (golden_util.c5_phase_stats): the GPU's atan2f differs from torch's by an ulp on
     part of the bins, the exact running sum (torch.cumsum: float64 accumulator) turns that into one ulp(1e5 rad) on ~0.1 % of the
-    elements.  Bounds: >= 90 % of the sampled elements within 1e-6, NONE beyond two ulps of the unwrapped phase, <= 3 wrap flips
+    elements.  Bounds: >= 92 % of the sampled elements within 1e-6, none beyond 0.6 of two ulps of the unwrapped phase, <= 1 wrap flip
     (the numpy oracle, same sum with numpy's atan2f, sits at 94 %; a float32 running sum -- rounds 1-2 -- at 0.05 %).
     Second, the scan itself with the math library taken out: the oracle's codec fed the device's own |X| and angle(X) must
     reproduce the kernel's images bit for bit."""
@@ -99,7 +99,8 @@ def test_codec_at_config5_size_against_the_reference():
     assert tuple(magn.shape) == tuple(phase.shape) == (201, 512, 512)
     frac, worst, flips, n = c5_phase_stats(g, "spec", phase.cpu().numpy())
     print(f"config-5 codec vs reference: {frac:.4%} of {n} within 1e-6, worst {worst:.3f} of the 2-ulp bound, {flips} flips")
-    assert frac >= 0.90 and worst <= 1.0 and flips <= 3, (frac, worst, flips, n)
+    # gates = measured (94.05 %, worst 0.5 of the bound, 0 flips) less a small margin, so that a regression shows
+    assert frac >= 0.92 and worst <= 0.6 and flips <= 1, (frac, worst, flips, n)
     _c5_check_magn(g, "spec", magn, 2e-6)
     assert float(magn.min()) == -1.0 and float(magn.max()) == 1.0 and float(phase.min()) == -1.0 and float(phase.max()) == 1.0
     # the stacked form create_dataset uses is the same bits in one (S, 2, 512, 512) tensor
@@ -131,7 +132,7 @@ def test_waveform_to_codec_at_config5_size_against_the_reference():
     magn, phase = audio.stft_to_phase_magn(c)
     frac, worst, flips, n = c5_phase_stats(g, "wav", phase.cpu().numpy())
     print(f"config-5 wav -> codec vs reference: {frac:.4%} of {n} within 1e-6, worst {worst:.3f} of the 2-ulp bound, {flips} flips")
-    assert frac >= 0.75 and worst <= 1.0 and flips <= 3, (frac, worst, flips, n)
+    assert frac >= 0.90 and worst <= 1.0 and flips <= 3, (frac, worst, flips, n)  # measured 92.1 %
     _c5_check_magn(g, "wav", magn, 5e-6)
 
 
@@ -170,7 +171,9 @@ def test_codec_odd_sizes_against_oracle():
 
 
 def test_codec_long_track_against_oracle():
-    """2 000 frames: the unwrap must track the oracle's torch.cumsum-style (float64 accumulator) running sum."""
+    """2 000 frames of a tone + noise: the unwrap must reproduce the oracle's torch.cumsum-style (float64 accumulator) running
+    sum.  Gated like the ragged sizes above: with the device's own |X| and angle(X) handed to the oracle the phase image is
+    bit-identical (the only freedom left is the normalisation's last bit); the magnitude within 2 ulp of 1."""
     from musicgan_amd import audio
     from oracle import audio as OA
     rng = np.random.default_rng(3)
@@ -178,11 +181,13 @@ def test_codec_long_track_against_oracle():
     t = np.arange(wav.size) / 44100.0
     wav += (0.4 * np.sin(2 * np.pi * 880.0 * t)).astype(np.float32)
     c_ref = OA.stft(wav)
-    m_ref, p_ref = OA.stft_to_phase_magn(c_ref)
-    magn, phase = audio.stft_to_phase_magn(torch.from_numpy(c_ref))
+    xd = torch.from_numpy(c_ref).to(DEV)
+    m_ref, p_ref = OA.stft_to_phase_magn(c_ref, lib=(torch.abs(xd).cpu().numpy(), torch.angle(xd).cpu().numpy()))
+    magn, phase = audio.stft_to_phase_magn(xd)
     assert tuple(magn.shape) == m_ref.shape == (3, 512, 512)
-    assert float(np.abs(magn.cpu().numpy() - m_ref).max()) <= 5e-6
-    assert float(np.abs(phase.cpu().numpy() - p_ref).max()) <= 5e-4
+    assert float(np.abs(magn.cpu().numpy() - m_ref).max()) <= 2e-6
+    assert float(np.mean(phase.cpu().numpy() == p_ref)) >= 0.999
+    assert float(np.abs(phase.cpu().numpy() - p_ref).max()) <= 1e-4
 
 
 def test_drivers_end_to_end_tiny_corpus(tmp_path):

@@ -169,6 +169,10 @@ def test_packed_sidecar_index_and_invalidation(tmp_path):
     assert not ds.has_packed(folder)
     torch.save(samples[3].double(), os.path.join(folder, "magn_phase_3.pt"))
     assert ds.has_packed(folder)
+    torch.save(samples[4].double(), os.path.join(folder, "magn_phase_3.pt"))          # same size, another sample
+    assert not ds.has_packed(folder)
+    torch.save(samples[3].double(), os.path.join(folder, "magn_phase_3.pt"))
+    assert ds.has_packed(folder)
     with open(os.path.join(folder, ds.PACKED_BIN), "r+b") as fh:                       # truncated array
         fh.truncate(100)
     assert not ds.has_packed(folder)

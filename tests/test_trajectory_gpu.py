@@ -281,6 +281,55 @@ def test_graph_replay_is_bit_identical_to_eager_updates(monkeypatch):
         assert torch.equal(s_graph[k], s_eager[k]), k
 
 
+def test_failed_graph_capture_falls_back_to_bit_identical_eager_updates(monkeypatch):
+    """a capture that fails half way -- here: the one-launch weight-gradient reduction raises while the stream
+    is capturing -- has already marked every packed weight layout as fresh (the pack kernels were captured, never run) and left
+    deferred reduction jobs that point into the discarded graph pool.  The eager fallback must not inherit either: the whole
+    trajectory equals the MG_GRAPHS=0 one bit for bit."""
+    import warnings
+
+    import bench
+    from musicgan_amd import ops
+    from musicgan_amd.optim import FusedAdam
+    from musicgan_amd.train_step import ProGANStepper
+
+    def run(fail: bool):
+        monkeypatch.setenv("MG_GRAPHS", "1" if fail else "0")
+        gen, disc = bench.build_nets(3, 32, DEV)
+        og = FusedAdam(gen.parameters(), lr=LR, betas=BETAS)
+        od = FusedAdam(disc.parameters(), lr=LR, betas=BETAS)
+        st = ProGANStepper(gen, disc, og, od, 32)
+        rng = torch.Generator(device=DEV).manual_seed(11)
+        losses = []
+        for it in range(7):
+            x = torch.rand(4, 2, 32, 32, device=DEV, generator=rng) * 2 - 1
+            z = torch.randn(4, 32, 2, 2, device=DEV, generator=rng)
+            eps = torch.rand(4, 1, 1, 1, device=DEV, generator=rng)
+            m = st.d_step(x, 0.6, z=z, eps=eps)
+            losses += [float(m["disc_loss"]), float(m["grad_pen"])]
+            losses.append(float(st.g_step(4, 0.6, DEV, z=z)["gen_loss"]))
+        st.finish()
+        if fail:
+            assert all(e.get("eager") for e in st._graphs.values()) and len(st._graphs) == 2
+        state = {f"{n}.{k}": p.detach().clone() for n, net in (("G", gen), ("D", disc)) for k, p in net.named_parameters()}
+        return losses, state
+
+    real_flush = ops.WgradDefer.flush
+
+    def flush(self):
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("injected: capture fails inside the weight-gradient sweep")
+        return real_flush(self)
+    l_eager, s_eager = run(False)
+    monkeypatch.setattr(ops.WgradDefer, "flush", flush)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        l_fail, s_fail = run(True)
+    assert l_fail == l_eager
+    for k in s_eager:
+        assert torch.equal(s_fail[k], s_eager[k]), k
+
+
 def test_captured_graphs_follow_the_optimizer(monkeypatch):
     """lr / betas / eps travel into a captured Adam launch as scalars and the moment tensors by address, so a graph
     must not outlive a change of either.  (i) lr set to 0 in every param group after the critic graph exists: the following
@@ -313,7 +362,8 @@ def test_captured_graphs_follow_the_optimizer(monkeypatch):
         d_step(st)
     torch.cuda.synchronize()
     assert all(torch.equal(p, frozen[k]) for k, p in disc.named_parameters()), "a stale graph kept training with the old lr"
-    assert sum("graph" in e for e in st._graphs.values()) == 2  # the lr = 0 signature has its own graph
+    # the lr = 0 signature has its own graph; the lr = 1e-3 one (and its private memory pool) is dropped, not kept
+    assert sum("graph" in e for e in st._graphs.values()) == 1 and len(st._graphs) == 1
     # (ii) load_state_dict
     for group in od.param_groups:
         group["lr"] = LR

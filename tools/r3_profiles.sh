@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 for c in 5:64 4:32 6:6 7:6 7:16; do
   L=${c%%:*}; B=${c##*:}
-  rm -rf $R/gpurun_out/ks_$L_$B
+  rm -rf $R/gpurun_out/ks_${L}_${B}
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ks_${L}_${B} -- python3 $R/bench.py --level $L --batch $B --steps 40 --warmup 10 --no-extra --no-cpu-baseline > $R/gpurun_out/ks_${L}_${B}.json 2>/dev/null || exit 1
   cp $R/gpurun_out/ks_${L}_${B}/*/*kernel_stats.csv $R/gpurun_out/r03_bench_l${L}_bs${B}_kernel_stats.csv
   rm -rf $R/gpurun_out/ks_${L}_${B}
