@@ -219,11 +219,11 @@ int mg_group_means(const float* x, int groups, int n, float* out, mg_stream_t st
  * All of mg_conv3x3_pack / mg_wino3x3_pack / mg_upconv3x3_pack / mg_upconv3x3_dgrad_pack for a list of weights in ONE launch (the
  * reference has no counterpart: these layouts replace what MIOpen / oneDNN re-derive from nn.Conv2d.weight inside every call).
  * descs is a HOST array; `out` buffers are sized by the matching *_packed_floats(). */
-enum { MG_PACK_CONV3X3 = 0, MG_PACK_WINO3X3 = 1, MG_PACK_UPCONV3X3 = 2, MG_PACK_UPCONV3X3_DGRAD = 3 };
+enum { MG_PACK_CONV3X3 = 0, MG_PACK_WINO3X3 = 1, MG_PACK_UPCONV3X3 = 2, MG_PACK_UPCONV3X3_DGRAD = 3, MG_PACK_SMALLNET = 4 };
 typedef struct {
   const float* w; /* module weight [Co][Ci][3][3] */
   float* out;
-  int32_t kind, Co, Ci, dgrad; /* dgrad: data-gradient variant (kinds 0 and 1 only) */
+  int32_t kind, Co, Ci, dgrad; /* dgrad: data-gradient variant (kinds 0, 1 and 4 only) */
 } mg_pack_desc_t;
 int mg_pack_multi(const mg_pack_desc_t* descs, int n, mg_stream_t stream);
 
@@ -259,6 +259,52 @@ int mg_adam_step_dev(const mg_adam_tensor_dev_t* desc, int n_tensors, float lr, 
  * wav: mono fp32 [L]; out_re/out_im: [512][T] (freq-major, Nyquist row dropped), T = 1 + L/256.  Periodic Hann(1024),
  * centre reflect padding, hop 256, divided by sqrt(sum w^2).  If out_im == NULL, out_re is interleaved complex64 [512][T][2]. */
 int mg_stft_1024(const float* wav, float* out_re, float* out_im, int64_t L, mg_stream_t stream);
+
+/* ------------------------------------------------------------------ multi-layer chains on small maps
+ * The <= 4x4 ends of both networks -- the generator's first blocks [generator.py:15-40,67-76: conv3x3 -> LeakyReLU -> PixelNorm
+ * -> Upsample -> conv3x3 -> LeakyReLU -> PixelNorm] and the critic's last blocks + classifier [discriminator.py:14-34,60-70,
+ * 94-101: conv3x3 -> LeakyReLU -> AvgPool2d -> conv3x3 -> LeakyReLU ... -> Flatten -> Linear(160, 1)] -- are ~0.1 GFLOP of work
+ * behind 6-10 dependent launches per pass at one launch per layer.  mg_smallnet runs such a chain as ONE launch: a workgroup
+ * carries `imgs_per_wg` images through a list of ops with the activations in LDS ([pixel incl. a zero halo ring][channel]), the
+ * 3x3 filters streamed from L2 straight into MFMA operand registers (layout of MG_PACK_SMALLNET / mg_smallnet_packed_floats:
+ * [Cin/16][9 taps][Cout/16][64 lanes][4], dgrad = 1: the flipped / transposed filters of the data gradient) and every tensor a
+ * later pass needs (activations, masks' sources, masked gradients) written to global memory on the way.  The same op list
+ * serves the forward passes, the data-gradient chains and the tangent pass of the gradient penalty; weight gradients stay
+ * per-layer launches on the stored tensors.  Ops (global tensors are (N, C, H, W) fp32; `src` / `dst` = LDS buffer 0..2):
+ *   MG_SN_LOAD     dst <- in                                             (C, H, W)
+ *   MG_SN_STORE    out <- src
+ *   MG_SN_CONV     dst <- act(conv3x3(src, w) + bias), also -> out       (C -> C2 at H x W; flags MG_SN_LRELU | MG_SN_MASK: act =
+ *                  LeakyReLU, or multiplication by lrelu'(aux) = (aux > 0 ? 1 : slope): the tangent pass / LeakyReLU backward)
+ *                  1x1 maps take the centre tap in fp64 accumulation (what mg_conv3x3 does there)
+ *   MG_SN_MASK     src <- src * lrelu'(aux), also -> out                 (LeakyReLU backward on its own)
+ *   MG_SN_PIXNORM  src <- src * rn, rn = 1/sqrt(mean_c src^2 + 1e-8); p -> out, rn -> out2 (N,1,H,W)        [layers.py:11-17]
+ *   MG_SN_PNBWD    src <- lrelu'(p) * rn * (src - p * mean_c(src * p)), also -> out;  p = in, rn = aux (PixelNorm + LeakyReLU backward)
+ *   MG_SN_POOL     dst <- AvgPool2d(2,2)(src), also -> out               (H, W = input size)
+ *   MG_SN_POOLBWD  dst <- 0.25 * up2(src) * lrelu'(aux), also -> out     (H, W = input size; MG_SN_NOLDS: only -> out)
+ *   MG_SN_UP       dst <- nearest-upsample x2 of src                     (H, W = input size)
+ *   MG_SN_UPBWD    dst <- 2x2 block sums of src                          (H, W = input size)
+ *   MG_SN_LINEAR   out[n] <- sum_c w[c] * src[c] + bias[0]               (1x1 map; w = in, bias = aux; fp64 accumulation)
+ *   MG_SN_LINBWD   dst[c] <- in[n] * aux[c]                              (in = upstream (N,1), aux = classifier weight)
+ * Limits: H, W <= 8 and imgs_per_wg * H * W <= 64 at every CONV, C <= 192, lds_floats_per_buffer * 12 bytes <= 160 KB
+ * (mg_smallnet_buffer_floats gives the size one tensor needs).  descs is a HOST array of at most MG_SN_MAX_OPS records. */
+enum { MG_SN_LOAD = 0, MG_SN_STORE, MG_SN_CONV, MG_SN_MASK, MG_SN_PIXNORM, MG_SN_PNBWD, MG_SN_POOL, MG_SN_POOLBWD, MG_SN_UP,
+       MG_SN_UPBWD, MG_SN_LINEAR, MG_SN_LINBWD };
+#define MG_SN_LRELU 1
+#define MG_SN_MASK_AUX 2
+#define MG_SN_NOLDS 4
+#define MG_SN_MAX_OPS 32
+typedef struct {
+  int32_t op, src, dst, C, C2, H, W, flags;
+  const float* in;  /* LOAD: tensor; CONV: packed filters; PNBWD: p; LINEAR: weight; LINBWD: upstream */
+  const float* aux; /* CONV: mask source (MG_SN_MASK_AUX); MASK / POOLBWD: mask source; PNBWD: rn; LINEAR: bias; LINBWD: weight */
+  const float* bias; /* CONV */
+  float* out;
+  float* out2; /* PIXNORM: rn */
+} mg_sn_op_t;
+size_t mg_smallnet_packed_floats(int Cin, int Cout);
+size_t mg_smallnet_buffer_floats(int imgs_per_wg, int C, int H, int W);
+int mg_smallnet(const mg_sn_op_t* ops, int nops, int N, int imgs_per_wg, size_t lds_floats_per_buffer, float slope,
+                mg_stream_t stream);
 
 /* ------------------------------------------------------------------ magnitude/phase codec + inverse STFT
  * mg_codec_fwd: stft_to_phase_magn [audio/functions.py:65-94].  stft_c64: interleaved complex64 [512][T] (mg_stft_1024 output);

@@ -43,7 +43,18 @@ class PackDesc(Structure):
     _fields_ = [("w", c_void_p), ("out", c_void_p), ("kind", c_int), ("Co", c_int), ("Ci", c_int), ("dgrad", c_int)]
 
 
-MG_PACK_CONV3X3, MG_PACK_WINO3X3, MG_PACK_UPCONV3X3, MG_PACK_UPCONV3X3_DGRAD = 0, 1, 2, 3
+MG_PACK_CONV3X3, MG_PACK_WINO3X3, MG_PACK_UPCONV3X3, MG_PACK_UPCONV3X3_DGRAD, MG_PACK_SMALLNET = 0, 1, 2, 3, 4
+
+(MG_SN_LOAD, MG_SN_STORE, MG_SN_CONV, MG_SN_MASK, MG_SN_PIXNORM, MG_SN_PNBWD, MG_SN_POOL, MG_SN_POOLBWD, MG_SN_UP, MG_SN_UPBWD,
+ MG_SN_LINEAR, MG_SN_LINBWD) = range(12)
+MG_SN_LRELU, MG_SN_MASK_AUX, MG_SN_NOLDS = 1, 2, 4
+MG_SN_MAX_OPS = 32
+
+
+class SnOp(Structure):
+    _fields_ = [("op", c_int), ("src", c_int), ("dst", c_int), ("C", c_int), ("C2", c_int), ("H", c_int), ("W", c_int),
+                ("flags", c_int), ("inp", c_void_p), ("aux", c_void_p), ("bias", c_void_p), ("out", c_void_p), ("out2", c_void_p)]
+
 
 _P = c_void_p
 # name -> (restype, argtypes); every entry must be exported by the library (checked by tests/test_abi.py)
@@ -100,6 +111,9 @@ SIGNATURES = {
     "mg_adam_step": (c_int, [_P, c_int, c_float, c_float, c_float, c_float, _P]),
     "mg_group_means": (c_int, [_P, c_int, c_int, _P, _P]),
     "mg_pack_multi": (c_int, [_P, c_int, _P]),
+    "mg_smallnet_packed_floats": (c_size_t, [c_int, c_int]),
+    "mg_smallnet_buffer_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "mg_smallnet": (c_int, [_P, c_int, c_int, c_int, c_size_t, c_float, _P]),
     "mg_adam_step_dev": (c_int, [_P, c_int, c_float, c_float, c_float, c_float, c_float, _P]),
     "mg_input_transform_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "mg_input_transform": (c_int, [_P, c_int, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_float, _P]),

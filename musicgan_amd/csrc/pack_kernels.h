@@ -123,3 +123,25 @@ __device__ __forceinline__ void pack_downconv_elem(size_t e, const float* __rest
 __host__ __device__ static inline size_t pack_downconv_total(int Co, int Ci) {
   return (size_t)mg_cdiv(Co, MG_PACK_CC) * 16 * MG_PACK_CC * (size_t)(16 * mg_cdiv(Ci, 16));
 }
+
+// multi-layer small-map chains (smallnet.hip): the filter fragment IS the MFMA A operand, read from L2 straight into registers:
+// [Cin/16 group g][tap][Cout/16 tile][lane = (oc % 16) + 16 * kq][s]  <->  filter (oc, ci = 16 g + 4 kq + s, tap); zero padded
+__device__ __forceinline__ void pack_smallnet_elem(size_t e, const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci,
+                                                   int dgrad) {
+  const int cin_call = dgrad ? Co : Ci, cout_call = dgrad ? Ci : Co;
+  const int MT = mg_cdiv(cout_call, 16);
+  const int s = (int)(e & 3), lane = (int)((e >> 2) & 63);
+  size_t r = e >> 8;
+  const int mt = (int)(r % MT);
+  r /= MT;
+  const int t = (int)(r % 9);
+  const int g = (int)(r / 9);
+  const int o = mt * 16 + (lane & 15), c = g * 16 + 4 * (lane >> 4) + s;
+  float v = 0.f;
+  if (c < cin_call && o < cout_call) v = dgrad ? w[((size_t)c * Ci + o) * 9 + (8 - t)] : w[((size_t)o * Ci + c) * 9 + t];
+  wp[e] = v;
+}
+__host__ __device__ static inline size_t pack_smallnet_total(int Co, int Ci, int dgrad) {
+  const int cin_call = dgrad ? Co : Ci, cout_call = dgrad ? Ci : Co;
+  return (size_t)mg_cdiv(cin_call, 16) * 9 * mg_cdiv(cout_call, 16) * 256;
+}

@@ -78,6 +78,8 @@ def packed_floats(kind: int, co: int, ci: int, dgrad: bool) -> int:
         return lib.mg_wino3x3_packed_floats(cin_call, cout_call)
     if kind == _lib.MG_PACK_UPCONV3X3:
         return lib.mg_upconv3x3_packed_floats(ci, co)
+    if kind == _lib.MG_PACK_SMALLNET:
+        return lib.mg_smallnet_packed_floats(cin_call, cout_call)
     return lib.mg_upconv3x3_dgrad_packed_floats(ci, co)
 
 
@@ -361,6 +363,89 @@ def conv3x3_wgrad(x, gy, gw, gb, *, ups=False, accumulate=False, bias_n: int = 0
     ws = workspace(nbytes, x.device)
     check(lib.mg_conv3x3_wgrad(_p(x), _p(gy), _p(gw), _p(gb), _p(ws), ws.numel(), n, cin, cout, h, w,
                                MG_CONV_UPS_IN if ups else 0, int(accumulate), int(bias_n), _s()), "mg_conv3x3_wgrad")
+
+
+# ------------------------------------------------------------------ multi-layer chains on small maps
+class SmallNet:
+    """Builds the op list of one mg_smallnet launch (include/musicgan_hip.h): a workgroup carries `imgs_per_wg` images through
+    all ops with the activations in three LDS buffers.  Methods append an op and return self; `run(n)` launches.  Global tensors
+    are contiguous fp32 (N, C, H, W) (views of a leading-dimension slice are fine: only data_ptr() is passed); filters come
+    from PackCache.get_sn()."""
+
+    def __init__(self, imgs_per_wg: int = 1):
+        self.g = int(imgs_per_wg)
+        self.ops = []
+        self.keep = []       # tensors the launch reads / writes (kept alive until run() has been issued)
+        self.buf_floats = 0
+
+    def _fit(self, c, h, w):
+        self.buf_floats = max(self.buf_floats, _lib.load().mg_smallnet_buffer_floats(self.g, c, h, w))
+
+    def _add(self, op, src=0, dst=0, C=1, C2=0, H=1, W=1, flags=0, inp=None, aux=None, bias=None, out=None, out2=None):
+        _chk(inp, aux, bias, out, out2)
+        self.keep += [t for t in (inp, aux, bias, out, out2) if t is not None]
+        self.ops.append(_lib.SnOp(op, src, dst, C, C2, H, W, flags, _p(inp), _p(aux), _p(bias), _p(out), _p(out2)))
+        self._fit(C, H, W)
+        return self
+
+    def load(self, dst, x):
+        _, c, h, w = x.shape
+        return self._add(_lib.MG_SN_LOAD, dst=dst, C=c, H=h, W=w, inp=x)
+
+    def store(self, src, out):
+        _, c, h, w = out.shape
+        return self._add(_lib.MG_SN_STORE, src=src, C=c, H=h, W=w, out=out)
+
+    def conv(self, src, dst, wpk, cin, cout, h, w, *, bias=None, lrelu=False, mask=None, out=None):
+        self._fit(cout, h, w)
+        fl = (_lib.MG_SN_LRELU if lrelu else 0) | (_lib.MG_SN_MASK_AUX if mask is not None else 0)
+        return self._add(_lib.MG_SN_CONV, src=src, dst=dst, C=cin, C2=cout, H=h, W=w, flags=fl, inp=wpk, aux=mask, bias=bias,
+                         out=out)
+
+    def mask(self, src, c, h, w, aux, out=None):
+        return self._add(_lib.MG_SN_MASK, src=src, C=c, H=h, W=w, aux=aux, out=out)
+
+    def pixnorm(self, src, c, h, w, p_out=None, rn_out=None):
+        return self._add(_lib.MG_SN_PIXNORM, src=src, C=c, H=h, W=w, out=p_out, out2=rn_out)
+
+    def pnbwd(self, src, c, h, w, p, rn, out=None):
+        return self._add(_lib.MG_SN_PNBWD, src=src, C=c, H=h, W=w, inp=p, aux=rn, out=out)
+
+    def pool(self, src, dst, c, h, w, out=None):
+        return self._add(_lib.MG_SN_POOL, src=src, dst=dst, C=c, H=h, W=w, out=out)
+
+    def poolbwd(self, src, dst, c, h, w, aux, out=None, lds=True):
+        if lds:
+            self._fit(c, 2 * h, 2 * w)
+        return self._add(_lib.MG_SN_POOLBWD, src=src, dst=dst, C=c, H=h, W=w, flags=0 if lds else _lib.MG_SN_NOLDS, aux=aux,
+                         out=out)
+
+    def up(self, src, dst, c, h, w):
+        self._fit(c, 2 * h, 2 * w)
+        return self._add(_lib.MG_SN_UP, src=src, dst=dst, C=c, H=h, W=w)
+
+    def upbwd(self, src, dst, c, h, w):
+        return self._add(_lib.MG_SN_UPBWD, src=src, dst=dst, C=c, H=h, W=w)
+
+    def linear(self, src, c, w, b, out):
+        return self._add(_lib.MG_SN_LINEAR, src=src, C=c, inp=w, aux=b, out=out)
+
+    def linbwd(self, dst, c, g_out, w):
+        return self._add(_lib.MG_SN_LINBWD, dst=dst, C=c, inp=g_out, aux=w)
+
+    def run(self, n: int) -> None:
+        arr = (_lib.SnOp * len(self.ops))(*self.ops)
+        check(_lib.load().mg_smallnet(ctypes.cast(arr, ctypes.c_void_p), len(self.ops), int(n), self.g,
+                                      (int(self.buf_floats) + 3) & ~3, SLOPE, _s()), "mg_smallnet")
+        self.keep = []
+
+
+def pack_smallnet(w: torch.Tensor, dgrad: bool) -> torch.Tensor:
+    """Filters of a 3x3 convolution in the operand order mg_smallnet streams (MG_PACK_SMALLNET)."""
+    _chk(w)
+    out = torch.empty(packed_floats(_lib.MG_PACK_SMALLNET, w.shape[0], w.shape[1], dgrad), dtype=torch.float32, device=w.device)
+    pack_multi([(_lib.MG_PACK_SMALLNET, w, dgrad, out)])
+    return out
 
 
 # ------------------------------------------------------------------ conv 1x1
