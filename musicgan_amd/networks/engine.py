@@ -130,6 +130,10 @@ class PackCache:
             return p, rn
         return ops.pixelnorm_fwd(self.conv(x, w, False, bias, cout, ups=ups, lrelu=True))  # "conv+pixnorm"
 
+    def get_sn(self, w: torch.Tensor, dgrad: bool) -> torch.Tensor:
+        """Filters in the operand order the multi-layer small-map kernel streams (ops.SmallNet)."""
+        return self._get(w, _lib.MG_PACK_SMALLNET, dgrad)
+
     def get_up(self, w: torch.Tensor) -> torch.Tensor:
         """Effective sub-pixel weights of Upsample(x2) -> Conv3x3 (ops.upconv3x3)."""
         return self._get(w, _lib.MG_PACK_UPCONV3X3, False)
@@ -193,6 +197,43 @@ class FadeIn:
 _COEF: Dict[tuple, torch.Tensor] = {}
 
 
+# =====================================================================================================================
+# Multi-layer chains on the <= 4x4 maps (ops.SmallNet / mg_smallnet): the critic's last blocks + classifier and the generator's
+# first blocks as ONE launch per pass instead of 6-10 (MG_SMALLNET=0: one launch per layer everywhere)
+# =====================================================================================================================
+def _smallnet_on() -> bool:
+    return os.environ.get("MG_SMALLNET", "1") != "0"
+
+
+def _imgs_per_wg(n: int) -> int:
+    """One image per workgroup while every image still gets a CU of its own (shortest chain); two beyond that (half the
+    filter traffic per image)."""
+    return 1 if n <= 256 else 2
+
+
+def disc_tail_start(W: "DiscWeights", h: int, w: int) -> Optional[int]:
+    """Index t of the critic block whose first conv runs at 8x8 (so its second conv, and every later layer, sits on <= 4x4
+    maps), when the fused tail applies: square input, final map 1x1, and t >= 1 so that the fade-in blend (block 0) stays
+    outside it.  The tail then covers conv2 of block t, blocks t+1 and t+2, and the classifier."""
+    if not _smallnet_on() or h != w:
+        return None
+    t = len(W.blocks) - 3
+    if t < 1 or h != (8 << t):
+        return None
+    return t
+
+
+def _rot(cur: int):
+    """The two LDS buffers other than `cur`."""
+    return [b for b in (0, 1, 2) if b != cur]
+
+
+def gen_head_ok(W: "GenWeights", z: torch.Tensor) -> bool:
+    """The generator's first three convs (block 0 and the first conv of block 1: 2x2 and 4x4 maps) as one launch: latent maps of
+    2x2 only (generate's wide latents take the per-layer path) and at least three blocks, so that neither head hangs off them."""
+    return _smallnet_on() and len(W.blocks) >= 3 and tuple(z.shape[2:]) == (2, 2)
+
+
 class GradSink:
     """Collects parameter gradients keyed by the parameter object; a second write to the same key accumulates.
     `flat` (optional, with `layout` = {id(param): (offset, numel)}): the gradients are carved out of ONE buffer, which is what the
@@ -242,10 +283,34 @@ class GenWeights:
 def gen_forward(W: GenWeights, z: torch.Tensor, alpha: float, cache: PackCache, save: bool, out=None):
     x = z.contiguous()
     saved = []
-    for (w1, b1, w2, b2) in W.blocks:
+    head = gen_head_ok(W, x)
+    if head:
+        # block 0 and the first conv of block 1 in one launch (activations in LDS); only what the backward pass needs is stored
+        n, rc = x.shape[0], x.shape[1]
+        (w1a, b1a, w2a, b2a), (w1b, b1b, _, _) = W.blocks[0], W.blocks[1]
+        c0, c1 = w2a.shape[0], w1b.shape[0]
+        new = lambda c, s: torch.empty((n, c, s, s), dtype=torch.float32, device=x.device)
+        p1a, rn1a, p2a, rn2a = (new(rc, 2), new(1, 2), new(c0, 4), new(1, 4)) if save else (None,) * 4
+        p1b, rn1b = new(c1, 4), (new(1, 4) if save else None)
+        sn = ops.SmallNet(_imgs_per_wg(n))
+        sn.load(0, x)
+        sn.conv(0, 1, cache.get_sn(w1a, False), rc, rc, 2, 2, bias=b1a, lrelu=True).pixnorm(1, rc, 2, 2, p1a, rn1a)
+        sn.up(1, 2, rc, 2, 2)
+        sn.conv(2, 0, cache.get_sn(w2a, False), rc, c0, 4, 4, bias=b2a, lrelu=True).pixnorm(0, c0, 4, 4, p2a, rn2a)
+        sn.conv(0, 1, cache.get_sn(w1b, False), c0, c1, 4, 4, bias=b1b, lrelu=True).pixnorm(1, c1, 4, 4, p1b, rn1b)
+        sn.run(n)
+    for bi, (w1, b1, w2, b2) in enumerate(W.blocks):
         ci, co = w1.shape[0], w2.shape[0]
+        if head and bi == 0:
+            if save:
+                saved.append((x, rn1a, p1a, rn2a, p2a))
+            x_in_last, x = x, p2a
+            continue
         # only the normalised outputs p and the per-pixel 1/norm are kept: the backward derives mask and x_hat from p
-        p1, rn1 = cache.conv_lrelu_pixnorm(x, w1, b1, ci)
+        if head and bi == 1:
+            p1, rn1 = p1b, rn1b
+        else:
+            p1, rn1 = cache.conv_lrelu_pixnorm(x, w1, b1, ci)
         p2, rn2 = cache.conv_lrelu_pixnorm(p1, w2, b2, co, ups=True)
         if save:
             saved.append((x, rn1, p1, rn2, p2))
@@ -292,6 +357,31 @@ def gen_backward(W: GenWeights, ctx, g_out: torch.Tensor, cache: PackCache, sink
             gp1 = ops.upconv3x3_dgrad(gpre2, cache.get_up_dgrad(w2), ci)  # stride-2 4x4 form: no high-res intermediate
         else:
             gp1 = ops.upsample2x_bwd(cache.conv(gpre2, w2, True, None, ci))
+        if i == 1 and gen_head_ok(W, saved[0][0]):
+            # the data-gradient chain of the generator's first three convs in one launch; their weight gradients from the
+            # stored masked gradients
+            z, rn1a, p1a, rn2a, p2a = saved[0]
+            w1a, b1a, w2a, b2a = W.blocks[0]
+            n, rc, c0 = z.shape[0], z.shape[1], w2a.shape[0]
+            new = lambda c, s: torch.empty((n, c, s, s), dtype=torch.float32, device=z.device)
+            gpre1, gpre2a, gpre1a = new(ci, 4), new(c0, 4), new(rc, 2)
+            gz = new(rc, 2) if need_gz else None
+            sn = ops.SmallNet(_imgs_per_wg(n))
+            sn.load(0, gp1)
+            sn.pnbwd(0, ci, 4, 4, p1, rn1, out=gpre1)
+            sn.conv(0, 1, cache.get_sn(w1, True), ci, c0, 4, 4)
+            sn.pnbwd(1, c0, 4, 4, p2a, rn2a, out=gpre2a)
+            sn.conv(1, 2, cache.get_sn(w2a, True), c0, rc, 4, 4)
+            sn.upbwd(2, 0, rc, 4, 4)
+            sn.pnbwd(0, rc, 2, 2, p1a, rn1a, out=gpre1a)
+            if need_gz:
+                sn.conv(0, 1, cache.get_sn(w1a, True), rc, rc, 2, 2, out=gz)
+            sn.run(n)
+            for wt, bt, xi, gy, ups in ((w1, b1, xin, gpre1, False), (w2a, b2a, p1a, gpre2a, True), (w1a, b1a, z, gpre1a, False)):
+                gwt, acc = sink.slot(wt)
+                gbt, _ = sink.slot(bt)
+                ops.conv3x3_wgrad(xi, gy, gwt, gbt, ups=ups, accumulate=acc, defer=defer)
+            break
         gpre1 = ops.pixelnorm_lrelu_bwd(gp1, p1, rn1, from_p=True)
         gw1, acc = sink.slot(w1)
         gb1, _ = sink.slot(b1)
@@ -334,6 +424,8 @@ def _tile_mask_ok(n: int, cin: int, cout: int, h: int, w: int) -> bool:
     the penalty's tangent pass sends through the same layer again (MG_TILEMASK=0 keeps fp32 activations everywhere)."""
     if os.environ.get("MG_TILEMASK", "1") == "0" or (w % 4) or (h % 2):
         return False
+    if h <= 8 and w <= 8 and _smallnet_on():
+        return False  # the fused tail's un-pooling step reads the fp32 activation of the 8x8 layer
     return ops.wino3x3_supported(max(1, n // 3), cout, h, w, cin=cin)
 
 
@@ -346,6 +438,90 @@ def _fade_fused_ok(n: int, c1: int, c_next: int, h: int, w: int) -> bool:
     return ops.wino3x3_supported(nmin, c1, h, w, cin=c1) and ops.wino3x3_supported(nmin, c1, h, w, cin=c_next)
 
 
+def _disc_tail_forward(W: DiscWeights, t: int, q1: torch.Tensor, cache: PackCache, save: bool, masks=None):
+    """conv2 of block t (4x4), blocks t+1 (4x4 -> 2x2) and t+2 (2x2 -> 1x1) and the classifier in one launch.  Returns (scores,
+    [(a2_t,), (inp, a1, q1, a2) of block t+1, ... of block t+2]) -- the tuples only with `save`.
+    `masks` (the tangent pass of the penalty): the saved tuples of a forward pass; every conv is then bias-free, multiplied by
+    the LeakyReLU derivative of the saved activation, and written over it (q1 must be the tangent of block t's pooled output, in
+    place in the saved tensor); nothing is returned."""
+    n = q1.shape[0]
+    dev = q1.device
+    tangent = masks is not None
+    new = lambda c, s: torch.empty((n, c, s, s), dtype=torch.float32, device=dev)
+    sn = ops.SmallNet(_imgs_per_wg(n))
+    w1, b1, w2, b2 = W.blocks[t]
+    c1 = w1.shape[0]
+    sn.load(0, q1)
+    cur = 0
+    rest = []
+    a2 = masks[0][3] if tangent else (new(c1, 4) if save else None)
+    nxt = _rot(cur)[0]
+    sn.conv(cur, nxt, cache.get_sn(w2, False), c1, c1, 4, 4, bias=None if tangent else b2, lrelu=not tangent,
+            mask=a2 if tangent else None, out=a2)
+    rest.append((a2,))
+    cur, cin, h, inp = nxt, c1, 4, a2
+    for k, j in enumerate((t + 1, t + 2)):
+        w1, b1, w2, b2 = W.blocks[j]
+        c1 = w1.shape[0]
+        a1 = masks[k + 1][1] if tangent else (new(c1, h) if save else None)
+        qn = masks[k + 1][2] if tangent else (new(c1, h // 2) if save else None)
+        a2 = masks[k + 1][3] if tangent else (new(c1, h // 2) if save else None)
+        b_a, b_q = _rot(cur)
+        sn.conv(cur, b_a, cache.get_sn(w1, False), cin, c1, h, h, bias=None if tangent else b1, lrelu=not tangent,
+                mask=a1 if tangent else None, out=a1)
+        sn.pool(b_a, b_q, c1, h, h, out=qn)
+        sn.conv(b_q, cur, cache.get_sn(w2, False), c1, c1, h // 2, h // 2, bias=None if tangent else b2, lrelu=not tangent,
+                mask=a2 if tangent else None, out=a2)
+        rest.append((inp, a1, qn, a2))
+        cin, h, inp = c1, h // 2, a2
+    if tangent:
+        sn.run(n)
+        return None
+    out = torch.empty((n, 1), dtype=torch.float32, device=dev)
+    sn.linear(cur, cin, W.clf[0], W.clf[1], out)
+    sn.run(n)
+    return out, rest
+
+
+def _disc_tail_backward(W: DiscWeights, t: int, saved, g_out: torch.Tensor, cache: PackCache):
+    """The data-gradient chain of the same layers in one launch: classifier backward, LeakyReLU masks, transposed convs, AvgPool2d
+    backward, down to the masked gradient in front of block t's first conv (8x8, written straight to global memory).  Returns
+    {block index: (gpre1, gpre2)} for blocks t .. t+2 (what the weight gradients and the penalty's second-order pass consume)."""
+    n = g_out.shape[0]
+    dev = g_out.device
+    new = lambda c, s: torch.empty((n, c, s, s), dtype=torch.float32, device=dev)
+    sn = ops.SmallNet(_imgs_per_wg(n))
+    hs = {}
+    last = t + 2
+    c_last = W.blocks[last][0].shape[0]
+    gpre2 = new(c_last, 1)
+    sn.linbwd(0, c_last, g_out, W.clf[0])
+    sn.mask(0, c_last, 1, 1, saved[last][3], out=gpre2)
+    cur, h = 0, 1
+    for j in (last, last - 1):
+        w1, b1, w2, b2 = W.blocks[j]
+        c1, cin = w1.shape[0], w1.shape[1]
+        inp, a1, q1, a2 = saved[j]
+        gpre1 = new(c1, 2 * h)
+        gprev = new(cin, 2 * h)   # masked gradient behind the previous block's second conv
+        b_a, b_b = _rot(cur)
+        sn.conv(cur, b_a, cache.get_sn(w2, True), c1, c1, h, h)
+        sn.poolbwd(b_a, b_b, c1, h, h, a1, out=gpre1)
+        sn.conv(b_b, cur, cache.get_sn(w1, True), c1, cin, 2 * h, 2 * h, mask=saved[j - 1][3], out=gprev)
+        hs[j] = (gpre1, gpre2)
+        gpre2, h = gprev, 2 * h
+    w1, b1, w2, b2 = W.blocks[t]
+    c1 = w1.shape[0]
+    inp, a1, q1, a2 = saved[t]
+    gpre1 = new(c1, 8)
+    b_a, b_b = _rot(cur)
+    sn.conv(cur, b_a, cache.get_sn(w2, True), c1, c1, 4, 4)
+    sn.poolbwd(b_a, b_b, c1, 4, 4, a1, out=gpre1, lds=False)
+    hs[t] = (gpre1, gpre2)
+    sn.run(n)
+    return hs
+
+
 def disc_forward(W: DiscWeights, x: torch.Tensor, alpha: float, cache: PackCache, save: bool):
     x = x.contiguous()
     n = x.shape[0]
@@ -354,8 +530,19 @@ def disc_forward(W: DiscWeights, x: torch.Tensor, alpha: float, cache: PackCache
     saved = []
     inp = h0
     xp = o = None
+    tail = disc_tail_start(W, x.shape[2], x.shape[3])
     for i, (w1, b1, w2, b2) in enumerate(W.blocks):
         c1 = w1.shape[0]
+        if tail is not None and i == tail:
+            # this block's first conv (8x8) on its own, then everything behind it -- its second conv, the two last blocks and the
+            # classifier -- as ONE launch with the activations in LDS; the tensors the backward passes read are stored on the way
+            a1, q1 = cache.conv(inp, w1, False, b1, c1, lrelu=True, pool=True)
+            out, rest = _disc_tail_forward(W, tail, q1, cache, save)
+            if save:
+                saved.append((inp, a1, q1, rest[0][0]))
+                saved.extend(rest[1:])
+            flat = rest[-1][3].reshape(n, -1) if save else None
+            return out, ((x, h0, saved, xp, o, flat, alpha) if save else None)
         # AvgPool2d fused in the epilogue.  Of the full-resolution activation the backward passes only need the sign, so on the
         # large maps (Winograd kernel, for every batch slice that will come back with the mask) it is kept as one byte per
         # 2x2 tile and a1 is that uint8 tile mask (N,c1,H/2,W/2) instead of the fp32 tensor.
@@ -393,40 +580,65 @@ def disc_backward(W: DiscWeights, ctx, g_out: torch.Tensor, cache: PackCache, si
     F = FadeIn.of(alpha)
     g_out = g_out.contiguous()
     n = x.shape[0]
-    if sink is not None:
-        gwc, acc = sink.slot(W.clf[0])
-        gbc, _ = sink.slot(W.clf[1])
-        g = ops.linear1_bwd(flat, W.clf[0], g_out, gw=gwc, gb=gbc, accumulate=acc)
-    else:
-        g = ops.linear1_bwd(flat, W.clf[0], g_out, need_gx=True)
     nb = len(W.blocks)
     hs = {"blocks": [None] * nb, "stem": None, "old": None}
-    a2_last = saved[nb - 1][3]
-    g = g.reshape(a2_last.shape)
-    if nb == 1 and W.old_stem is not None:  # the blend is the classifier input
-        gpre2, gpre_o = ops.blend_lrelu_bwd(g, a2_last, o, F.a, F.b, coef=F.dev)
+    tail = disc_tail_start(W, x.shape[2], x.shape[3])
+    gpre_o = gpre_s = None
+    if tail is not None:
+        # classifier + the <= 4x4 layers in one launch, down to the masked gradient in front of block `tail`'s first conv; their
+        # weight gradients (if wanted) from the tensors it stored
+        ths = _disc_tail_backward(W, tail, saved, g_out, cache)
+        if sink is not None:
+            gwc, acc = sink.slot(W.clf[0])
+            gbc, _ = sink.slot(W.clf[1])
+            ops.linear1_bwd(flat, W.clf[0], g_out, gw=gwc, gb=gbc, need_gx=False, accumulate=acc)
+            for j in range(nb - 1, tail - 1, -1):
+                w1, b1, w2, b2 = W.blocks[j]
+                inp, a1, q1, a2 = saved[j]
+                gw2, acc = sink.slot(w2)
+                gb2, _ = sink.slot(b2)
+                ops.conv3x3_wgrad(q1, ths[j][1], gw2, gb2, accumulate=acc)
+                gw1, acc = sink.slot(w1)
+                gb1, _ = sink.slot(b1)
+                ops.conv3x3_wgrad(inp, ths[j][0], gw1, gb1, accumulate=acc)
+        for j in range(tail, nb):
+            hs["blocks"][j] = ths[j]
+        first, gpre2 = tail, None
     else:
-        gpre2 = ops.lrelu_bwd(g, a2_last)
-        gpre_o = None
-    gpre_s = None
-    for i in range(nb - 1, -1, -1):
+        if sink is not None:
+            gwc, acc = sink.slot(W.clf[0])
+            gbc, _ = sink.slot(W.clf[1])
+            g = ops.linear1_bwd(flat, W.clf[0], g_out, gw=gwc, gb=gbc, accumulate=acc)
+        else:
+            g = ops.linear1_bwd(flat, W.clf[0], g_out, need_gx=True)
+        a2_last = saved[nb - 1][3]
+        g = g.reshape(a2_last.shape)
+        if nb == 1 and W.old_stem is not None:  # the blend is the classifier input
+            gpre2, gpre_o = ops.blend_lrelu_bwd(g, a2_last, o, F.a, F.b, coef=F.dev)
+        else:
+            gpre2 = ops.lrelu_bwd(g, a2_last)
+        first = nb - 1
+    for i in range(first, -1, -1):
         w1, b1, w2, b2 = W.blocks[i]
         inp, a1, q1, a2 = saved[i]
         c1, cin = w1.shape[0], w1.shape[1]
-        if sink is not None:
-            gw2, acc = sink.slot(w2)
-            gb2, _ = sink.slot(b2)
-            ops.conv3x3_wgrad(q1, gpre2, gw2, gb2, accumulate=acc)
-        if a1.dtype == torch.uint8 and ops.wino3x3_supported(n, c1, gpre2.shape[2], gpre2.shape[3], cin=c1):
-            gpre1 = cache.conv(gpre2, w2, True, None, c1, unpool_mask=a1)  # AvgPool2d + LeakyReLU backward in the conv epilogue
+        if tail is not None and i == tail:
+            gpre1 = hs["blocks"][i][0]
         else:
-            gq1 = cache.conv(gpre2, w2, True, None, c1)
-            gpre1 = ops.avgpool2_bwd(gq1, a1)
-        if sink is not None:
-            gw1, acc = sink.slot(w1)
-            gb1, _ = sink.slot(b1)
-            ops.conv3x3_wgrad(inp, gpre1, gw1, gb1, accumulate=acc)
-        if keep_h:
+            if sink is not None:
+                gw2, acc = sink.slot(w2)
+                gb2, _ = sink.slot(b2)
+                ops.conv3x3_wgrad(q1, gpre2, gw2, gb2, accumulate=acc)
+            if a1.dtype == torch.uint8 and ops.wino3x3_supported(n, c1, gpre2.shape[2], gpre2.shape[3], cin=c1):
+                gpre1 = cache.conv(gpre2, w2, True, None, c1, unpool_mask=a1)  # AvgPool2d + LeakyReLU backward in the conv epilogue
+            else:
+                gq1 = cache.conv(gpre2, w2, True, None, c1)
+                gpre1 = ops.avgpool2_bwd(gq1, a1)
+            if sink is not None:
+                gw1, acc = sink.slot(w1)
+                gb1, _ = sink.slot(b1)
+                ops.conv3x3_wgrad(inp, gpre1, gw1, gb1, accumulate=acc)
+        if keep_h and hs["blocks"][i] is None:
             hs["blocks"][i] = (gpre1, gpre2)
         if i > 0:
             a2_prev = saved[i - 1][3]
@@ -538,6 +750,7 @@ def disc_step_fused(W: DiscWeights, x_real: torch.Tensor, x_fake: torch.Tensor, 
         ops.avgpool2_fwd(x[sl], out=xp[sl])
         ops.conv1x1(xp[sl], W.old_stem[0], None, W.old_stem[0].shape[0], mask_aux=o[sl], out=o[sl])
     nb = len(W.blocks)
+    tail = disc_tail_start(W, x.shape[2], x.shape[3])
     for i, (w1, b1, w2, b2) in enumerate(W.blocks):
         inp, a1, q1, a2 = saved[i]
         c1 = w1.shape[0]
@@ -545,6 +758,9 @@ def disc_step_fused(W: DiscWeights, x_real: torch.Tensor, x_fake: torch.Tensor, 
             cache.conv(inp[sl], w1, False, None, c1, mask_aux=a1[sl], pool_out=q1[sl])
         else:
             cache.conv(inp[sl], w1, False, None, c1, mask_aux=a1[sl], out=a1[sl], pool_out=q1[sl])
+        if tail is not None and i == tail:  # the rest of the tangent pass (<= 4x4 maps) in one launch, in place as well
+            _disc_tail_forward(W, tail, q1[sl], cache, False, masks=[tuple(u[sl] for u in saved[j]) for j in range(tail, nb)])
+            break
         if a2.dtype == torch.uint8:  # fade-in block with the blend fused: straight into the next block's input slice
             F = FadeIn.of(alpha)
             ops.conv3x3_fade(q1[sl], cache.get_wino(w2, False), None, c1, _lib.MG_FADE_TANGENT, o[sl], F.coef(x.device),
