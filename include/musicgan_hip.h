@@ -306,6 +306,21 @@ size_t mg_smallnet_buffer_floats(int imgs_per_wg, int C, int H, int W);
 int mg_smallnet(const mg_sn_op_t* ops, int nops, int N, int imgs_per_wg, size_t lds_floats_per_buffer, float slope,
                 mg_stream_t stream);
 
+/* One 3x3 convolution (the nn.Conv2d(3x3) + LeakyReLU / AvgPool2d / Upsample neighbours of mg_conv3x3 above) on maps of at
+ * most 8x8 as a latency-optimised launch: a workgroup takes a few images x ONE 16-out-channel tile, its waves split the input
+ * channels and have their whole filter share in flight at once (one memory round trip instead of Cin / 8 dependent ones).
+ * wpk: MG_PACK_SMALLNET filters (dgrad = 1 for the data gradient).  y (N,Cout,H,W) unless noted; flags:
+ *   MG_CONV_UPS_IN     x is (N,Cin,H/2,W/2), nearest-upsampled on the way in [generator.py:26-29]
+ *   MG_CONV_LRELU      y = leaky_relu(conv + bias);   MG_CONV_MASK_AUX   y = conv * lrelu'(aux), aux (N,Cout,H,W) (may alias y)
+ *   MG_CONV_POOL_OUT   also p (N,Cout,H/2,W/2) = AvgPool2d(2,2)(y) [discriminator.py:24];  y may be NULL
+ *   MG_CONV_UPSUM_OUT  also p = 2x2 block SUMS of y (backward of the nearest upsampling in front of the forward conv)
+ *   MG_CONV_UNPOOL     alone: y is (N,Cout,2H,2W) = 0.25 * up2(conv) * lrelu'(aux), aux fp32 of that shape (AvgPool2d backward +
+ *                      LeakyReLU backward of the layer below; mg_wino3x3's flag of this name takes tile-mask bytes instead) */
+#define MG_CONV_UPSUM_OUT 256
+int mg_conv3x3_small_supported(int N, int Cin, int Cout, int H, int W);
+int mg_conv3x3_small(const float* x, const float* wpk, const float* bias, const float* aux, float* y, float* p, int N, int Cin,
+                     int Cout, int H, int W, int flags, float slope, mg_stream_t stream);
+
 /* ------------------------------------------------------------------ magnitude/phase codec + inverse STFT
  * mg_codec_fwd: stft_to_phase_magn [audio/functions.py:65-94].  stft_c64: interleaved complex64 [512][T] (mg_stft_1024 output);
  * bark_scale: [512] unit-norm bark vector (functions.py:26-35); outputs [S][512][nb_vec], S = (T-1)/nb_vec, both in [-1,1].

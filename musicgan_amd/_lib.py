@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmusicgan_hip.so")
 
 MG_CONV_UPS_IN, MG_CONV_LRELU, MG_CONV_MASK_AUX, MG_CONV_PIXNORM, MG_CONV_POOL_OUT = 1, 2, 4, 8, 16
-MG_CONV_MASK_OUT, MG_CONV_MASK_BYTES, MG_CONV_UNPOOL = 32, 64, 128
+MG_CONV_MASK_OUT, MG_CONV_MASK_BYTES, MG_CONV_UNPOOL, MG_CONV_UPSUM_OUT = 32, 64, 128, 256
 MG_FADE_FWD, MG_FADE_TANGENT, MG_FADE_BWD = 1, 2, 3
 MG_C1_LRELU, MG_C1_TANH, MG_C1_MASK_AUX, MG_C1_TRANSPOSED, MG_C1_TANH_BWD_IN = 1, 2, 4, 8, 16
 
@@ -111,6 +111,8 @@ SIGNATURES = {
     "mg_adam_step": (c_int, [_P, c_int, c_float, c_float, c_float, c_float, _P]),
     "mg_group_means": (c_int, [_P, c_int, c_int, _P, _P]),
     "mg_pack_multi": (c_int, [_P, c_int, _P]),
+    "mg_conv3x3_small_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "mg_conv3x3_small": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "mg_smallnet_packed_floats": (c_size_t, [c_int, c_int]),
     "mg_smallnet_buffer_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "mg_smallnet": (c_int, [_P, c_int, c_int, c_int, c_size_t, c_float, _P]),

@@ -17,8 +17,12 @@
 // covers all pixels.  Point-wise / pooling / normalisation steps are small LDS passes between barriers; every tensor a later
 // pass needs goes to global memory from the op that produces it.  1x1 maps take the centre tap with fp64 accumulation on the
 // vector ALU (as conv3x3_tiny does: the classifier's gradient inherits the round-off of these sums one to one).
+#include <cstdlib>
+
 #include "mg_common.h"
 #include "pack_kernels.h"
+
+extern "C" size_t mg_smallnet_buffer_floats(int imgs_per_wg, int C, int H, int W);
 
 namespace {
 
@@ -57,6 +61,48 @@ __device__ __forceinline__ void for_slots(const Geo& g, int G, F f) {
   }
 }
 
+// G images (N, C, Hin, Win) -> LDS [slot][channel] with zero halo / zero pad channels; `ups`: nearest-upsampled x2 on the way.
+// Loads in batches of 8 per thread, all issued before the first LDS store (left to itself hipcc waits for every load before it
+// issues the next: one memory round trip per element), in global order (coalesced); the zero fill touches other addresses.
+__device__ __forceinline__ void stage_images(const float* __restrict__ x, float* xs, const Geo& g, int G, int C, int img0, int N,
+                                             bool ups) {
+  const int Hin = ups ? g.H >> 1 : g.H, Win = ups ? g.W >> 1 : g.W;
+  const int nimg = N - img0 < G ? N - img0 : G;
+  const int per = C * g.HW, total = nimg * per;
+  const float* xb = x + (size_t)img0 * C * (Hin * Win);
+  for (int base = threadIdx.x; base < total; base += SN_THREADS * 8) {
+    float v[8];
+    int dst[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int e = base + u * SN_THREADS;
+      const bool ok = e < total;
+      e = ok ? e : 0;
+      const int nl = e / per, r = e - nl * per, c = r / g.HW, pr = r - c * g.HW, y = pr / g.W, xx = pr - y * g.W;
+      const int srci = ups ? (nl * C + c) * (Hin * Win) + (y >> 1) * Win + (xx >> 1) : e;
+      v[u] = xb[srci];
+      dst[u] = ok ? g.slot(nl, y, xx) * g.CS + c : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (dst[u] >= 0) xs[dst[u]] = v[u];
+  }
+  // halo ring (all padded channels), pad channels of interior pixels, images past the batch: zero
+  const int quads = g.CP / 4, slots = G * g.SPI;
+  for (int e = threadIdx.x; e < slots * quads; e += SN_THREADS) {
+    const int cq = e % quads, sl = e / quads;
+    const int nl = sl / g.SPI, r = sl - nl * g.SPI, yy = r / g.W2, xx = r - yy * g.W2;
+    const bool inside = yy >= 1 && yy <= g.H && xx >= 1 && xx <= g.W && nl < nimg;
+    if (!inside) {
+      *reinterpret_cast<f32x4*>(xs + sl * g.CS + cq * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else if (cq * 4 + 4 > C) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (cq * 4 + i >= C) xs[sl * g.CS + cq * 4 + i] = 0.f;
+    }
+  }
+}
+
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -65,54 +111,79 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 
 // ------------------------------------------------------------------------------------------------ the convolution core
 // acc[j][nt] += sum over (channel group g, tap t) of A(g, t, tile mt0 + 4 j) x B(pixel tile nt shifted by tap t, group g)
-template <int MTW, int NTW>
-__device__ __forceinline__ void conv_core(const float* __restrict__ wpk, const float* src, int KG, int MT, int mt0, int CS, int W2,
-                                          const int (&boff)[NTW], f32x4 (&acc)[MTW][NTW]) {
-  const int lane = threadIdx.x & 63;
-  const float* wl = wpk + (size_t)mt0 * 256 + lane * 4;
-  const size_t gstride = (size_t)9 * MT * 256;
-  f32x4 ring[9][MTW];
-#pragma unroll
-  for (int t = 0; t < 9; ++t) {
-#pragma unroll
-    for (int j = 0; j < MTW; ++j) ring[t][j] = *reinterpret_cast<const f32x4*>(wl + ((size_t)t * MT + 4 * j) * 256);
-    // issued in the order the loop consumes them: the wait in front of step t is then a counted one on both ways into the loop
-    // (the scheduler had put slot 0 last: vmcnt(0) at the top of every iteration)
-    __builtin_amdgcn_sched_barrier(0);
+// The filter ring of one wave: 9 taps x MTW out-channel tiles of ONE input-channel group, as buffer loads: address = base +
+// per-lane offset (one VGPR, set once) + a scalar offset per (group, tap, tile).  fp32 MFMA and vector-ALU time add up on
+// gfx950, so the 64-bit per-lane pointer arithmetic of plain global loads (~8 vector instructions per step) came straight out
+// of the matrix rate.
+template <int MTW>
+struct FilterRing {
+  f32x4 r[9][MTW];
+  __amdgpu_buffer_rsrc_t rs;
+  int voff, MT;
+  __device__ __forceinline__ void init(const float* wpk, int KG, int MT_, int mt0) {
+    rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wpk), 0, KG * 9 * MT_ * 1024, 0x00020000);
+    voff = (mt0 * 256 + (threadIdx.x & 63) * 4) * 4;
+    MT = MT_;
   }
+  __device__ __forceinline__ f32x4 load(int g, int t, int j) const {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, ((g * 9 + t) * MT + 4 * j) * 1024, 0));
+  }
+  // group g0's filters, issued in the order the loop consumes them: the wait in front of step t is then a counted one on both
+  // ways into the loop (the scheduler had put slot 0 last: vmcnt(0) at the top of every iteration)
+  __device__ __forceinline__ void fill(int g0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int j = 0; j < MTW; ++j) r[t][j] = load(g0, t, j);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+};
+
+// acc[j][nt] += sum over (channel group g0 <= g < g1, tap t) of A(g, t, tile mt0 + 4 j) x B(pixel tile nt shifted by tap t, group
+// g); all groups when the waves split the out-channel tiles, a quarter when they split K.  `F` holds group g0 (FilterRing::fill).
+template <int MTW, int NTW>
+__device__ __forceinline__ void conv_core(FilterRing<MTW>& F, const float* src, int g0, int g1, int CS, int W2, const int (&boff)[NTW],
+                                          f32x4 (&acc)[MTW][NTW]) {
+  if (g0 >= g1) return;
+  auto& ring = F.r;
+  auto wload = [&](int g, int t, int j) __attribute__((always_inline)) { return F.load(g, t, j); };
   int toff[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) toff[t] = ((t / 3 - 1) * W2 + (t % 3 - 1)) * CS;
-  f32x4 b[2][NTW];
+  f32x4 b[3][NTW];  // activation fragments, three deep: nine steps per group, so slot (t % 3) lines up across groups
 #pragma unroll
-  for (int nt = 0; nt < NTW; ++nt) b[0][nt] = *reinterpret_cast<const f32x4*>(src + boff[nt] + toff[0]);
-  for (int g = 0; g < KG; ++g) {
+  for (int nt = 0; nt < NTW; ++nt) b[0][nt] = *reinterpret_cast<const f32x4*>(src + boff[nt] + toff[0] + g0 * 16);
+  for (int g = g0; g < g1; ++g) {
     // Step (g, t): the activation fragment of the NEXT step is requested, the MFMAs of this one are issued, and its ring slot is
     // re-requested with the next group's filters (the last group re-requests itself: 9 x MTW KB nobody waits for) -- in that
     // order, pinned per step: left alone the scheduler sinks all re-requests to the end of the loop body (shorter live ranges)
     // and the next iteration opens with vmcnt(0), i.e. a memory round trip per channel group with the matrix pipe idle.
-    const int gn = g + 1 < KG ? g + 1 : g;
-    const float* wn = wl + (size_t)gn * gstride;
+    const int gn = g + 1 < g1 ? g + 1 : g;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const int cur = t & 1, nxt = cur ^ 1;
+      const int cur = t % 3, nxt = (t + 1) % 3;
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt)
         b[nxt][nt] = *reinterpret_cast<const f32x4*>(src + boff[nt] + (t < 8 ? toff[t + 1] + g * 16 : toff[0] + gn * 16));
+      __builtin_amdgcn_sched_barrier(0);  // (else the reads sink below the MFMAs and the next step opens with their latency)
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int j = 0; j < MTW; ++j)
 #pragma unroll
           for (int nt = 0; nt < NTW; ++nt)
+#ifdef SN_NO_MFMA  // ablation build (tools/bench_smallnet.py): the filter stream alone
+            acc[j][nt][s] += ring[t][j][s] * b[cur][nt][s];
+#else
             acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[t][j][s], b[cur][nt][s], acc[j][nt], 0, 0, 0);
+#endif
+#ifndef SN_NO_STREAM  // ablation build: the matrix instructions alone (the ring keeps the first group's filters)
 #pragma unroll
-      for (int j = 0; j < MTW; ++j) ring[t][j] = *reinterpret_cast<const f32x4*>(wn + ((size_t)t * MT + 4 * j) * 256);
+      for (int j = 0; j < MTW; ++j) ring[t][j] = wload(gn, t, j);
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
-    // (nine steps per iteration is odd: the fragment buffers swap roles every iteration, so rotate them back)
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) b[0][nt] = b[1][nt];
     // The filters are read-only memory, so without this the compiler replaces the ring by "load the current step, wait, use"
     // (fewer live registers, every step a full memory round trip).  Behind a memory clobber it cannot re-load what it holds.
     asm volatile("" ::: "memory");
@@ -153,7 +224,10 @@ __device__ __forceinline__ void conv_tiles(const mg_sn_op_t& o, const float* src
   for (int j = 0; j < MTW; ++j)
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) acc[j][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  conv_core<MTW, NTW>(o.in, src, KG, MT, mt0, gi.CS, gi.W2, boff, acc);
+  FilterRing<MTW> F;
+  F.init(o.in, KG, MT, mt0);
+  F.fill(0);
+  conv_core<MTW, NTW>(F, src, 0, KG, gi.CS, gi.W2, boff, acc);
 #pragma unroll
   for (int j = 0; j < MTW; ++j) {
     const int oc0 = (mt0 + 4 * j) * 16 + 4 * q;
@@ -253,11 +327,7 @@ __global__ void __launch_bounds__(SN_THREADS) smallnet_k(const SnProgram P) {
     switch (o.op) {
       case MG_SN_LOAD: {
         const Geo g(o.C, o.H, o.W);
-        for_slots(g, G, [&](int s, int nl, int y, int x, int c, bool in) {
-          float v = 0.f;
-          if (in && c < o.C && img0 + nl < N) v = o.in[((size_t)(img0 + nl) * o.C + c) * g.HW + y * g.W + x];
-          dst[s * g.CS + c] = v;
-        });
+        stage_images(o.in, dst, g, G, o.C, img0, N, false);
         break;
       }
       case MG_SN_STORE: {
@@ -415,7 +485,152 @@ __global__ void __launch_bounds__(SN_THREADS) smallnet_k(const SnProgram P) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ one layer, whole chip
+// The same convolution as ONE launch per layer for maps of at most 8x8 with few images (mg_conv3x3_small): a workgroup takes G
+// images x ONE 16-out-channel tile, stages the images' input channels in LDS ([slot][channel], as above), and its four waves
+// split the input-channel groups (split-K), so a wave's whole filter share -- 2-3 groups x 9 taps x 1 KB -- is in flight from
+// the first instruction: one memory round trip, a few dozen MFMAs, a partial-sum exchange through LDS and the epilogue.  The
+// direct kernel of conv3x3.hip walks the same K as 16 dependent chunk round trips (13-16 us on these layers, whatever their
+// size).  Epilogues: bias + LeakyReLU, LeakyReLU-derivative mask, AvgPool2d / 2x2 block sums of the result as a second output,
+// AvgPool2d backward x mask as the output, nearest-upsampled input.
+struct ScArgs {
+  const float* x;
+  const float* wpk;
+  const float* bias;
+  const float* aux;
+  float* y;
+  float* p;
+  int N, Cin, Cout, H, W, flags, G;
+  float slope, pool_scale;
+};
+constexpr int SC_UNPOOL = 1 << 20;  // internal: y is (N, Cout, 2H, 2W) = 0.25 * result * lrelu'(aux), aux of that shape
+
+template <int NTW>
+__global__ void __launch_bounds__(SN_THREADS) smallconv_k(const ScArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int G = a.G, img0 = blockIdx.x * G, mt = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const Geo gi(a.Cin, a.H, a.W);
+  const int MT = sn_cp(a.Cout) / 16, KG = gi.CP / 16;
+  float* xs = smem;
+  f32x4* part = reinterpret_cast<f32x4*>(smem + (size_t)G * gi.SPI * gi.CS);  // [4 waves][NTW][64]
+  float* tile = reinterpret_cast<float*>(part + 4 * NTW * 64);                  // [16 out-channels][NTW * 16 + 1] (pooling)
+  // the wave's first filter group is requested before the images are staged: both round trips run at once
+  const int g0 = KG * wave / 4, g1 = KG * (wave + 1) / 4;
+  FilterRing<1> F;
+  F.init(a.wpk, KG, MT, mt);
+  if (g0 < g1) F.fill(g0);
+  stage_images(a.x, xs, gi, G, a.Cin, img0, a.N, a.flags & MG_CONV_UPS_IN);
+  __syncthreads();
+  const int npx = G * gi.HW;
+  const int col = lane & 15, q = lane >> 4;
+  int boff[NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    const int px = nt * 16 + col;
+    boff[nt] = gi.slot_px(px < npx ? px : 0) * gi.CS + 4 * q;
+  }
+  f32x4 acc[1][NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) acc[0][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  conv_core<1, NTW>(F, xs, g0, g1, gi.CS, gi.W2, boff, acc);
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) part[(wave * NTW + nt) * 64 + lane] = acc[0][nt];
+  __syncthreads();
+  const bool pool = a.flags & MG_CONV_POOL_OUT;
+  constexpr int TS = NTW * 16 + 1;
+  for (int idx = threadIdx.x; idx < NTW * 64; idx += SN_THREADS) {
+    const int nt = idx >> 6, l = idx & 63;
+    f32x4 v = (part[nt * 64 + l] + part[(NTW + nt) * 64 + l]) + (part[(2 * NTW + nt) * 64 + l] + part[(3 * NTW + nt) * 64 + l]);
+    const int px = nt * 16 + (l & 15), oc0 = mt * 16 + 4 * (l >> 4);
+    const int nl = px / gi.HW, pr = px - nl * gi.HW;
+    const bool ok = px < npx && img0 + nl < a.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int oc = oc0 + i;
+      float r = v[i];
+      if (a.bias != nullptr && oc < a.Cout) r += a.bias[oc];
+      if (a.flags & MG_CONV_LRELU) r = mg_lrelu(r, a.slope);
+      if (ok && oc < a.Cout) {
+        const size_t o = ((size_t)(img0 + nl) * a.Cout + oc) * gi.HW + pr;
+        if (a.flags & SC_UNPOOL) {
+          const int y = pr / a.W, x = pr - y * a.W, W2o = 2 * a.W;
+          const size_t o2 = ((size_t)(img0 + nl) * a.Cout + oc) * (4 * gi.HW) + (size_t)(2 * y) * W2o + 2 * x;
+          const float2 m0 = *reinterpret_cast<const float2*>(a.aux + o2), m1 = *reinterpret_cast<const float2*>(a.aux + o2 + W2o);
+          const float h = 0.25f * r;
+          *reinterpret_cast<float2*>(a.y + o2) = make_float2(h * mg_lrelu_mask(m0.x, a.slope), h * mg_lrelu_mask(m0.y, a.slope));
+          *reinterpret_cast<float2*>(a.y + o2 + W2o) = make_float2(h * mg_lrelu_mask(m1.x, a.slope), h * mg_lrelu_mask(m1.y, a.slope));
+        } else {
+          if (a.flags & MG_CONV_MASK_AUX) r *= mg_lrelu_mask(a.aux[o], a.slope);
+          if (a.y != nullptr) a.y[o] = r;
+        }
+      }
+      if (pool) tile[(4 * (l >> 4) + i) * TS + px] = r;
+    }
+  }
+  if (pool) {  // second output: 2x2 block means (AvgPool2d) or sums (nearest-upsample backward) of the result
+    __syncthreads();
+    const int Hp = a.H >> 1, Wp = a.W >> 1, HWp = Hp * Wp;
+    for (int e = threadIdx.x; e < 16 * G * HWp; e += SN_THREADS) {
+      const int ocl = e / (G * HWp), r = e - ocl * (G * HWp);
+      const int nl = r / HWp, pp = r - nl * HWp, yy = pp / Wp, xx = pp - yy * Wp;
+      const int oc = mt * 16 + ocl;
+      if (oc < a.Cout && img0 + nl < a.N) {
+        const float* t0 = tile + ocl * TS + nl * gi.HW + (2 * yy) * a.W + 2 * xx;
+        a.p[((size_t)(img0 + nl) * a.Cout + oc) * HWp + pp] = ((t0[0] + t0[1]) + (t0[a.W] + t0[a.W + 1])) * a.pool_scale;
+      }
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int mg_conv3x3_small_supported(int N, int Cin, int Cout, int H, int W) {
+  return H >= 2 && W >= 2 && H <= 8 && W <= 8 && H * W <= 64 && Cin <= 192 && Cout <= 192 && N > 0;
+}
+
+extern "C" int mg_conv3x3_small(const float* x, const float* wpk, const float* bias, const float* aux, float* y, float* p, int N,
+                                int Cin, int Cout, int H, int W, int flags, float slope, mg_stream_t stream) {
+  MG_CHECK_ARG(x && wpk && N > 0 && mg_conv3x3_small_supported(N, Cin, Cout, H, W), "mg_conv3x3_small: unsupported shape");
+  const bool pool = flags & (MG_CONV_POOL_OUT | MG_CONV_UPSUM_OUT), unpool = flags & MG_CONV_UNPOOL;
+  MG_CHECK_ARG(!(flags & ~(MG_CONV_UPS_IN | MG_CONV_LRELU | MG_CONV_MASK_AUX | MG_CONV_POOL_OUT | MG_CONV_UPSUM_OUT | MG_CONV_UNPOOL)),
+               "mg_conv3x3_small: unsupported flags %d", flags);
+  MG_CHECK_ARG(!pool || (p && (H % 2) == 0 && (W % 2) == 0), "mg_conv3x3_small: pooled output needs p and an even map");
+  MG_CHECK_ARG(!((flags & MG_CONV_UPS_IN) && ((H % 2) || (W % 2))), "mg_conv3x3_small: upsampled input needs an even map");
+  MG_CHECK_ARG(!(unpool || (flags & MG_CONV_MASK_AUX)) || aux, "mg_conv3x3_small: mask without a source");
+  MG_CHECK_ARG(!unpool || (y && !pool && !(flags & (MG_CONV_MASK_AUX | MG_CONV_LRELU))), "mg_conv3x3_small: UNPOOL stands alone");
+  MG_CHECK_ARG(y || pool, "mg_conv3x3_small: no output");
+  ScArgs a;
+  a.x = x; a.wpk = wpk; a.bias = bias; a.aux = aux; a.y = y; a.p = p;
+  a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.slope = slope;
+  a.flags = (flags & (MG_CONV_UPS_IN | MG_CONV_LRELU | MG_CONV_MASK_AUX)) | (pool ? MG_CONV_POOL_OUT : 0) | (unpool ? SC_UNPOOL : 0);
+  a.pool_scale = (flags & MG_CONV_UPSUM_OUT) ? 1.0f : 0.25f;
+  const int MT = mg_cdiv(Cout, 16), HW = H * W;
+  // Images per workgroup: enough to fill one 16-pixel tile (2x2 maps: 4 -- the matrix instructions cost the same with 4 or 16
+  // live columns), then doubled while the grid is beyond ~768 workgroups (every workgroup re-reads its out-channel tile's
+  // filters: past a few workgroups per CU that traffic, not latency, is the run time), at most 64 pixels.
+  static const int wg_target = getenv("MG_SMALLCONV_WGS") ? atoi(getenv("MG_SMALLCONV_WGS")) : 768;
+  int G = 16 / HW > 1 ? 16 / HW : 1;
+  if (G > N) G = N;
+  while (mg_cdiv(N, G) * MT > wg_target && 2 * G * HW <= 64) G *= 2;
+  while (G > 1 && mg_cdiv(G * HW, 16) == 3) --G;  // 48 pixels would need three pixel tiles: instantiated for 1, 2, 4
+  a.G = G;
+  const int NTW = mg_cdiv(G * HW, 16) <= 1 ? 1 : (mg_cdiv(G * HW, 16) == 2 ? 2 : 4);
+  const size_t lds = (mg_smallnet_buffer_floats(G, Cin, H, W) + (size_t)4 * NTW * 64 * 4 + (size_t)16 * (NTW * 16 + 1)) * sizeof(float);
+  MG_CHECK_ARG(lds <= 160 * 1024, "mg_conv3x3_small: %zu bytes of LDS", lds);
+  static MgPerDevice once;
+  if (mg_first_use_on_device(once)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&smallconv_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&smallconv_k<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&smallconv_k<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  const dim3 grid((unsigned)mg_cdiv(N, G), (unsigned)MT);
+  if (NTW == 1) hipLaunchKernelGGL(smallconv_k<1>, grid, dim3(SN_THREADS), lds, (hipStream_t)stream, a);
+  else if (NTW == 2) hipLaunchKernelGGL(smallconv_k<2>, grid, dim3(SN_THREADS), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(smallconv_k<4>, grid, dim3(SN_THREADS), lds, (hipStream_t)stream, a);
+  MG_CHECK_LAUNCH("mg_conv3x3_small");
+  return MG_OK;
+}
 
 extern "C" size_t mg_smallnet_packed_floats(int Cin, int Cout) { return pack_smallnet_total(Cout, Cin, 0); }
 

@@ -102,9 +102,45 @@ class PackCache:
         """ops.conv3x3 with the kernel chosen per shape: Winograd F(2x2,3x3) where it is supported and pays (large maps, no
         fused up-sampling), the direct implicit GEMM otherwise.  Only the form that is used gets packed."""
         n, cin, h, wd = x.shape
+        if self.small_ok(x, cout, **kw):
+            # <= 4x4 maps (default) of a few images: the latency-optimised one-layer kernel (split-K over the waves, the whole
+            # filter share of a wave in flight at once; a fused AvgPool2d is a second output of the same launch)
+            pool = kw.get("pool", False) or kw.get("pool_out") is not None
+            return ops.conv3x3_small(x, self.get_sn(w, dgrad), bias, cout, ups=kw.get("ups", False), lrelu=kw.get("lrelu", False),
+                                     mask_aux=kw.get("mask_aux"), out=kw.get("out"), pool=pool, pool_out=kw.get("pool_out"))
         if ops.wino3x3_supported(n, cout, h, wd, ups=kw.get("ups", False), pixnorm=kw.get("pixnorm", False), cin=cin):
             return ops.conv3x3(x, None, bias, cout, wino=self.get_wino(w, dgrad), **kw)
         return ops.conv3x3(x, self.get(w, dgrad), bias, cout, **kw)
+
+    @staticmethod
+    def small_ok(x: torch.Tensor, cout: int, **kw) -> bool:
+        """Whether `conv` routes this call to ops.conv3x3_small: supported epilogue (no PixelNorm / tile masks), output map within
+        MG_SMALLCONV_MAX_SIDE (default 4) and few enough pixels to be latency-bound (MG_SMALLCONV_MAX_PIXELS, default 1536)."""
+        if kw.get("pixnorm") or kw.get("mask_out") or kw.get("unpool_mask") is not None or kw.get("want_y", True) is False:
+            return False
+        m = kw.get("mask_aux")
+        if m is not None and m.dtype != torch.float32:
+            return False
+        n, cin, h, wd = x.shape
+        if kw.get("ups"):
+            h, wd = 2 * h, 2 * wd
+        side = int(os.environ.get("MG_SMALLCONV_MAX_SIDE", "4"))
+        if h > side or wd > side or n * h * wd > int(os.environ.get("MG_SMALLCONV_MAX_PIXELS", "1536")):
+            return False
+        return ops.conv3x3_small_supported(n, cin, cout, h, wd)
+
+    def conv_unpool(self, gy: torch.Tensor, w: torch.Tensor, cout: int, act: torch.Tensor) -> torch.Tensor:
+        """0.25 * up2(dgrad-conv(gy, w)) * lrelu'(act): the data gradient through conv -> LeakyReLU -> AvgPool2d back to the
+        pre-activation of the layer in front of the pool (act: its fp32 activation, 2H x 2W) -- one launch on small maps."""
+        if act.dtype == torch.float32 and self.small_ok(gy, cout):
+            return ops.conv3x3_small(gy, self.get_sn(w, True), None, cout, unpool_aux=act)
+        return ops.avgpool2_bwd(self.conv(gy, w, True, None, cout), act)
+
+    def conv_upsum(self, gy: torch.Tensor, w: torch.Tensor, cout: int) -> torch.Tensor:
+        """2x2 block sums of dgrad-conv(gy, w): the data gradient through Upsample(x2) -> conv back to the low-resolution input."""
+        if self.small_ok(gy, cout):
+            return ops.conv3x3_small(gy, self.get_sn(w, True), None, cout, upsum=True, want_y=False)[1]
+        return ops.upsample2x_bwd(self.conv(gy, w, True, None, cout))
 
     def conv_lrelu_pixnorm(self, x: torch.Tensor, w: torch.Tensor, bias, cout: int, ups: bool = False):
         """conv3x3 (+ nearest x2 up-sampling of its input) + LeakyReLU + PixelNorm -> (p, 1/norm).  The fused kernels keep all
@@ -202,7 +238,10 @@ _COEF: Dict[tuple, torch.Tensor] = {}
 # first blocks as ONE launch per pass instead of 6-10 (MG_SMALLNET=0: one launch per layer everywhere)
 # =====================================================================================================================
 def _smallnet_on() -> bool:
-    return os.environ.get("MG_SMALLNET", "1") != "0"
+    """Opt-in (MG_SMALLNET=1): measured on the MI355X, one CU per image through the whole chain (80-110 us per pass) loses to
+    the per-layer launches it replaces (75-80 us with the direct kernel, ~45 with ops.conv3x3_small): a CU's fp32 matrix rate
+    and its ~70 GB/s filter stream bound the chain, while a per-layer launch spreads each layer over the chip."""
+    return os.environ.get("MG_SMALLNET", "0") == "1"
 
 
 def _imgs_per_wg(n: int) -> int:
@@ -356,7 +395,7 @@ def gen_backward(W: GenWeights, ctx, g_out: torch.Tensor, cache: PackCache, sink
         if ops.upconv3x3_dgrad_supported(p1.shape[2], p1.shape[3], gpre2.numel(), p1.shape[0]):
             gp1 = ops.upconv3x3_dgrad(gpre2, cache.get_up_dgrad(w2), ci)  # stride-2 4x4 form: no high-res intermediate
         else:
-            gp1 = ops.upsample2x_bwd(cache.conv(gpre2, w2, True, None, ci))
+            gp1 = cache.conv_upsum(gpre2, w2, ci)
         if i == 1 and gen_head_ok(W, saved[0][0]):
             # the data-gradient chain of the generator's first three convs in one launch; their weight gradients from the
             # stored masked gradients
@@ -632,8 +671,7 @@ def disc_backward(W: DiscWeights, ctx, g_out: torch.Tensor, cache: PackCache, si
             if a1.dtype == torch.uint8 and ops.wino3x3_supported(n, c1, gpre2.shape[2], gpre2.shape[3], cin=c1):
                 gpre1 = cache.conv(gpre2, w2, True, None, c1, unpool_mask=a1)  # AvgPool2d + LeakyReLU backward in the conv epilogue
             else:
-                gq1 = cache.conv(gpre2, w2, True, None, c1)
-                gpre1 = ops.avgpool2_bwd(gq1, a1)
+                gpre1 = cache.conv_unpool(gpre2, w2, c1, a1)
             if sink is not None:
                 gw1, acc = sink.slot(w1)
                 gb1, _ = sink.slot(b1)

@@ -440,6 +440,40 @@ class SmallNet:
         self.keep = []
 
 
+def conv3x3_small_supported(n: int, cin: int, cout: int, h: int, w: int) -> bool:
+    """Whether the latency-optimised one-layer kernel (mg_conv3x3_small) takes this shape and should: maps of 2x2 .. 8x8 with few
+    enough pixels that the layer is latency-bound (MG_SMALLCONV=0 switches it off, MG_SMALLCONV_MAX_PIXELS moves the bound)."""
+    if os.environ.get("MG_SMALLCONV", "1") == "0":
+        return False
+    if not _lib.load().mg_conv3x3_small_supported(n, cin, cout, h, w):
+        return False
+    return n * h * w <= int(os.environ.get("MG_SMALLCONV_MAX_PIXELS", "8192"))
+
+
+def conv3x3_small(x, wpk, bias, cout: int, *, ups=False, lrelu=False, mask_aux=None, out=None, pool=False, upsum=False,
+                  unpool_aux=None, pool_out=None, want_y=True):
+    """3x3 convolution on a small map through mg_conv3x3_small (wpk: PackCache.get_sn).  Returns y; (y, p) with `pool` (p =
+    AvgPool2d(2,2)(y)) or `upsum` (p = 2x2 block sums of y); with `unpool_aux` (N,cout,2H,2W) the un-pooled, masked tensor of
+    that shape (AvgPool2d backward + LeakyReLU backward).  `out` receives y (may alias mask_aux); want_y=False skips y."""
+    _chk(x, wpk, bias, mask_aux, out, unpool_aux, pool_out)
+    n, cin, hin, win = x.shape
+    h, w = (2 * hin, 2 * win) if ups else (hin, win)
+    pool = pool or (pool_out is not None and not upsum)
+    flags = (MG_CONV_UPS_IN if ups else 0) | (MG_CONV_LRELU if lrelu else 0) | (MG_CONV_MASK_AUX if mask_aux is not None else 0) | \
+        (MG_CONV_POOL_OUT if pool else 0) | (_lib.MG_CONV_UPSUM_OUT if upsum else 0) | (_lib.MG_CONV_UNPOOL if unpool_aux is not None else 0)
+    aux = unpool_aux if unpool_aux is not None else mask_aux
+    p = None
+    if unpool_aux is not None:
+        y = torch.empty((n, cout, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+    else:
+        y = out if out is not None else (torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device) if want_y else None)
+    if pool or upsum:
+        p = pool_out if pool_out is not None else torch.empty((n, cout, h // 2, w // 2), dtype=torch.float32, device=x.device)
+    check(_lib.load().mg_conv3x3_small(_p(x), _p(wpk), _p(bias), _p(aux), _p(y), _p(p), n, cin, cout, h, w, flags, SLOPE, _s()),
+          "mg_conv3x3_small")
+    return (y, p) if (pool or upsum) else y
+
+
 def pack_smallnet(w: torch.Tensor, dgrad: bool) -> torch.Tensor:
     """Filters of a 3x3 convolution in the operand order mg_smallnet streams (MG_PACK_SMALLNET)."""
     _chk(w)

@@ -235,3 +235,46 @@ def test_smallnet_rejects_what_does_not_fit():
     sn.conv(0, 1, ops.pack_smallnet(torch.zeros(16, 16, 3, 3, device=DEV), False), 16, 16, 16, 16)
     with pytest.raises(_lib.MusicGanHipError):
         sn.run(2)   # 256 pixels per workgroup
+
+
+@pytest.mark.parametrize("n", [1, 5, 24, 70, 200])
+def test_conv3x3_small_every_epilogue(n):
+    """mg_conv3x3_small (one layer per launch, split-K over the waves) against float64 F.conv2d on 2x2, 4x4, 8x8 and non-square
+    maps: bias + LeakyReLU, the LeakyReLU-derivative mask written in place over its source, AvgPool2d / 2x2 block sums as a second
+    output, AvgPool2d-backward x mask as the output, nearest-upsampled input, data-gradient filters; batch sizes that exercise 1,
+    2 and 4 pixel tiles per workgroup and ragged last workgroups."""
+    from musicgan_amd import ops
+    gen = torch.Generator().manual_seed(40 + n)
+    d = lambda t: t.to(DEV, torch.float32).contiguous()
+    lr = lambda t: F.leaky_relu(t, SLOPE)
+    m = lambda a: torch.where(a > 0, torch.ones_like(a), torch.full_like(a, SLOPE))
+    for (ci, co, h, w) in ((24, 40, 4, 4), (144, 160, 2, 2), (36, 20, 8, 8), (128, 128, 4, 4), (20, 36, 2, 4)):
+        if n * h * w > 4096:
+            continue
+        x = torch.randn(n, ci, h, w, generator=gen)
+        wt = _w(co, ci, gen)
+        b = torch.randn(co, generator=gen) * 0.1
+        wp, wpd = ops.pack_smallnet(d(wt), False), ops.pack_smallnet(d(wt), True)
+        ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+        y, p = ops.conv3x3_small(d(x), wp, d(b), co, lrelu=True, pool=True)
+        assert _rel(y, lr(ref)) < 2e-6 and _rel(p, F.avg_pool2d(lr(ref), 2)) < 2e-6, (ci, co, h, w)
+        # tangent form: no bias, times the mask of a saved activation, written over it; pooled second output
+        act = torch.randn(n, co, h, w, generator=gen)
+        buf = d(act)
+        pool_out = torch.full((n, co, h // 2, w // 2), float("nan"), device=DEV)
+        ops.conv3x3_small(d(x), wp, None, co, mask_aux=buf, out=buf, pool_out=pool_out)
+        want = F.conv2d(x.double(), wt.double(), padding=1) * m(act.double())
+        assert _rel(buf, want) < 3e-6 and _rel(pool_out, F.avg_pool2d(want, 2)) < 3e-6, (ci, co, h, w)
+        # data gradient (transposed, flipped filters): plain, with 2x2 block sums, and un-pooled x mask
+        gy = torch.randn(n, co, h, w, generator=gen)
+        gx = F.conv_transpose2d(gy.double(), wt.double(), padding=1)
+        assert _rel(ops.conv3x3_small(d(gy), wpd, None, ci), gx) < 3e-6
+        s4 = ops.conv3x3_small(d(gy), wpd, None, ci, upsum=True, want_y=False)[1]
+        assert _rel(s4, 4 * F.avg_pool2d(gx, 2)) < 3e-6
+        big = torch.randn(n, ci, 2 * h, 2 * w, generator=gen)
+        un = ops.conv3x3_small(d(gy), wpd, None, ci, unpool_aux=d(big))
+        assert _rel(un, 0.25 * F.interpolate(gx, scale_factor=2, mode="nearest") * m(big.double())) < 3e-6
+        # nearest-upsampled input
+        if h <= 4 and w <= 4:
+            yu = ops.conv3x3_small(d(x), wp, d(b), co, ups=True, lrelu=True)
+            assert _rel(yu, lr(F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), wt.double(), b.double(), padding=1))) < 2e-6
