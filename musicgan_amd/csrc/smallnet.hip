@@ -65,34 +65,51 @@ __device__ __forceinline__ void for_slots(const Geo& g, int G, F f) {
 // Loads in batches of 8 per thread, all issued before the first LDS store (left to itself hipcc waits for every load before it
 // issues the next: one memory round trip per element), in global order (coalesced); the zero fill touches other addresses.
 __device__ __forceinline__ void stage_images(const float* __restrict__ x, float* xs, const Geo& g, int G, int C, int img0, int N,
-                                             bool ups) {
-  const int Hin = ups ? g.H >> 1 : g.H, Win = ups ? g.W >> 1 : g.W;
+                                             bool ups, int Hfull = 0, int row0 = 0) {
+  // `g` describes what is staged: g.H rows starting at image row `row0` of maps that are Hfull rows high (Hfull = 0: whole
+  // images); the slot rows above / below them hold the neighbouring image rows where those exist (a band's halo is real data)
+  if (Hfull == 0) Hfull = g.H;
+  const int Hin = ups ? Hfull >> 1 : Hfull, Win = ups ? g.W >> 1 : g.W;
   const int nimg = N - img0 < G ? N - img0 : G;
-  const int per = C * g.HW, total = nimg * per;
+  // image rows that exist among row0 - 1 .. row0 + g.H (slot rows 0 .. g.H + 1)
+  const int ylo = row0 > 0 ? row0 - 1 : 0, yhi = row0 + g.H + 1 < Hfull ? row0 + g.H + 1 : Hfull;
+  const int rows = yhi - ylo, PW = rows * g.W, npos = nimg * PW;
   const float* xb = x + (size_t)img0 * C * (Hin * Win);
-  for (int base = threadIdx.x; base < total; base += SN_THREADS * 8) {
-    float v[8];
-    int dst[8];
+  // A thread keeps ONE pixel position (image, row, column) and walks the channels in steps of `cpp` (threads / positions): the
+  // only divisions are these, once; 16 loads are issued before the first LDS store -- every batch is a memory round trip (~2.5 us
+  // on a tensor the previous launch wrote), and a 4x4 image of up to 256 channels, four 2x2 images or a two-row band of an 8x8
+  // one take ONE.  Loads of a wave run along a row (and over consecutive channels): contiguous 32..128-byte pieces.
+  for (int p0 = 0; p0 < npos; p0 += SN_THREADS) {
+    const int cpp = npos - p0 >= SN_THREADS ? 1 : SN_THREADS / (npos - p0);
+    const int pos = p0 + (int)threadIdx.x % (npos - p0 < SN_THREADS ? npos - p0 : SN_THREADS);
+    const int c0 = npos - p0 >= SN_THREADS ? 0 : (int)threadIdx.x / (npos - p0);
+    const bool live = c0 < cpp;
+    const int nl = pos / PW, pr = pos - nl * PW, yr = pr / g.W, xx = pr - yr * g.W, y = ylo + yr;
+    const float* src = xb + (size_t)nl * C * (Hin * Win) + (ups ? (y >> 1) * Win + (xx >> 1) : y * Win + xx);
+    float* dst = xs + (nl * g.SPI + (y - row0 + 1) * g.W2 + xx + 1) * g.CS;
+    constexpr int U = 16;
+    for (int cb = c0; cb < C; cb += U * cpp) {
+      float v[U];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      int e = base + u * SN_THREADS;
-      const bool ok = e < total;
-      e = ok ? e : 0;
-      const int nl = e / per, r = e - nl * per, c = r / g.HW, pr = r - c * g.HW, y = pr / g.W, xx = pr - y * g.W;
-      const int srci = ups ? (nl * C + c) * (Hin * Win) + (y >> 1) * Win + (xx >> 1) : e;
-      v[u] = xb[srci];
-      dst[u] = ok ? g.slot(nl, y, xx) * g.CS + c : -1;
+      for (int u = 0; u < U; ++u) {
+        const int c = cb + u * cpp;
+        v[u] = src[(size_t)(c < C ? c : C - 1) * (Hin * Win)];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = cb + u * cpp;
+        if (live && c < C) dst[c] = v[u];
+      }
     }
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (dst[u] >= 0) xs[dst[u]] = v[u];
   }
-  // halo ring (all padded channels), pad channels of interior pixels, images past the batch: zero
+  // what the loop above does not write -- left / right halo columns, rows outside the image, pad channels, images past the
+  // batch -- is zero
   const int quads = g.CP / 4, slots = G * g.SPI;
   for (int e = threadIdx.x; e < slots * quads; e += SN_THREADS) {
     const int cq = e % quads, sl = e / quads;
     const int nl = sl / g.SPI, r = sl - nl * g.SPI, yy = r / g.W2, xx = r - yy * g.W2;
-    const bool inside = yy >= 1 && yy <= g.H && xx >= 1 && xx <= g.W && nl < nimg;
+    const int y = row0 + yy - 1;
+    const bool inside = xx >= 1 && xx <= g.W && y >= 0 && y < Hfull && nl < nimg;
     if (!inside) {
       *reinterpret_cast<f32x4*>(xs + sl * g.CS + cq * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
     } else if (cq * 4 + 4 > C) {
@@ -501,6 +518,7 @@ struct ScArgs {
   float* y;
   float* p;
   int N, Cin, Cout, H, W, flags, G;
+  int R;  // image rows per workgroup (R < H: one image per workgroup, H / R bands of it; their halo rows are staged too)
   float slope, pool_scale;
 };
 constexpr int SC_UNPOOL = 1 << 20;  // internal: y is (N, Cout, 2H, 2W) = 0.25 * result * lrelu'(aux), aux of that shape
@@ -508,9 +526,12 @@ constexpr int SC_UNPOOL = 1 << 20;  // internal: y is (N, Cout, 2H, 2W) = 0.25 *
 template <int NTW>
 __global__ void __launch_bounds__(SN_THREADS) smallconv_k(const ScArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int G = a.G, img0 = blockIdx.x * G, mt = blockIdx.y;
+  const int G = a.G, mt = blockIdx.y;
+  const int nbands = a.H / a.R;
+  const int img0 = (blockIdx.x / nbands) * G, row0 = (blockIdx.x % nbands) * a.R;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const Geo gi(a.Cin, a.H, a.W);
+  const Geo gi(a.Cin, a.R, a.W);
+  const int HWf = a.H * a.W;  // the full map (global indexing); gi.HW is this workgroup's band
   const int MT = sn_cp(a.Cout) / 16, KG = gi.CP / 16;
   float* xs = smem;
   f32x4* part = reinterpret_cast<f32x4*>(smem + (size_t)G * gi.SPI * gi.CS);  // [4 waves][NTW][64]
@@ -520,7 +541,7 @@ __global__ void __launch_bounds__(SN_THREADS) smallconv_k(const ScArgs a) {
   FilterRing<1> F;
   F.init(a.wpk, KG, MT, mt);
   if (g0 < g1) F.fill(g0);
-  stage_images(a.x, xs, gi, G, a.Cin, img0, a.N, a.flags & MG_CONV_UPS_IN);
+  stage_images(a.x, xs, gi, G, a.Cin, img0, a.N, a.flags & MG_CONV_UPS_IN, a.H, row0);
   __syncthreads();
   const int npx = G * gi.HW;
   const int col = lane & 15, q = lane >> 4;
@@ -543,7 +564,8 @@ __global__ void __launch_bounds__(SN_THREADS) smallconv_k(const ScArgs a) {
     const int nt = idx >> 6, l = idx & 63;
     f32x4 v = (part[nt * 64 + l] + part[(NTW + nt) * 64 + l]) + (part[(2 * NTW + nt) * 64 + l] + part[(3 * NTW + nt) * 64 + l]);
     const int px = nt * 16 + (l & 15), oc0 = mt * 16 + 4 * (l >> 4);
-    const int nl = px / gi.HW, pr = px - nl * gi.HW;
+    const int nl = px / gi.HW, prl = px - nl * gi.HW;
+    const int pr = row0 * a.W + prl;  // position in the full map
     const bool ok = px < npx && img0 + nl < a.N;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -552,10 +574,10 @@ __global__ void __launch_bounds__(SN_THREADS) smallconv_k(const ScArgs a) {
       if (a.bias != nullptr && oc < a.Cout) r += a.bias[oc];
       if (a.flags & MG_CONV_LRELU) r = mg_lrelu(r, a.slope);
       if (ok && oc < a.Cout) {
-        const size_t o = ((size_t)(img0 + nl) * a.Cout + oc) * gi.HW + pr;
+        const size_t o = ((size_t)(img0 + nl) * a.Cout + oc) * HWf + pr;
         if (a.flags & SC_UNPOOL) {
           const int y = pr / a.W, x = pr - y * a.W, W2o = 2 * a.W;
-          const size_t o2 = ((size_t)(img0 + nl) * a.Cout + oc) * (4 * gi.HW) + (size_t)(2 * y) * W2o + 2 * x;
+          const size_t o2 = ((size_t)(img0 + nl) * a.Cout + oc) * (4 * HWf) + (size_t)(2 * y) * W2o + 2 * x;
           const float2 m0 = *reinterpret_cast<const float2*>(a.aux + o2), m1 = *reinterpret_cast<const float2*>(a.aux + o2 + W2o);
           const float h = 0.25f * r;
           *reinterpret_cast<float2*>(a.y + o2) = make_float2(h * mg_lrelu_mask(m0.x, a.slope), h * mg_lrelu_mask(m0.y, a.slope));
@@ -570,14 +592,14 @@ __global__ void __launch_bounds__(SN_THREADS) smallconv_k(const ScArgs a) {
   }
   if (pool) {  // second output: 2x2 block means (AvgPool2d) or sums (nearest-upsample backward) of the result
     __syncthreads();
-    const int Hp = a.H >> 1, Wp = a.W >> 1, HWp = Hp * Wp;
-    for (int e = threadIdx.x; e < 16 * G * HWp; e += SN_THREADS) {
-      const int ocl = e / (G * HWp), r = e - ocl * (G * HWp);
-      const int nl = r / HWp, pp = r - nl * HWp, yy = pp / Wp, xx = pp - yy * Wp;
+    const int Rp = a.R >> 1, Wp = a.W >> 1, bp = Rp * Wp, HWp = (a.H >> 1) * Wp;
+    for (int e = threadIdx.x; e < 16 * G * bp; e += SN_THREADS) {
+      const int ocl = e / (G * bp), r = e - ocl * (G * bp);
+      const int nl = r / bp, pp = r - nl * bp, yy = pp / Wp, xx = pp - yy * Wp;
       const int oc = mt * 16 + ocl;
       if (oc < a.Cout && img0 + nl < a.N) {
         const float* t0 = tile + ocl * TS + nl * gi.HW + (2 * yy) * a.W + 2 * xx;
-        a.p[((size_t)(img0 + nl) * a.Cout + oc) * HWp + pp] = ((t0[0] + t0[1]) + (t0[a.W] + t0[a.W + 1])) * a.pool_scale;
+        a.p[((size_t)(img0 + nl) * a.Cout + oc) * HWp + (row0 >> 1) * Wp + pp] = ((t0[0] + t0[1]) + (t0[a.W] + t0[a.W + 1])) * a.pool_scale;
       }
     }
   }
@@ -586,7 +608,7 @@ __global__ void __launch_bounds__(SN_THREADS) smallconv_k(const ScArgs a) {
 }  // namespace
 
 extern "C" int mg_conv3x3_small_supported(int N, int Cin, int Cout, int H, int W) {
-  return H >= 2 && W >= 2 && H <= 8 && W <= 8 && H * W <= 64 && Cin <= 192 && Cout <= 192 && N > 0;
+  return H >= 2 && W >= 2 && H <= 8 && W <= 8 && H * W <= 64 && (H * W <= 16 || (H % 2) == 0) && Cin <= 192 && Cout <= 192 && N > 0;
 }
 
 extern "C" int mg_conv3x3_small(const float* x, const float* wpk, const float* bias, const float* aux, float* y, float* p, int N,
@@ -606,17 +628,28 @@ extern "C" int mg_conv3x3_small(const float* x, const float* wpk, const float* b
   a.flags = (flags & (MG_CONV_UPS_IN | MG_CONV_LRELU | MG_CONV_MASK_AUX)) | (pool ? MG_CONV_POOL_OUT : 0) | (unpool ? SC_UNPOOL : 0);
   a.pool_scale = (flags & MG_CONV_UPSUM_OUT) ? 1.0f : 0.25f;
   const int MT = mg_cdiv(Cout, 16), HW = H * W;
-  // Images per workgroup: enough to fill one 16-pixel tile (2x2 maps: 4 -- the matrix instructions cost the same with 4 or 16
-  // live columns), then doubled while the grid is beyond ~768 workgroups (every workgroup re-reads its out-channel tile's
-  // filters: past a few workgroups per CU that traffic, not latency, is the run time), at most 64 pixels.
+  // Images per workgroup: one, doubled while the grid is beyond ~768 workgroups (every workgroup re-reads its out-channel tile's
+  // filters: past a few workgroups per CU that traffic, not latency, is the run time), at most 64 pixels.  (Filling the
+  // 16-pixel tile of a 2x2 map with four images first was measured slower at 24 images: 9.0 against 7.1 us.)
   static const int wg_target = getenv("MG_SMALLCONV_WGS") ? atoi(getenv("MG_SMALLCONV_WGS")) : 768;
-  int G = 16 / HW > 1 ? 16 / HW : 1;
-  if (G > N) G = N;
-  while (mg_cdiv(N, G) * MT > wg_target && 2 * G * HW <= 64) G *= 2;
-  while (G > 1 && mg_cdiv(G * HW, 16) == 3) --G;  // 48 pixels would need three pixel tiles: instantiated for 1, 2, 4
+  int G = 1, R = H;
+  if (HW > 16) {
+    // maps of more than 16 pixels: ONE image per workgroup, split into bands of R rows (16, 32 or 64 pixels) while the grid
+    // stays within the target -- a band stages its rows + one halo row either side
+    for (R = 2; R < H && (R * W < 16 || (H % R) || (R & 1)); ++R) {}
+    while (N * (H / R) * MT > wg_target && 2 * R <= H && 2 * R * W <= 64) R *= 2;
+    while (R * W == 48 && 2 * R <= H) R *= 2;
+    G = 1;
+  } else {
+    while (mg_cdiv(N, G) * MT > wg_target && 2 * G * HW <= 64) G *= 2;
+    while (G > 1 && mg_cdiv(G * HW, 16) == 3) --G;  // 48 pixels would need three pixel tiles: instantiated for 1, 2, 4
+  }
   a.G = G;
-  const int NTW = mg_cdiv(G * HW, 16) <= 1 ? 1 : (mg_cdiv(G * HW, 16) == 2 ? 2 : 4);
-  const size_t lds = (mg_smallnet_buffer_floats(G, Cin, H, W) + (size_t)4 * NTW * 64 * 4 + (size_t)16 * (NTW * 16 + 1)) * sizeof(float);
+  a.R = R;
+  const int tiles = mg_cdiv(G * R * W, 16);
+  MG_CHECK_ARG(tiles <= 4 && tiles != 3 && (H % R) == 0, "mg_conv3x3_small: %d x %d map does not tile", H, W);
+  const int NTW = tiles;
+  const size_t lds = (mg_smallnet_buffer_floats(G, Cin, R, W) + (size_t)4 * NTW * 64 * 4 + (size_t)16 * (NTW * 16 + 1)) * sizeof(float);
   MG_CHECK_ARG(lds <= 160 * 1024, "mg_conv3x3_small: %zu bytes of LDS", lds);
   static MgPerDevice once;
   if (mg_first_use_on_device(once)) {
@@ -624,7 +657,7 @@ extern "C" int mg_conv3x3_small(const float* x, const float* wpk, const float* b
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&smallconv_k<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&smallconv_k<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  const dim3 grid((unsigned)mg_cdiv(N, G), (unsigned)MT);
+  const dim3 grid((unsigned)(mg_cdiv(N, G) * (H / R)), (unsigned)MT);
   if (NTW == 1) hipLaunchKernelGGL(smallconv_k<1>, grid, dim3(SN_THREADS), lds, (hipStream_t)stream, a);
   else if (NTW == 2) hipLaunchKernelGGL(smallconv_k<2>, grid, dim3(SN_THREADS), lds, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(smallconv_k<4>, grid, dim3(SN_THREADS), lds, (hipStream_t)stream, a);

@@ -103,7 +103,7 @@ class PackCache:
         fused up-sampling), the direct implicit GEMM otherwise.  Only the form that is used gets packed."""
         n, cin, h, wd = x.shape
         if self.small_ok(x, cout, **kw):
-            # <= 4x4 maps (default) of a few images: the latency-optimised one-layer kernel (split-K over the waves, the whole
+            # <= 8x8 maps of a few images: the latency-optimised one-layer kernel (split-K over the waves, the whole
             # filter share of a wave in flight at once; a fused AvgPool2d is a second output of the same launch)
             pool = kw.get("pool", False) or kw.get("pool_out") is not None
             return ops.conv3x3_small(x, self.get_sn(w, dgrad), bias, cout, ups=kw.get("ups", False), lrelu=kw.get("lrelu", False),
@@ -115,7 +115,7 @@ class PackCache:
     @staticmethod
     def small_ok(x: torch.Tensor, cout: int, **kw) -> bool:
         """Whether `conv` routes this call to ops.conv3x3_small: supported epilogue (no PixelNorm / tile masks), output map within
-        MG_SMALLCONV_MAX_SIDE (default 4) and few enough pixels to be latency-bound (MG_SMALLCONV_MAX_PIXELS, default 1536)."""
+        MG_SMALLCONV_MAX_SIDE (default 8) and few enough pixels to be latency-bound (MG_SMALLCONV_MAX_PIXELS, default 1536)."""
         if kw.get("pixnorm") or kw.get("mask_out") or kw.get("unpool_mask") is not None or kw.get("want_y", True) is False:
             return False
         m = kw.get("mask_aux")
@@ -124,7 +124,7 @@ class PackCache:
         n, cin, h, wd = x.shape
         if kw.get("ups"):
             h, wd = 2 * h, 2 * wd
-        side = int(os.environ.get("MG_SMALLCONV_MAX_SIDE", "4"))
+        side = int(os.environ.get("MG_SMALLCONV_MAX_SIDE", "8"))
         if h > side or wd > side or n * h * wd > int(os.environ.get("MG_SMALLCONV_MAX_PIXELS", "1536")):
             return False
         return ops.conv3x3_small_supported(n, cin, cout, h, wd)

@@ -45,6 +45,8 @@ def conv_mode(request, monkeypatch):
     onto every 3x3 convolution and weight gradient it supports (any even size) so the small golden cases exercise it end to end."""
     if request.param != "auto":
         monkeypatch.setenv("MG_WINO_MIN_PIXELS", "1")
+        # "everywhere" includes the <= 8x8 maps that mg_conv3x3_small otherwise takes first ("auto" covers that kernel)
+        monkeypatch.setenv("MG_SMALLCONV", "0")
         monkeypatch.setenv("MG_WINO_WGRAD_MIN_PIXELS", "1")
     return request.param
 

@@ -18,6 +18,8 @@ LR, BETAS = 1e-3, (0.0, 0.9)
 def mode(request, monkeypatch):
     if request.param == "wino_everywhere":
         monkeypatch.setenv("MG_WINO_MIN_PIXELS", "1")
+        # "everywhere" includes the <= 8x8 maps that mg_conv3x3_small otherwise takes first ("auto" covers that kernel)
+        monkeypatch.setenv("MG_SMALLCONV", "0")
         monkeypatch.setenv("MG_WINO_WGRAD_MIN_PIXELS", "1")
     return request.param
 
