@@ -259,6 +259,14 @@ int mg_adam_step_dev(const mg_adam_tensor_dev_t* desc, int n_tensors, float lr, 
  * wav: mono fp32 [L]; out_re/out_im: [512][T] (freq-major, Nyquist row dropped), T = 1 + L/256.  Periodic Hann(1024),
  * centre reflect padding, hop 256, divided by sqrt(sum w^2).  If out_im == NULL, out_re is interleaved complex64 [512][T][2]. */
 int mg_stft_1024(const float* wav, float* out_re, float* out_im, int64_t L, mg_stream_t stream);
+/* The same transform straight from a file's PCM frames [functions.py:43-49: th_audio.load (normalised to [-1, 1]) and
+ * raw_audio.mean(0)]: pcm holds L frames of `channels` interleaved samples as a WAV file stores them (kind: MG_PCM_*), the
+ * scaling (int16: / 32768, int32: / 2^31, uint8: (v - 128) / 128) and the mono mean happen inside the STFT kernel's loads for
+ * float32 / int16 with one or two channels; other formats take one conversion pass through `ws` (mg_stft_1024_pcm_ws_bytes). */
+enum { MG_PCM_F32 = 0, MG_PCM_I16 = 1, MG_PCM_I32 = 2, MG_PCM_U8 = 3 };
+size_t mg_stft_1024_pcm_ws_bytes(int64_t L, int channels, int kind);
+int mg_stft_1024_pcm(const void* pcm, int kind, int channels, float* out_re, float* out_im, void* ws, size_t ws_bytes, int64_t L,
+                     mg_stream_t stream);
 
 /* ------------------------------------------------------------------ multi-layer chains on small maps
  * The <= 4x4 ends of both networks -- the generator's first blocks [generator.py:15-40,67-76: conv3x3 -> LeakyReLU -> PixelNorm

@@ -49,6 +49,7 @@ MG_PACK_CONV3X3, MG_PACK_WINO3X3, MG_PACK_UPCONV3X3, MG_PACK_UPCONV3X3_DGRAD, MG
  MG_SN_LINEAR, MG_SN_LINBWD) = range(12)
 MG_SN_LRELU, MG_SN_MASK_AUX, MG_SN_NOLDS = 1, 2, 4
 MG_SN_MAX_OPS = 32
+MG_PCM_F32, MG_PCM_I16, MG_PCM_I32, MG_PCM_U8 = 0, 1, 2, 3
 
 
 class SnOp(Structure):
@@ -120,6 +121,8 @@ SIGNATURES = {
     "mg_input_transform_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "mg_input_transform": (c_int, [_P, c_int, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_float, _P]),
     "mg_stft_1024": (c_int, [_P, _P, _P, c_int64, _P]),
+    "mg_stft_1024_pcm_ws_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "mg_stft_1024_pcm": (c_int, [_P, c_int, c_int, _P, _P, _P, c_size_t, c_int64, _P]),
     "mg_codec_fwd_ws_bytes": (c_size_t, [c_int]),
     "mg_codec_fwd": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, _P]),
     "mg_codec_fwd_strided": (c_int, [_P, _P, _P, _P, c_size_t, _P, c_size_t, c_int, c_int, _P]),

@@ -41,16 +41,26 @@ def stft_from_waveform(raw_audio: th.Tensor, nperseg: int = constant.N_FFT, stri
         "the HIP STFT kernel is specialised for n_fft=1024, hop=256 (audio/constant.py)"
     dev = raw_audio.device if raw_audio.is_cuda else _device()
     x = raw_audio.to(dev, th.float32)
-    mono = x.mean(0) if x.dim() == 2 else x
-    return ops.stft_1024(mono.contiguous())
+    if x.dim() == 2 and x.shape[0] > 1:
+        return ops.stft_1024_pcm(x.t().contiguous())  # frames x channels: the mono mean (functions.py:49) is taken by the kernel
+    return ops.stft_1024(x.reshape(-1).contiguous())
+
+
+def stft_from_pcm(pcm: th.Tensor, nperseg: int = constant.N_FFT, stride: int = constant.STFT_STRIDE) -> th.Tensor:
+    """PCM frames (frames, channels) exactly as a WAV file stores them (wavio.load_pcm), on the device -> the same result as
+    wav_to_stft on that file: normalisation to [-1, 1], mono mean and STFT in one launch."""
+    assert nperseg == constant.N_FFT and stride == constant.STFT_STRIDE, \
+        "the HIP STFT kernel is specialised for n_fft=1024, hop=256 (audio/constant.py)"
+    return ops.stft_1024_pcm(pcm)
 
 
 def wav_to_stft(wav_p: str, nperseg: int = constant.N_FFT, stride: int = constant.STFT_STRIDE) -> th.Tensor:
-    raw_audio, sr = wavio.load(wav_p)
+    pcm, sr = wavio.load_pcm(wav_p)
     assert sr == constant.SAMPLE_RATE, \
         f"Audio sample rate must be {constant.SAMPLE_RATE}Hz, " \
         f"file \"{wav_p}\" is {sr}Hz"
-    return stft_from_waveform(raw_audio, nperseg, stride)
+    import numpy as np
+    return stft_from_pcm(th.from_numpy(np.ascontiguousarray(pcm)).to(_device()), nperseg, stride)
 
 
 def stft_to_phase_magn(complex_values: th.Tensor, nb_vec: int = constant.N_VEC) -> Tuple[th.Tensor, th.Tensor]:

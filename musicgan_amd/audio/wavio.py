@@ -22,6 +22,21 @@ def load(path: str):
     return torch.from_numpy(np.ascontiguousarray(x.T)), int(sr)
 
 
+def load_pcm(path: str, mmap: bool = True):
+    """The file's frames as stored: array (frames, channels) of int16 / int32 / uint8 / float32 (a read-only memory map where the
+    format allows) and the sample rate -- what `load` normalises and transposes; the device path does both inside the STFT kernel
+    (ops.stft_1024_pcm), so a file's bytes travel to the GPU as they are (int16: half of float32's)."""
+    try:
+        sr, data = wavfile.read(path, mmap=mmap)
+    except ValueError:  # formats scipy cannot map (e.g. 24-bit)
+        sr, data = wavfile.read(path)
+    if data.ndim == 1:
+        data = data[:, None]
+    if data.dtype not in (np.int16, np.int32, np.uint8, np.float32):
+        data = np.asarray(data, dtype=np.float32)  # (64-bit float files)
+    return data, int(sr)
+
+
 def save(path: str, wav: torch.Tensor, sample_rate: int) -> None:
     """(channels, samples) float tensor -> 32-bit float WAV (what torchaudio.save writes for float32 input)."""
     x = wav.detach().to("cpu", torch.float32).numpy()

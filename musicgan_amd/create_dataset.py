@@ -58,12 +58,19 @@ class _Writers:
             job = self.q.get()
             if job is None:
                 return
-            chunk, row, path = job
+            chunk, row, path, side_fd, side_off = job
             try:
                 if self.err is None:
                     chunk.event.synchronize()  # the chunk's device-to-host copy has landed
                     t0 = time.perf_counter()
-                    th.save(chunk.host[row].to(th.float64), path)
+                    if side_fd is not None:  # the float32 side-car row of this sample, at its place in the array file
+                        view = memoryview(chunk.host[row].numpy()).cast("B")
+                        done = 0
+                        while done < len(view):
+                            done += os.pwrite(side_fd, view[done:], side_off + done)
+                    # widened by numpy on this thread: torch's intra-op pool under 16 writer threads made `.to(float64)` of
+                    # one 4 MiB sample cost 20-50 ms (over-subscription) against 0.6 ms here
+                    th.save(th.from_numpy(chunk.host[row].numpy().astype("float64")), path)
                     with self._lock:
                         self.busy_s += time.perf_counter() - t0
             except BaseException as e:  # noqa: BLE001  (kept for the submitting thread)
@@ -71,11 +78,11 @@ class _Writers:
             finally:
                 chunk.release()
 
-    def submit(self, chunk, row, path):
+    def submit(self, chunk, row, path, side_fd=None, side_off=0):
         if self.err is not None:
             raise self.err
         chunk.acquire()
-        self.q.put((chunk, row, path))
+        self.q.put((chunk, row, path, side_fd, side_off))
 
     def close(self):
         for _ in self.threads:
@@ -84,6 +91,95 @@ class _Writers:
             t.join()
         if self.err is not None:
             raise self.err
+
+
+class _Loader:
+    """Reads, page-locks and uploads the wav files one ahead of the loop that transforms them (create_dataset.py:34-38 does
+    `wav_to_stft(path)` in line): a thread maps file k+1, copies its PCM frames AS STORED (int16 stays int16: half of float32's
+    bytes; de-interleaving, scaling and the mono mean happen inside the STFT kernel) into one of two pinned staging buffers and
+    queues the host-to-device copy on its own stream, while the main thread is busy with the device-to-host copies and writers
+    of file k.  Items come out in file order: (path, device PCM tensor (frames, channels) or None, sample rate, ready event)."""
+
+    STAGE_BYTES = 32 << 20  # two pinned staging buffers of this size, page-locked once (with the chunk ring, at set-up)
+
+    def __init__(self, paths, device):
+        self.q: "queue.Queue" = queue.Queue(maxsize=2)
+        self.device = device
+        self.busy_s = 0.0
+        self._stop = False
+        self._pins = [th.empty(self.STAGE_BYTES, dtype=th.uint8).pin_memory() for _ in range(2)]
+        self._t = threading.Thread(target=self._run, args=(list(paths),), daemon=True)
+        self._t.start()
+
+    def _run(self, paths):
+        import numpy as np
+        stream = th.cuda.Stream(device=self.device)
+        events = [None, None]
+        tdt = {np.dtype(np.int16): th.int16, np.dtype(np.int32): th.int32, np.dtype(np.uint8): th.uint8,
+               np.dtype(np.float32): th.float32}
+        slot = 0
+        try:
+            for path in paths:
+                if self._stop:
+                    return
+                t0 = time.perf_counter()
+                pcm, sr = audio.wavio.load_pcm(path)  # a memory map where the format allows: header parsed, no sample read yet
+                nbytes = pcm.size * pcm.dtype.itemsize
+                with th.cuda.stream(stream):
+                    dev = th.empty(nbytes, dtype=th.uint8, device=self.device)
+                offset = getattr(pcm, "offset", None)
+                fh = open(path, "rb") if offset is not None else None
+                flat = None if fh is not None else np.ascontiguousarray(pcm).reshape(-1).view(np.uint8)
+                try:
+                    if fh is not None:
+                        fh.seek(offset)
+                    for o in range(0, nbytes, self.STAGE_BYTES):
+                        n = min(self.STAGE_BYTES, nbytes - o)
+                        if events[slot] is not None:
+                            events[slot].synchronize()  # the upload that last read this staging buffer has finished (HOST wait)
+                        host = self._pins[slot][:n]
+                        if fh is not None:  # file (page cache) -> pinned memory in one pass, no intermediate array
+                            got = fh.readinto(memoryview(host.numpy()))
+                            assert got == n, f"short read from {path}"
+                        else:
+                            host.numpy()[...] = flat[o:o + n]
+                        with th.cuda.stream(stream):
+                            dev[o:o + n].copy_(host, non_blocking=True)
+                            ev = th.cuda.Event()
+                            ev.record(stream)
+                        events[slot] = ev
+                        slot ^= 1
+                finally:
+                    if fh is not None:
+                        fh.close()
+                with th.cuda.stream(stream):
+                    ready = th.cuda.Event()
+                    ready.record(stream)
+                shape, dt = (pcm.shape[0], pcm.shape[1]), tdt[pcm.dtype]
+                del pcm
+                self.busy_s += time.perf_counter() - t0
+                self.q.put((path, dev.view(dt).view(*shape), sr, ready))
+            self.q.put(None)
+        except BaseException as e:  # noqa: BLE001  (re-raised by the consumer)
+            self.q.put(e)
+
+    def __iter__(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+
+    def close(self):
+        self._stop = True
+        while self._t.is_alive():  # a producer blocked on a full queue needs room to see the flag
+            try:
+                self.q.get_nowait()
+            except queue.Empty:
+                pass
+            self._t.join(timeout=0.05)
 
 
 class _Chunk:
@@ -128,6 +224,16 @@ def create_dataset(audio_path: str, dataset_output_dir: str, *, packed: bool = T
             _, data = wavfile.read(p, mmap=True)
             counts.append(_nb_samples(data.shape[0], nb_vec))
     t_setup = time.perf_counter()
+    mine = [f_i for f_i in range(len(w_p)) if world == 1 or f_i % world == rank]
+    first_idx = {}
+    if world > 1:  # global sample numbering: files of other ranks in front of each of mine
+        run = 0
+        for f_i in range(len(w_p)):
+            first_idx[f_i] = run
+            run += counts[f_i]
+    dev = th.device("cuda", th.cuda.current_device())
+    # started first: it reads and uploads file 0 while the chunk ring below is being page-locked
+    loader = _Loader([w_p[f_i] for f_i in mine], dev)
     n_thr = writer_threads or max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4))
     ring: "queue.Queue" = queue.Queue()
     for _ in range(4):
@@ -136,19 +242,27 @@ def create_dataset(audio_path: str, dataset_output_dir: str, *, packed: bool = T
     side = None
     names = []
     if packed and world == 1:
-        side = open(join(dataset_output_dir, _ds.PACKED_BIN + ".tmp"), "wb")
+        # written row by row by the writer threads (os.pwrite at row idx): one thread streaming 421 MB per file was the
+        # slowest stage of the loop
+        side = os.open(join(dataset_output_dir, _ds.PACKED_BIN + ".tmp"), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
     t_start = time.perf_counter()
     t_setup = t_start - t_setup  # pinned ring (4 x 64 MiB page-locked) + writer threads: paid once per call
-    t_gpu = t_load = t_wait = t_drain = 0.0
+    t_gpu = t_load = t_wait = t_drain = t_loader = 0.0
+    row_bytes = 2 * (audio.N_FFT // 2) * nb_vec * 4
     idx = n_files = 0
     ok = False
     try:
-        for f_i, wav_p in enumerate(w_p):
-            if world > 1 and f_i % world != rank:
-                idx += counts[f_i]
-                continue
+        for f_i, (wav_p, pcm, sr, ready) in zip(mine, loader):
+            if world > 1:
+                idx = first_idx[f_i]
             t0 = time.perf_counter()
-            complex_values = audio.wav_to_stft(wav_p, nperseg=audio.N_FFT, stride=audio.STFT_STRIDE)
+            assert sr == audio.SAMPLE_RATE, \
+                f"Audio sample rate must be {audio.SAMPLE_RATE}Hz, " \
+                f"file \"{wav_p}\" is {sr}Hz"
+            th.cuda.current_stream().wait_event(ready)  # the upload (loader's stream) is ordered in front of the STFT
+            pcm.record_stream(th.cuda.current_stream())
+            complex_values = audio.functions.stft_from_pcm(pcm, nperseg=audio.N_FFT, stride=audio.STFT_STRIDE)
+            del pcm
             t1 = time.perf_counter()
             t_load += t1 - t0
             # create_dataset.py:41-42 skips files of fewer than nb_vec frames; a file of EXACTLY nb_vec frames has nb_vec - 1 phase
@@ -167,26 +281,26 @@ def create_dataset(audio_path: str, dataset_output_dir: str, *, packed: bool = T
                 chunk.event.record()
                 for r in range(n):
                     name = f"magn_phase_{idx}.pt"
-                    writers.submit(chunk, r, join(dataset_output_dir, name))
+                    # side-car rows in idx order == AudioDataset order only after the sort in _finish_sidecar
+                    writers.submit(chunk, r, join(dataset_output_dir, name), side, len(names) * row_bytes)
                     names.append(name)
                     idx += 1
-                if side is not None:  # rows in idx order == AudioDataset order only after the sort below; see _finish_sidecar
-                    chunk.event.synchronize()
-                    side.write(memoryview(chunk.host[:n].numpy()).cast("B"))
                 chunk.release()
             t_gpu += time.perf_counter() - t1
+        t_loader = loader.busy_s
         t_drain = time.perf_counter()
         writers.close()  # the writers finish what is queued
         t_drain = time.perf_counter() - t_drain
         ok = True
     finally:
+        loader.close()
         if not ok:
             try:
                 writers.close()
             except BaseException:  # noqa: BLE001  (the original error is the one to report)
                 pass
         if side is not None:
-            side.close()
+            os.close(side)
             if not ok:
                 _remove_sidecar(dataset_output_dir)
     if side is not None:
@@ -194,7 +308,7 @@ def create_dataset(audio_path: str, dataset_output_dir: str, *, packed: bool = T
     if stats is not None:
         wall = time.perf_counter() - t_start
         stats.update({"files": n_files, "samples": len(names), "wall_s": wall, "setup_s": t_setup, "drain_s": t_drain,
-                      "load_stft_s": t_load,
+                      "load_stft_s": t_load, "loader_thread_busy_s": t_loader,
                       "codec_copy_submit_s": t_gpu, "ring_wait_s": t_wait, "writer_threads": n_thr,
                       "writer_busy_s": writers.busy_s, "pt_bytes": len(names) * 2 * (audio.N_FFT // 2) * nb_vec * 8})
 

@@ -93,8 +93,45 @@ __device__ __forceinline__ void dft8(c2 (&v)[8]) {
 // per workgroup, then each tile of 16 consecutive frames is transformed -- one wave = 2 frames, each in its own 4 KiB LDS column
 // that serves the two Stockham exchanges and finally holds the frame's 512 output bins, so there is no workgroup barrier inside
 // a frame -- and the 16 columns are read out transposed so that every global store instruction writes four 128-byte runs along t.
-__global__ void __launch_bounds__(64 * NWAVE, 2) stft1024_kernel(const float* __restrict__ wav, float* __restrict__ out_re,
+// PCM: what `wav` holds -- 0: float32 samples, 1: int16 (scaled by 1/32768 as torchaudio.load(normalize=True) does);  CH: 1 = mono,
+// 2 = interleaved stereo frames as a WAV file stores them, averaged on the way in (functions.py:49: raw_audio.mean(0)) -- a
+// file's bytes go to the GPU as they are and the de-interleave / scale / mono mean cost no pass of their own.
+template <int PCM, int CH>
+struct PcmSrc {
+  // two consecutive mono samples s, s + 1 (s even: aligned loads of 4 .. 16 bytes)
+  static __device__ __forceinline__ c2 pair(const void* __restrict__ w, long long s) {
+    if constexpr (PCM == 0 && CH == 1) {
+      return *reinterpret_cast<const c2*>(reinterpret_cast<const float*>(w) + s);
+    } else if constexpr (PCM == 0) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(w) + 2 * s);
+      return c2{(v[0] + v[1]) / 2.0f, (v[2] + v[3]) / 2.0f};
+    } else if constexpr (CH == 1) {
+      const short2 v = *reinterpret_cast<const short2*>(reinterpret_cast<const short*>(w) + s);
+      return c2{(float)v.x / 32768.0f, (float)v.y / 32768.0f};
+    } else {
+      const short4 v = *reinterpret_cast<const short4*>(reinterpret_cast<const short*>(w) + 2 * s);
+      return c2{((float)v.x / 32768.0f + (float)v.y / 32768.0f) / 2.0f, ((float)v.z / 32768.0f + (float)v.w / 32768.0f) / 2.0f};
+    }
+  }
+  static __device__ __forceinline__ float one(const void* __restrict__ w, long long s) {
+    if constexpr (PCM == 0 && CH == 1) {
+      return reinterpret_cast<const float*>(w)[s];
+    } else if constexpr (PCM == 0) {
+      const float2 v = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(w) + 2 * s);
+      return (v.x + v.y) / 2.0f;
+    } else if constexpr (CH == 1) {
+      return (float)reinterpret_cast<const short*>(w)[s] / 32768.0f;
+    } else {
+      const short2 v = *reinterpret_cast<const short2*>(reinterpret_cast<const short*>(w) + 2 * s);
+      return ((float)v.x / 32768.0f + (float)v.y / 32768.0f) / 2.0f;
+    }
+  }
+};
+
+template <int PCM, int CH>
+__global__ void __launch_bounds__(64 * NWAVE, 2) stft1024_kernel(const void* __restrict__ wav, float* __restrict__ out_re,
                                                               float* __restrict__ out_im, long long L, int T, int ntiles) {
+  using Src = PcmSrc<PCM, CH>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   c2* tw = reinterpret_cast<c2*>(smem);                       // tw[k], k < 512
   c2* tw1 = tw + NB;                                           // tw1[r * 8 + k]
@@ -135,14 +172,14 @@ __global__ void __launch_bounds__(64 * NWAVE, 2) stft1024_kernel(const float* __
       for (int r = 0; r < 8; ++r) {
         const int n = 2 * (lane + 64 * r);
         if (interior) {
-          x[r] = *reinterpret_cast<const c2*>(wav + base + n);
+          x[r] = Src::pair(wav, base + n);
         } else {
           long long s0 = base + n, s1 = base + n + 1;
           if (s0 < 0) s0 = -s0;
           if (s1 < 0) s1 = -s1;
           if (s0 >= L) s0 = 2 * (L - 1) - s0;
           if (s1 >= L) s1 = 2 * (L - 1) - s1;
-          x[r] = c2{wav[s0], wav[s1]};
+          x[r] = c2{Src::one(wav, s0), Src::one(wav, s1)};
         }
       }
     } else {
@@ -254,21 +291,70 @@ __global__ void __launch_bounds__(64 * NWAVE, 2) stft1024_kernel(const float* __
   }
 }
 
+// Other sample formats / channel counts: one pass to mono float32 first (rare: 8-bit, 32-bit integer, more than two channels).
+__global__ void __launch_bounds__(256) pcm_to_mono_k(const void* __restrict__ pcm, float* __restrict__ mono, long long L, int C, int kind) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < L; i += (long long)gridDim.x * 256) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const long long e = i * C + c;
+      float v;
+      if (kind == MG_PCM_F32) v = reinterpret_cast<const float*>(pcm)[e];
+      else if (kind == MG_PCM_I16) v = (float)reinterpret_cast<const short*>(pcm)[e] / 32768.0f;
+      else if (kind == MG_PCM_I32) v = (float)reinterpret_cast<const int*>(pcm)[e] / 2147483648.0f;
+      else v = ((float)reinterpret_cast<const unsigned char*>(pcm)[e] - 128.0f) / 128.0f;
+      s += v;
+    }
+    mono[i] = C > 1 ? s / (float)C : s;
+  }
+}
+
+template <int PCM, int CH>
+static int launch_stft(const void* wav, float* out_re, float* out_im, long long L, hipStream_t stream) {
+  const int T = (int)(L / HOP) + 1;
+  const int ntiles = (T + FPB - 1) / FPB;
+  const int n_cu = mg_cu_count();
+  static MgPerDevice once;
+  if (mg_first_use_on_device(once))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stft1024_kernel<PCM, CH>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+  const int blocks = ntiles < 2 * n_cu ? ntiles : 2 * n_cu;  // two 78 KB workgroups per CU, persistent over the tiles
+  hipLaunchKernelGGL((stft1024_kernel<PCM, CH>), dim3(blocks), dim3(64 * NWAVE), STFT_LDS, stream, wav, out_re, out_im, L, T, ntiles);
+  MG_CHECK_LAUNCH("mg_stft_1024");
+  return MG_OK;
+}
+
 }  // namespace
 
 extern "C" int mg_stft_1024(const float* wav, float* out_re, float* out_im, int64_t L, mg_stream_t stream) {
   MG_CHECK_ARG(wav && out_re, "mg_stft_1024: bad arguments");
   MG_CHECK_ARG(L > NFFT / 2, "mg_stft_1024: reflect padding needs L > 512 (got %lld)", (long long)L);
   MG_CHECK_ARG(L / HOP + 1 < (1ll << 30), "mg_stft_1024: too many frames");
-  const int T = (int)(L / HOP) + 1;
-  const int ntiles = (T + FPB - 1) / FPB;
-  const int n_cu = mg_cu_count();
-  static MgPerDevice once;
-  if (mg_first_use_on_device(once))
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stft1024_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  const int blocks = ntiles < 2 * n_cu ? ntiles : 2 * n_cu;  // two 78 KB workgroups per CU, persistent over the tiles
-  hipLaunchKernelGGL(stft1024_kernel, dim3(blocks), dim3(64 * NWAVE), STFT_LDS, (hipStream_t)stream, wav, out_re, out_im,
-                     (long long)L, T, ntiles);
-  MG_CHECK_LAUNCH("mg_stft_1024");
-  return MG_OK;
+  return launch_stft<0, 1>(wav, out_re, out_im, (long long)L, (hipStream_t)stream);
+}
+
+extern "C" size_t mg_stft_1024_pcm_ws_bytes(int64_t L, int channels, int kind) {
+  const bool direct = (kind == MG_PCM_F32 || kind == MG_PCM_I16) && (channels == 1 || channels == 2);
+  return direct ? 0 : (size_t)L * sizeof(float);
+}
+
+extern "C" int mg_stft_1024_pcm(const void* pcm, int kind, int channels, float* out_re, float* out_im, void* ws, size_t ws_bytes,
+                                int64_t L, mg_stream_t stream) {
+  MG_CHECK_ARG(pcm && out_re && channels >= 1 && channels <= 64 && kind >= MG_PCM_F32 && kind <= MG_PCM_U8,
+               "mg_stft_1024_pcm: bad arguments");
+  MG_CHECK_ARG(L > NFFT / 2, "mg_stft_1024_pcm: reflect padding needs L > 512 (got %lld)", (long long)L);
+  MG_CHECK_ARG(L / HOP + 1 < (1ll << 30), "mg_stft_1024_pcm: too many frames");
+  hipStream_t s = (hipStream_t)stream;
+  if (kind == MG_PCM_F32 && channels == 1) return launch_stft<0, 1>(pcm, out_re, out_im, (long long)L, s);
+  if (kind == MG_PCM_F32 && channels == 2) return launch_stft<0, 2>(pcm, out_re, out_im, (long long)L, s);
+  if (kind == MG_PCM_I16 && channels == 1) return launch_stft<1, 1>(pcm, out_re, out_im, (long long)L, s);
+  if (kind == MG_PCM_I16 && channels == 2) return launch_stft<1, 2>(pcm, out_re, out_im, (long long)L, s);
+  if (ws == nullptr || ws_bytes < (size_t)L * sizeof(float)) {
+    mg_set_error("mg_stft_1024_pcm: workspace of %zu bytes needed", (size_t)L * sizeof(float));
+    return MG_EWORKSPACE;
+  }
+  const long long nb = (L + 255) / 256;
+  hipLaunchKernelGGL(pcm_to_mono_k, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, s, pcm, reinterpret_cast<float*>(ws),
+                     (long long)L, channels, kind);
+  MG_CHECK_LAUNCH("mg_stft_1024_pcm(mono)");
+  return launch_stft<0, 1>(ws, out_re, out_im, (long long)L, s);
 }

@@ -705,6 +705,25 @@ def stft_1024(wav_mono: torch.Tensor) -> torch.Tensor:
     return torch.view_as_complex(out)
 
 
+_PCM_KIND = {torch.float32: _lib.MG_PCM_F32, torch.int16: _lib.MG_PCM_I16, torch.int32: _lib.MG_PCM_I32, torch.uint8: _lib.MG_PCM_U8}
+
+
+def stft_1024_pcm(pcm: torch.Tensor) -> torch.Tensor:
+    """PCM frames as a WAV file stores them -- (L, C) or (L,) of float32 / int16 / int32 / uint8, on the device -- -> complex64
+    [512, 1 + L//256]: scaling to [-1, 1], the mono mean (audio/functions.py:43-49) and the STFT in one launch."""
+    if not pcm.is_cuda or not pcm.is_contiguous() or pcm.dtype not in _PCM_KIND:
+        raise _lib.MusicGanHipError(f"stft_1024_pcm: contiguous GPU tensor of float32 / int16 / int32 / uint8 expected, got {pcm.dtype}")
+    length, ch = pcm.shape[0], (pcm.shape[1] if pcm.dim() == 2 else 1)
+    kind = _PCM_KIND[pcm.dtype]
+    lib = _lib.load()
+    t = 1 + length // 256
+    out = torch.empty((512, t, 2), dtype=torch.float32, device=pcm.device)
+    nws = lib.mg_stft_1024_pcm_ws_bytes(length, ch, kind)
+    ws = workspace(nws, pcm.device) if nws else None
+    check(lib.mg_stft_1024_pcm(_p(pcm), kind, ch, _p(out), None, _p(ws), nws, length, _s()), "mg_stft_1024_pcm")
+    return torch.view_as_complex(out)
+
+
 def codec_fwd(stft_c: torch.Tensor, bark_scale: torch.Tensor, nb_vec: int, stacked: bool = False):
     """complex64 [512, T] -> (magn, phase) each [S, 512, nb_vec] in [-1, 1]  (audio/functions.py:65-94).
     `stacked`: one [S, 2, 512, nb_vec] tensor instead (what create_dataset.py:52-58 stacks), written in place by the kernel."""

@@ -152,6 +152,47 @@ def test_inverse_codec_over_20480_frames_against_the_reference():
     assert max(errs) <= 1e-5 * scale, errs  # measured 2e-7: the cumulative phase is the same sequential float32 sum
 
 
+def test_stft_from_pcm_frames_equals_the_normalised_mono_path(tmp_path):
+    """mg_stft_1024_pcm: a file's frames as stored (int16 / float32 / int32 / uint8, 1-3 interleaved channels) -> the bins of
+    `th_audio.load` (normalised to [-1, 1]) + `mean(0)` + spectrogram (functions.py:43-62).  float32 and int16 with one or two
+    channels are converted inside the STFT kernel's loads: bit-identical to the mono float32 path; the other formats take one
+    conversion pass: same bits again.  Also through a real stereo int16 file and `wav_to_stft(path)`."""
+    from scipy.io import wavfile
+    from musicgan_amd import audio, ops
+    from musicgan_amd.audio import wavio
+    rng = np.random.default_rng(21)
+    frames = 256 * 40 + 77
+    cases = {
+        "f32x1": (rng.random((frames, 1), dtype=np.float32) - 0.5),
+        "f32x2": (rng.random((frames, 2), dtype=np.float32) - 0.5),
+        "i16x1": rng.integers(-32768, 32767, (frames, 1), dtype=np.int16),
+        "i16x2": rng.integers(-32768, 32767, (frames, 2), dtype=np.int16),
+        "i32x2": rng.integers(-2 ** 31, 2 ** 31 - 1, (frames, 2), dtype=np.int32),
+        "u8x1": rng.integers(0, 255, (frames, 1), dtype=np.uint8),
+        "f32x3": (rng.random((frames, 3), dtype=np.float32) - 0.5),
+    }
+    for name, pcm in cases.items():
+        if pcm.dtype == np.int16:
+            x = pcm.astype(np.float32) / 32768.0
+        elif pcm.dtype == np.int32:
+            x = pcm.astype(np.float32) / 2147483648.0
+        elif pcm.dtype == np.uint8:
+            x = (pcm.astype(np.float32) - 128.0) / 128.0
+        else:
+            x = pcm
+        mono = torch.from_numpy(np.ascontiguousarray(x.T)).mean(0)          # the reference's order: normalise, then mean(0)
+        want = ops.stft_1024(mono.to(DEV).contiguous())
+        got = ops.stft_1024_pcm(torch.from_numpy(pcm).to(DEV))
+        assert torch.equal(torch.view_as_real(got), torch.view_as_real(want)), name
+    path = str(tmp_path / "stereo16.wav")
+    wavfile.write(path, 44100, cases["i16x2"])
+    loaded, sr = wavio.load(path)
+    assert sr == 44100 and tuple(loaded.shape) == (2, frames)
+    want = ops.stft_1024(loaded.mean(0).to(DEV).contiguous())
+    assert torch.equal(torch.view_as_real(audio.wav_to_stft(path)), torch.view_as_real(want))
+    assert torch.equal(torch.view_as_real(audio.stft_from_waveform(loaded)), torch.view_as_real(want))
+
+
 def test_codec_odd_sizes_against_oracle():
     """Ragged shapes: track lengths around the 2048-column block of the scan, nb_vec that is not a multiple of 4 (scalar stores)
     and one that does not divide the track (leading remainder dropped, functions.py:89-90)."""
