@@ -425,6 +425,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the other levels' records, the STFT / codec / create_dataset records and the train-loop record")
     ap.add_argument("--cpu-batch", type=int, default=64)
+    ap.add_argument("--no-cadence", action="store_true",
+                    help="skip the 5 critic : 1 generator `secondary` record (profiling runs: the trace then holds D+G steps only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -494,7 +496,7 @@ def main():
     # secondary figure: the reference's own cadence, five critic updates per generator update (train.py:189);
     # images/s counts the real images consumed (one batch per critic update).  Single GPU only.
     cadence = None
-    if world == 1:
+    if world == 1 and not args.no_cadence:
         def cycle():
             for _ in range(5):
                 z = torch.randn(args.batch, args.rand_channels, 2, 2, device=device, generator=data_rng)

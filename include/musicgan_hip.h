@@ -315,7 +315,7 @@ int mg_smallnet(const mg_sn_op_t* ops, int nops, int N, int imgs_per_wg, size_t 
                 mg_stream_t stream);
 
 /* One 3x3 convolution (the nn.Conv2d(3x3) + LeakyReLU / AvgPool2d / Upsample neighbours of mg_conv3x3 above) on maps of at
- * most 8x8 as a latency-optimised launch: a workgroup takes a few images x ONE 16-out-channel tile, its waves split the input
+ * most 16x16 as a latency-optimised launch: a workgroup takes a few images x ONE 16-out-channel tile, its waves split the input
  * channels and have their whole filter share in flight at once (one memory round trip instead of Cin / 8 dependent ones).
  * wpk: MG_PACK_SMALLNET filters (dgrad = 1 for the data gradient).  y (N,Cout,H,W) unless noted; flags:
  *   MG_CONV_UPS_IN     x is (N,Cin,H/2,W/2), nearest-upsampled on the way in [generator.py:26-29]

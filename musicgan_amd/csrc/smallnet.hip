@@ -608,7 +608,9 @@ __global__ void __launch_bounds__(SN_THREADS) smallconv_k(const ScArgs a) {
 }  // namespace
 
 extern "C" int mg_conv3x3_small_supported(int N, int Cin, int Cout, int H, int W) {
-  return H >= 2 && W >= 2 && H <= 8 && W <= 8 && H * W <= 64 && (H * W <= 16 || (H % 2) == 0) && Cin <= 192 && Cout <= 192 && N > 0;
+  // whole images of at most 16 pixels, or bands of an even number of rows with 16, 32 or 64 pixels (W = 4, 8 or 16)
+  return H >= 2 && W >= 2 && H <= 16 && W <= 16 && (H * W <= 16 || ((H % 2) == 0 && (W == 4 || W == 8 || W == 16))) && Cin <= 192 &&
+         Cout <= 192 && N > 0;
 }
 
 extern "C" int mg_conv3x3_small(const float* x, const float* wpk, const float* bias, const float* aux, float* y, float* p, int N,
@@ -628,10 +630,10 @@ extern "C" int mg_conv3x3_small(const float* x, const float* wpk, const float* b
   a.flags = (flags & (MG_CONV_UPS_IN | MG_CONV_LRELU | MG_CONV_MASK_AUX)) | (pool ? MG_CONV_POOL_OUT : 0) | (unpool ? SC_UNPOOL : 0);
   a.pool_scale = (flags & MG_CONV_UPSUM_OUT) ? 1.0f : 0.25f;
   const int MT = mg_cdiv(Cout, 16), HW = H * W;
-  // Images per workgroup: one, doubled while the grid is beyond ~768 workgroups (every workgroup re-reads its out-channel tile's
+  // Images per workgroup: one, doubled while the grid is beyond ~1024 workgroups (every workgroup re-reads its out-channel tile's
   // filters: past a few workgroups per CU that traffic, not latency, is the run time), at most 64 pixels.  (Filling the
   // 16-pixel tile of a 2x2 map with four images first was measured slower at 24 images: 9.0 against 7.1 us.)
-  static const int wg_target = getenv("MG_SMALLCONV_WGS") ? atoi(getenv("MG_SMALLCONV_WGS")) : 768;
+  static const int wg_target = getenv("MG_SMALLCONV_WGS") ? atoi(getenv("MG_SMALLCONV_WGS")) : 1024;
   int G = 1, R = H;
   if (HW > 16) {
     // maps of more than 16 pixels: ONE image per workgroup, split into bands of R rows (16, 32 or 64 pixels) while the grid

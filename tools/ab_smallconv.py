@@ -32,8 +32,11 @@ def t_us(fn, reps=20, inner=50):
 
 g = torch.Generator(device=dev).manual_seed(0)
 print("shape (n, cin, cout, h): old kernel us | small us | max rel diff   [plain lrelu conv]   and with pool")
-for (ci, co, h) in ((128, 128, 4), (128, 144, 4), (144, 144, 2), (144, 160, 2), (112, 112, 8), (112, 128, 8), (32, 128, 4), (96, 112, 8)):
-    for n in (8, 24, 64, 96, 192):
+shapes = ((128, 128, 4), (128, 144, 4), (144, 144, 2), (144, 160, 2), (112, 112, 8), (112, 128, 8), (32, 128, 4), (96, 112, 8))
+if len(sys.argv) > 1 and sys.argv[1] == "16":
+    shapes = ((96, 96, 16), (96, 112, 16), (112, 96, 16))
+for (ci, co, h) in shapes:
+    for n in ((6, 8, 18, 24, 32) if h == 16 else (8, 24, 64, 96, 192)):
         x = torch.randn(n, ci, h, h, device=dev, generator=g)
         w = torch.randn(co, ci, 3, 3, device=dev, generator=g) * 0.05
         b = torch.randn(co, device=dev, generator=g) * 0.1

@@ -1,5 +1,5 @@
 """Per-kernel table of a rocprofv3 --kernel-trace CSV (steady-state tail of the run), grouped by kernel name and workgroup count.
-    python tools/trace_table.py TRACE.csv [top]"""
+    python tools/trace_table.py TRACE.csv [top] [BENCH.json of the same (profiled) run: its ms_per_step is printed beside the busy time]"""
 import collections
 import csv
 import re
@@ -20,6 +20,11 @@ for r in sub:
     c[(nm, g)][0] += 1
     c[(nm, g)][1] += d
 tot = sum(v[1] for v in c.values())
-print(f"D+G steps {steps:.1f}, kernels/step {len(sub) / steps:.0f}, busy {tot / steps / 1e6:.3f} ms/step, span {span / steps / 1e6:.3f} ms/step")
+line = f"D+G steps {steps:.1f}, kernels/step {len(sub) / steps:.0f}, busy {tot / steps / 1e6:.3f} ms/step, span {span / steps / 1e6:.3f} ms/step"
+if len(sys.argv) > 3:
+    import json
+    d = json.loads([ln for ln in open(sys.argv[3]) if ln.startswith("{")][-1])
+    line += f"; ms_per_step of the same (profiled) run {d['ms_per_step']:.3f} (busy / that = {tot / steps / 1e6 / d['ms_per_step']:.3f})"
+print(line)
 for (k, g), (cnt, t) in sorted(c.items(), key=lambda kv: -kv[1][1])[:top]:
     print(f"  {k:50s} WGs {g:6d} {cnt / steps:5.1f}/step {t / cnt / 1e3:7.1f} us  {t / steps / 1e3:7.1f} us/step {100 * t / tot:5.1f}%")
