@@ -1,7 +1,8 @@
 """Progressive-growing critic with the reference's API (/root/reference/music_gan/networks/discriminator.py:53-191) on the
 MI355X kernels.  `gradient_penalty()` evaluates the WGAN-GP term and its parameter gradient with the hand-derived
-second-order pass of `engine.disc_gp_param_grads` instead of autograd's create_graph double backward; `forward()` is therefore
-once-differentiable (the reference only ever differentiates it twice through gradient_penalty)."""
+second-order pass of `engine.disc_gp_param_grads` instead of autograd's create_graph double backward; user code that
+differentiates `forward()` twice itself (`autograd.grad(out, x, create_graph=True)` as discriminator.py:170-176 does) reaches the
+same closed form through `_DiscInputGradFn`."""
 from __future__ import annotations
 
 from typing import Iterator
@@ -29,13 +30,51 @@ class _DiscFn(th.autograd.Function):
         return out
 
     @staticmethod
-    @th.autograd.function.once_differentiable
     def backward(ctx, g_out):
+        if th.is_grad_enabled() and ctx.need_gx:
+            # autograd.grad(..., create_graph=True) (discriminator.py:170-176 does this inside gradient_penalty; user code may do
+            # it itself): the input gradient becomes a node whose own backward is the closed-form second-order pass
+            state = _DiscState(ctx.net, ctx.W, ctx.saved, ctx.need_gp)
+            gx = _DiscInputGradFn.apply(g_out, state, *ctx.W.tensors())
+            return (gx, None, None) + state.pg
         sink = engine.GradSink() if ctx.need_gp else None
         gx, _ = engine.disc_backward(ctx.W, ctx.saved, g_out, ctx.net._pack_cache, sink, need_gx=ctx.need_gx)
         ctx.saved = None
         pg = tuple(sink.get(p) for p in ctx.W.tensors()) if sink is not None else (None,) * len(ctx.W.tensors())
         return (gx, None, None) + pg
+
+
+class _DiscState:
+    def __init__(self, net, W, saved, need_gp):
+        self.net, self.W, self.saved, self.need_gp = net, W, saved, need_gp
+        self.pg = (None,) * len(W.tensors())
+
+
+class _DiscInputGradFn(th.autograd.Function):
+    """g_x = J(x)^T g_out, the critic's input gradient, as a function of (g_out, parameters).  The critic is piecewise linear in x
+    and linear in each weight along this chain, so a loss L(g_x) has  dL/d theta = the penalty pass of engine.disc_gp_param_grads
+    with u_0 = dL/dg_x,  dL/dg_out = J(x) u_0 (the tangent of the scores)  and  dL/dx = 0 -- what autograd's double backward
+    through the reference's modules yields (leaky_relu's second derivative is zero almost everywhere).  The first-order
+    parameter gradients that `_DiscFn.backward` returns alongside are constants of this node (differentiating THEM again is not
+    supported)."""
+
+    @staticmethod
+    def forward(ctx, g_out, state, *params):
+        sink = engine.GradSink() if state.need_gp else None
+        gx, hs = engine.disc_backward(state.W, state.saved, g_out.detach(), state.net._pack_cache, sink, need_gx=True, keep_h=True)
+        if sink is not None:
+            state.pg = tuple(sink.get(p) for p in state.W.tensors())
+        ctx.state, ctx.hs, ctx.g_out = state, hs, g_out.detach()
+        return gx
+
+    @staticmethod
+    @th.autograd.function.once_differentiable
+    def backward(ctx, u):
+        st = ctx.state
+        sink = engine.GradSink()
+        _, t_out = engine.disc_gp_param_grads(st.W, st.saved, ctx.hs, u.contiguous(), st.net._pack_cache, sink, g_out=ctx.g_out,
+                                              want_t=True)
+        return (t_out, None) + tuple(sink.get(p) for p in st.W.tensors())
 
 
 class _GradPenFn(th.autograd.Function):

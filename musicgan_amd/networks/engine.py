@@ -713,7 +713,8 @@ def disc_backward(W: DiscWeights, ctx, g_out: torch.Tensor, cache: PackCache, si
     return gx, (hs if keep_h else None)
 
 
-def disc_gp_param_grads(W: DiscWeights, ctx, hs, u0: torch.Tensor, cache: PackCache, sink: GradSink):
+def disc_gp_param_grads(W: DiscWeights, ctx, hs, u0: torch.Tensor, cache: PackCache, sink: GradSink,
+                        g_out: Optional[torch.Tensor] = None, want_t: bool = False):
     """Second-order pass of the gradient penalty: tangent-forward u_l = mask_l * L_l u_{l-1} and dP/dW_l = wgrad(u_{l-1}, h_l).
     Biases receive no gradient from the penalty."""
     x, h0, saved, xp, o, flat, alpha = ctx
@@ -745,9 +746,13 @@ def disc_gp_param_grads(W: DiscWeights, ctx, hs, u0: torch.Tensor, cache: PackCa
             if i == 0 and to is not None:
                 F = FadeIn.of(alpha)
                 t = ops.axpby(F.a, t, F.b, to, out=t, coef=F.dev)
-    ones = torch.ones((n, 1), dtype=torch.float32, device=x.device)
+    # `g_out`: the upstream score gradient the first-order chain (hs) was run with -- ones for the penalty (discriminator.py:170-176)
+    up = torch.ones((n, 1), dtype=torch.float32, device=x.device) if g_out is None else g_out.contiguous()
     gwc, acc = sink.slot(W.clf[0])
-    ops.linear1_bwd(t.reshape(n, -1), W.clf[0], ones, gw=gwc, gb=None, need_gx=False, accumulate=acc)
+    ops.linear1_bwd(t.reshape(n, -1), W.clf[0], up, gw=gwc, gb=None, need_gx=False, accumulate=acc)
+    if want_t:  # the tangent of the scores themselves, J(x) u0: the derivative w.r.t. the upstream score gradient
+        zero = torch.zeros(1, dtype=torch.float32, device=x.device)
+        return sink, ops.linear1_fwd(t.reshape(n, -1).contiguous(), W.clf[0], zero)
     # parameters that the penalty does not reach (biases) still need a defined gradient when this sink is returned alone
     return sink
 
