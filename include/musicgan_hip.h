@@ -348,6 +348,13 @@ size_t mg_codec_inv_ws_bytes(int N, int W);
 int mg_codec_inv(const float* magn_phase, const float* bark_scale, float* wav_out, void* ws, size_t ws_bytes, int N, int W,
                  mg_stream_t stream);
 
+/* CRC-32 (zip / zlib) of the float64 widening of float32 samples: crc_out[i] = crc32 of the little-endian bytes of
+ * x[i*floats_per_sample ...].astype(float64) -- the checksum the zip container of `th.save(sample.to(th.float64))`
+ * [create_dataset.py:52-62] stores for its payload, which the reference's writer computes on one host core per sample.
+ * floats_per_sample = 8192 x a power of two <= 256 (a (2,512,512) sample: 524 288).  ws: mg_crc32_f64_ws_bytes. */
+size_t mg_crc32_f64_ws_bytes(int n, int64_t floats_per_sample);
+int mg_crc32_f64(const float* x, uint32_t* crc_out, void* ws, size_t ws_bytes, int n, int64_t floats_per_sample, mg_stream_t stream);
+
 /* Per-batch input transform of the training loop, fused: ChannelMinMaxNorm -> ChangeRange(-1,1) -> Resize(S) (bilinear with
  * anti-aliasing, align_corners = False: torchvision's tensor path) [audio/transforms.py:4-40, utils.py:70-86, train.py:138-140].
  * x (N,2,H,W) float64 (x_is_f64 != 0: cast to float32 on read, == x.to(th.float)) or float32; out (N,2,S,S) float32, S <= H, W. */

@@ -44,8 +44,9 @@ class _Writers:
     """`n` threads that widen a float32 sample to float64 and th.save it (create_dataset.py:52-62); the first failure is kept and
     re-raised by `close()` / the next `submit()`."""
 
-    def __init__(self, n: int):
+    def __init__(self, n: int, template=None):
         self.q: "queue.Queue" = queue.Queue(maxsize=4 * n)
+        self.template = template  # fast_pt.PtTemplate (byte-identical th.save output from a template + the payload's CRC) or None
         self.err = None
         self.busy_s = 0.0
         self._lock = threading.Lock()
@@ -58,7 +59,7 @@ class _Writers:
             job = self.q.get()
             if job is None:
                 return
-            chunk, row, path, side_fd, side_off = job
+            chunk, row, path, side_fd, side_off, crc = job
             try:
                 if self.err is None:
                     chunk.event.synchronize()  # the chunk's device-to-host copy has landed
@@ -70,7 +71,15 @@ class _Writers:
                             done += os.pwrite(side_fd, view[done:], side_off + done)
                     # widened by numpy on this thread: torch's intra-op pool under 16 writer threads made `.to(float64)` of
                     # one 4 MiB sample cost 20-50 ms (over-subscription) against 0.6 ms here
-                    th.save(th.from_numpy(chunk.host[row].numpy().astype("float64")), path)
+                    wide = chunk.host[row].numpy().astype("float64")
+                    if self.template is not None and crc is not None:
+                        if crc < 0:  # spot check (first sample of a file): the GPU's CRC against zlib's on the same bytes
+                            import zlib
+                            crc = -crc - 1
+                            assert zlib.crc32(wide) & 0xFFFFFFFF == crc, f"device CRC-32 of {path} disagrees with zlib"
+                        self.template.write(path, wide, crc)  # the bytes th.save would write, without its serializer / CRC pass
+                    else:
+                        th.save(th.from_numpy(wide), path)
                     with self._lock:
                         self.busy_s += time.perf_counter() - t0
             except BaseException as e:  # noqa: BLE001  (kept for the submitting thread)
@@ -78,11 +87,11 @@ class _Writers:
             finally:
                 chunk.release()
 
-    def submit(self, chunk, row, path, side_fd=None, side_off=0):
+    def submit(self, chunk, row, path, side_fd=None, side_off=0, crc=None):
         if self.err is not None:
             raise self.err
         chunk.acquire()
-        self.q.put((chunk, row, path, side_fd, side_off))
+        self.q.put((chunk, row, path, side_fd, side_off, crc))
 
     def close(self):
         for _ in self.threads:
@@ -238,7 +247,15 @@ def create_dataset(audio_path: str, dataset_output_dir: str, *, packed: bool = T
     ring: "queue.Queue" = queue.Queue()
     for _ in range(4):
         ring.put(_Chunk(nb_vec, ring))
-    writers = _Writers(n_thr)
+    # th.save's output for a (2, 512, nb_vec) float64 tensor as a template (checked against th.save at construction; None: keep
+    # calling th.save): the container's CRC-32 then comes from the GPU (mg_crc32_f64) instead of one host core per sample
+    template = None
+    if os.environ.get("MG_FAST_PT", "1") != "0":
+        from .fast_pt import PtTemplate
+        template = PtTemplate((2, audio.N_FFT // 2, nb_vec))
+        if not template.ok:
+            template = None
+    writers = _Writers(n_thr, template)
     side = None
     names = []
     if packed and world == 1:
@@ -271,6 +288,10 @@ def create_dataset(audio_path: str, dataset_output_dir: str, *, packed: bool = T
                 continue
             both = audio.stft_to_stacked_phase_magn(complex_values, nb_vec=nb_vec)  # (S, 2, 512, nb_vec) float32, on the device
             n_files += 1
+            crcs = None
+            if template is not None:
+                from . import ops
+                crcs = ops.crc32_of_float64(both).cpu().tolist()  # (one small synchronising copy per file)
             for c0 in range(0, both.size()[0], CHUNK_SAMPLES):
                 t2 = time.perf_counter()
                 chunk = ring.get()
@@ -282,7 +303,8 @@ def create_dataset(audio_path: str, dataset_output_dir: str, *, packed: bool = T
                 for r in range(n):
                     name = f"magn_phase_{idx}.pt"
                     # side-car rows in idx order == AudioDataset order only after the sort in _finish_sidecar
-                    writers.submit(chunk, r, join(dataset_output_dir, name), side, len(names) * row_bytes)
+                    crc = None if crcs is None else (-crcs[c0 + r] - 1 if c0 + r == 0 else crcs[c0 + r])
+                    writers.submit(chunk, r, join(dataset_output_dir, name), side, len(names) * row_bytes, crc)
                     names.append(name)
                     idx += 1
                 chunk.release()

@@ -1,0 +1,144 @@
+// CRC-32 (the zip / zlib one: reflected polynomial 0xEDB88320, init and final xor 0xFFFFFFFF) of the float64 widening of float32
+// samples, computed on the GPU.  `create_dataset` (/root/reference/music_gan/create_dataset.py:52-62) leaves every sample behind as
+// `th.save(magn_phase.to(th.float64))`: a zip container whose writer runs this CRC over the 4 MiB payload on one host core
+// (~4 ms per sample; with the file write it is what bounds the data-set loop once everything else is pipelined).  The payload
+// is already on the device as float32, its float64 bytes are a function of those bits, and the CRC is linear over GF(2):
+//   crc(A || B) = Z_{|B|}(crc(A)) ^ crc(B)      (zlib's crc32_combine; Z_n = "append n zero bytes", a 32 x 32 bit matrix)
+// so a thread takes 256 bytes (32 samples widened in registers, table-driven byte steps), a workgroup folds its 256 chunk CRCs
+// with the matrices Z_{256 * 2^k} (8 levels, LDS), a second tiny launch folds the workgroups of a sample (6 levels for 4 MiB).
+#include <cstring>
+
+#include "mg_common.h"
+
+namespace {
+
+constexpr int CRC_CHUNK_FLOATS = 32;                  // 256 bytes of float64 per thread
+constexpr int CRC_WG_FLOATS = 256 * CRC_CHUNK_FLOATS;  // 64 KiB of float64 per workgroup
+constexpr int CRC_MAX_LEVELS = 24;
+
+struct CrcMats {
+  unsigned m[CRC_MAX_LEVELS][32];  // m[k] = Z_{256 * 2^k bytes}
+};
+
+unsigned gf2_times(const unsigned* mat, unsigned vec) {
+  unsigned sum = 0;
+  while (vec) {
+    if (vec & 1) sum ^= *mat;
+    vec >>= 1;
+    ++mat;
+  }
+  return sum;
+}
+void gf2_square(unsigned* sq, const unsigned* mat) {
+  for (int n = 0; n < 32; ++n) sq[n] = gf2_times(mat, mat[n]);
+}
+const CrcMats& crc_mats() {
+  static CrcMats M;
+  static bool done = false;
+  if (!done) {
+    unsigned a[32], b[32];
+    a[0] = 0xedb88320u;  // one zero BIT
+    for (int n = 1; n < 32; ++n) a[n] = 1u << (n - 1);
+    gf2_square(b, a);    // 2 bits
+    gf2_square(a, b);    // 4 bits
+    gf2_square(b, a);    // 8 bits = 1 byte
+    for (int i = 0; i < 8; ++i) {  // 1 byte -> 256 bytes
+      gf2_square(a, b);
+      std::memcpy(b, a, sizeof(a));
+    }
+    for (int k = 0; k < CRC_MAX_LEVELS; ++k) {
+      std::memcpy(M.m[k], b, sizeof(b));
+      gf2_square(a, b);
+      std::memcpy(b, a, sizeof(a));
+    }
+    done = true;
+  }
+  return M;
+}
+
+__device__ __forceinline__ unsigned matvec(const unsigned* m, unsigned v) {
+  unsigned s = 0;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) s ^= (v >> i) & 1u ? m[i] : 0u;
+  return s;
+}
+
+__global__ void __launch_bounds__(256) crc32_f64_chunks_k(const float* __restrict__ x, unsigned* __restrict__ part, const CrcMats M,
+                                                          long long floats_per_sample, int wgs_per_sample) {
+  __shared__ unsigned tab[256], mats[8][32], vals[256];
+  const int t = threadIdx.x;
+  {
+    unsigned c = (unsigned)t;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+    tab[t] = c;
+    mats[t >> 5][t & 31] = M.m[t >> 5][t & 31];
+  }
+  __syncthreads();
+  const long long sample = blockIdx.x / wgs_per_sample, wg = blockIdx.x % wgs_per_sample;
+  const float* src = x + sample * floats_per_sample + wg * CRC_WG_FLOATS + t * CRC_CHUNK_FLOATS;
+  f32x4 v[CRC_CHUNK_FLOATS / 4];
+#pragma unroll
+  for (int i = 0; i < CRC_CHUNK_FLOATS / 4; ++i) v[i] = reinterpret_cast<const f32x4*>(src)[i];
+  unsigned r = 0xFFFFFFFFu;
+#pragma unroll
+  for (int i = 0; i < CRC_CHUNK_FLOATS; ++i) {
+    const unsigned long long bits = (unsigned long long)__builtin_bit_cast(long long, (double)v[i >> 2][i & 3]);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) r = tab[(r ^ (unsigned)(bits >> (8 * b))) & 0xFFu] ^ (r >> 8);
+  }
+  vals[t] = ~r;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {  // crc(left || right) = Z_{|right|}(crc(left)) ^ crc(right), |right| = 256 * 2^k bytes
+    unsigned c = 0;
+    const bool act = (t & ((2 << k) - 1)) == 0;
+    if (act) c = matvec(mats[k], vals[t]) ^ vals[t + (1 << k)];
+    __syncthreads();
+    if (act) vals[t] = c;
+    __syncthreads();
+  }
+  if (t == 0) part[blockIdx.x] = vals[0];
+}
+
+__global__ void __launch_bounds__(256) crc32_fold_k(const unsigned* __restrict__ part, unsigned* __restrict__ out, const CrcMats M,
+                                                    int wgs_per_sample, int levels) {
+  __shared__ unsigned vals[256];
+  const int t = threadIdx.x;
+  vals[t] = t < wgs_per_sample ? part[(size_t)blockIdx.x * wgs_per_sample + t] : 0u;
+  __syncthreads();
+  for (int k = 0; k < levels; ++k) {
+    unsigned c = 0;
+    const bool act = (t & ((2 << k) - 1)) == 0 && t + (1 << k) < wgs_per_sample;
+    if (act) c = matvec(M.m[8 + k], vals[t]) ^ vals[t + (1 << k)];
+    __syncthreads();
+    if (act) vals[t] = c;
+    __syncthreads();
+  }
+  if (t == 0) out[blockIdx.x] = vals[0];
+}
+
+}  // namespace
+
+extern "C" size_t mg_crc32_f64_ws_bytes(int n, int64_t floats_per_sample) {
+  return (size_t)n * (size_t)(floats_per_sample / CRC_WG_FLOATS) * sizeof(unsigned);
+}
+
+extern "C" int mg_crc32_f64(const float* x, uint32_t* crc_out, void* ws, size_t ws_bytes, int n, int64_t floats_per_sample,
+                            mg_stream_t stream) {
+  MG_CHECK_ARG(x && crc_out && ws && n > 0, "mg_crc32_f64: bad arguments");
+  const long long wgs = floats_per_sample / CRC_WG_FLOATS;
+  // a power-of-two number of 64 KiB pieces per sample, at most 256 (16 MiB of float64): the folds pair equal-length halves
+  MG_CHECK_ARG(floats_per_sample % CRC_WG_FLOATS == 0 && wgs >= 1 && wgs <= 256 && (wgs & (wgs - 1)) == 0,
+               "mg_crc32_f64: %lld floats per sample is not 8192 x a power of two <= 256", (long long)floats_per_sample);
+  MG_CHECK_ARG(ws_bytes >= mg_crc32_f64_ws_bytes(n, floats_per_sample), "mg_crc32_f64: workspace too small");
+  MG_CHECK_ARG((long long)n * wgs < (1ll << 31), "mg_crc32_f64: too many samples");
+  const CrcMats& M = crc_mats();
+  hipLaunchKernelGGL(crc32_f64_chunks_k, dim3((unsigned)(n * wgs)), dim3(256), 0, (hipStream_t)stream, x,
+                     reinterpret_cast<unsigned*>(ws), M, (long long)floats_per_sample, (int)wgs);
+  MG_CHECK_LAUNCH("mg_crc32_f64");
+  hipLaunchKernelGGL(crc32_fold_k, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const unsigned*>(ws),
+                     crc_out, M, (int)wgs, mg_ilog2((int)wgs));
+  MG_CHECK_LAUNCH("mg_crc32_f64(fold)");
+  return MG_OK;
+}

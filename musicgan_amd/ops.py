@@ -746,6 +746,18 @@ def codec_fwd(stft_c: torch.Tensor, bark_scale: torch.Tensor, nb_vec: int, stack
     return magn, phase
 
 
+def crc32_of_float64(x: torch.Tensor) -> torch.Tensor:
+    """x: float32 (n, ...) on the device -> int64 tensor [n] (values < 2^32) of zlib.crc32(x[i].double().numpy().tobytes())."""
+    _chk(x)
+    n, per = x.shape[0], x[0].numel()
+    lib = _lib.load()
+    nws = lib.mg_crc32_f64_ws_bytes(n, per)
+    ws = workspace(nws, x.device)
+    out = torch.empty((n,), dtype=torch.int32, device=x.device)
+    check(lib.mg_crc32_f64(_p(x), ctypes.c_void_p(out.data_ptr()), _p(ws), ws.numel(), n, per, _s()), "mg_crc32_f64")
+    return out.to(torch.int64) & 0xFFFFFFFF
+
+
 def codec_inv(magn_phase: torch.Tensor, bark_scale: torch.Tensor) -> torch.Tensor:
     """[N, 2, 512, W] -> waveform [256*(N*W-1)]  (audio/functions.py:97-139 without the file write)."""
     _chk(magn_phase, bark_scale)

@@ -543,3 +543,18 @@ def test_create_dataset_sidecar_is_rebuilt_not_reused(tmp_path):
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
             del os.environ[k]
     assert not audio.has_packed(str(out)) and not os.path.exists(str(out / "magn_phase_f32.bin"))
+
+
+def test_device_crc32_of_the_float64_payload_equals_zlib():
+    """mg_crc32_f64: the zip CRC-32 of a float32 sample's float64 widening, computed where the sample is -- against zlib.crc32 of
+    x.double().tobytes() for the (2,512,512) sample shape (64 pieces of 64 KiB), the smallest and the largest supported sizes,
+    and values that exercise every exponent range (denormals, zeros, negative zero, large)."""
+    import zlib
+    from musicgan_amd import ops
+    g = torch.Generator().manual_seed(12)
+    for n, per in ((3, 2 * 512 * 512), (5, 8192), (1, 8192 * 256), (2, 8192 * 4)):
+        x = torch.randn(n, per, generator=g) * torch.pow(10.0, torch.randint(-42, 30, (n, per), generator=g).float())
+        x[0, :4] = torch.tensor([0.0, -0.0, 1e-45, -3.4e38])
+        got = ops.crc32_of_float64(x.to(DEV)).cpu().tolist()
+        want = [zlib.crc32(x[i].double().numpy().tobytes()) & 0xFFFFFFFF for i in range(n)]
+        assert got == want, (n, per)

@@ -187,3 +187,24 @@ def test_packed_sidecar_index_and_invalidation(tmp_path):
         fh.write(samples[0].numpy().tobytes())
     cd._finish_sidecar(folder, ["magn_phase_0.pt"])
     assert not ds.has_packed(folder) and not os.path.exists(os.path.join(folder, ds.PACKED_BIN + ".tmp"))
+
+
+def test_pt_template_writes_what_torch_save_writes(tmp_path):
+    """fast_pt.PtTemplate: `th.save(float64 tensor of a fixed shape)` from a template + payload + the payload's CRC-32 (which
+    create_dataset takes from the GPU), byte for byte -- incl. the zip data descriptor, the central directory and the
+    serialization_id record torch derives from the records' CRCs -- for the sample shape (create_dataset.py:52-62) and others."""
+    import io
+    import zlib
+    from musicgan_amd.fast_pt import PtTemplate
+    rng = torch.Generator().manual_seed(3)
+    for shape in ((2, 512, 512), (2, 512, 64), (5, 3)):
+        tpl = PtTemplate(shape)
+        assert tpl.ok, shape
+        for _ in range(2):
+            x = (torch.rand(*shape, generator=rng) * 2 - 1).double()
+            want = io.BytesIO()
+            torch.save(x, want)
+            path = str(tmp_path / "s.pt")
+            tpl.write(path, x.numpy(), zlib.crc32(x.numpy().tobytes()) & 0xFFFFFFFF)
+            assert open(path, "rb").read() == want.getvalue()
+            assert torch.equal(torch.load(path), x)
