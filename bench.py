@@ -245,7 +245,8 @@ def stft_record(device, cpu: bool):
                         "frac": 5120.0 * fps / 8e12, "traffic": stft_traffic(),
                         "algorithmic_bytes": 5120.0 * T,
                         "basis": "5 120 algorithmic bytes per frame x frames per launch / HIP-event launch time; traffic = "
-                                 "HBM bytes per launch from rocprofv3 PMC passes (tools/measure_traffic.sh stft)"}}
+                                 "HBM bytes per launch, NOT measured in this run: read from profiles/traffic_stft_kernel.json "
+                                 "(rocprofv3 PMC passes, tools/measure_traffic.sh stft, last re-measured in round 4)"}}
     ms_codec = timeit(lambda: audio.stft_to_phase_magn(c_keep), 50, warm=10)
     rec["codec"] = {"workload": "stft_to_phase_magn (functions.py:65-94) of that file's 512 x 103 360 bins -> 201 images",
                     "ms_per_file": ms_codec,
@@ -571,7 +572,9 @@ def main():
                          "traffic": (dom.get("hbm_traffic") or {}).get("bytes_per_launch"),
                          "basis": f"whole step, per GPU: {fpi / 1e9:.2f} algorithmic GFLOP/image (4*Gf+12*Df) x images/s; "
                                   f"executed_frac: {xfpi / 1e9:.2f} GFLOP/image actually issued to the MFMA pipe "
-                                  f"(Winograd / sub-pixel passes count 1/2.25)",
+                                  f"(Winograd / sub-pixel passes count 1/2.25); traffic: HBM bytes of ONE dominant launch, NOT "
+                                  f"measured in this run -- read from profiles/traffic_dominant_kernel.json (rocprofv3 PMC passes, "
+                                  f"tools/measure_traffic.sh, last re-measured in round 4)",
                          # frac = FLOPs the kernel EXECUTES over the peak (a fraction of the machine); algorithmic_frac counts the
                          # direct-convolution FLOPs it replaces (2.25x as many) and may exceed 1
                          "dominant_kernel": {**dom, "frac": dom["executed_tflops"] / MFMA_F32_PEAK_TFLOPS,

@@ -264,6 +264,12 @@ int mg_stft_1024(const float* wav, float* out_re, float* out_im, int64_t L, mg_s
  * scaling (int16: / 32768, int32: / 2^31, uint8: (v - 128) / 128) and the mono mean happen inside the STFT kernel's loads for
  * float32 / int16 with one or two channels; other formats take one conversion pass through `ws` (mg_stft_1024_pcm_ws_bytes). */
 enum { MG_PCM_F32 = 0, MG_PCM_I16 = 1, MG_PCM_I32 = 2, MG_PCM_U8 = 3 };
+/* the conversion alone: mono[L] float32 = mean over channels of the normalised samples [functions.py:43-49] */
+int mg_pcm_to_mono(const void* pcm, int kind, int channels, float* mono, int64_t L, mg_stream_t stream);
+/* wav_to_stft's other arguments [functions.py:38-41: nperseg, stride]: the same definition for any power-of-two n_fft in
+ * [64, 8192] and any hop (periodic Hann(n_fft), reflect padding n_fft/2, / sqrt(sum w^2), rows 0 .. n_fft/2 - 1);
+ * out_c64: interleaved complex64 [n_fft/2][1 + L/hop].  An untuned radix-2 path: the drivers only use 1024 / 256. */
+int mg_stft_generic(const float* wav, float* out_c64, int64_t L, int n_fft, int hop, mg_stream_t stream);
 size_t mg_stft_1024_pcm_ws_bytes(int64_t L, int channels, int kind);
 int mg_stft_1024_pcm(const void* pcm, int kind, int channels, float* out_re, float* out_im, void* ws, size_t ws_bytes, int64_t L,
                      mg_stream_t stream);

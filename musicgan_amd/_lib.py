@@ -123,6 +123,8 @@ SIGNATURES = {
     "mg_stft_1024": (c_int, [_P, _P, _P, c_int64, _P]),
     "mg_stft_1024_pcm_ws_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "mg_stft_1024_pcm": (c_int, [_P, c_int, c_int, _P, _P, _P, c_size_t, c_int64, _P]),
+    "mg_pcm_to_mono": (c_int, [_P, c_int, c_int, _P, c_int64, _P]),
+    "mg_stft_generic": (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
     "mg_crc32_f64_ws_bytes": (c_size_t, [c_int, c_int64]),
     "mg_crc32_f64": (c_int, [_P, _P, _P, c_size_t, c_int, c_int64, _P]),
     "mg_codec_fwd_ws_bytes": (c_size_t, [c_int]),

@@ -35,23 +35,33 @@ def bark_magn_scale(magn: th.Tensor, unscale: bool = False) -> th.Tensor:
     return magn / s if unscale else magn * s
 
 
+def _fast_stft(nperseg: int, stride: int) -> bool:
+    """1024 / 256 (audio/constant.py; all the drivers use) runs the tuned kernel; any other power-of-two window the untuned one."""
+    if nperseg == constant.N_FFT and stride == constant.STFT_STRIDE:
+        return True
+    assert 64 <= nperseg <= 8192 and nperseg & (nperseg - 1) == 0 and stride >= 1, \
+        f"nperseg must be a power of two in [64, 8192] and stride >= 1, actual = ({nperseg}, {stride})"
+    return False
+
+
 def stft_from_waveform(raw_audio: th.Tensor, nperseg: int = constant.N_FFT, stride: int = constant.STFT_STRIDE) -> th.Tensor:
     """(channels, samples) or (samples,) -> complex64 (nperseg/2, 1 + samples//stride), Nyquist row dropped."""
-    assert nperseg == constant.N_FFT and stride == constant.STFT_STRIDE, \
-        "the HIP STFT kernel is specialised for n_fft=1024, hop=256 (audio/constant.py)"
+    fast = _fast_stft(nperseg, stride)
     dev = raw_audio.device if raw_audio.is_cuda else _device()
     x = raw_audio.to(dev, th.float32)
     if x.dim() == 2 and x.shape[0] > 1:
-        return ops.stft_1024_pcm(x.t().contiguous())  # frames x channels: the mono mean (functions.py:49) is taken by the kernel
-    return ops.stft_1024(x.reshape(-1).contiguous())
+        frames = x.t().contiguous()  # frames x channels: the mono mean (functions.py:49) is taken by the kernel
+        return ops.stft_1024_pcm(frames) if fast else ops.stft_generic(ops.pcm_to_mono(frames), nperseg, stride)
+    mono = x.reshape(-1).contiguous()
+    return ops.stft_1024(mono) if fast else ops.stft_generic(mono, nperseg, stride)
 
 
 def stft_from_pcm(pcm: th.Tensor, nperseg: int = constant.N_FFT, stride: int = constant.STFT_STRIDE) -> th.Tensor:
     """PCM frames (frames, channels) exactly as a WAV file stores them (wavio.load_pcm), on the device -> the same result as
-    wav_to_stft on that file: normalisation to [-1, 1], mono mean and STFT in one launch."""
-    assert nperseg == constant.N_FFT and stride == constant.STFT_STRIDE, \
-        "the HIP STFT kernel is specialised for n_fft=1024, hop=256 (audio/constant.py)"
-    return ops.stft_1024_pcm(pcm)
+    wav_to_stft on that file: normalisation to [-1, 1], mono mean and STFT in one launch (two for other window sizes)."""
+    if _fast_stft(nperseg, stride):
+        return ops.stft_1024_pcm(pcm)
+    return ops.stft_generic(ops.pcm_to_mono(pcm), nperseg, stride)
 
 
 def wav_to_stft(wav_p: str, nperseg: int = constant.N_FFT, stride: int = constant.STFT_STRIDE) -> th.Tensor:

@@ -8,6 +8,8 @@
 // A workgroup (8 waves, persistent: one per CU) covers 16 consecutive frames per tile and transposes its 512x16 output tile
 // through LDS so that global stores are 128-byte runs along t (the output is frequency-major).  Twiddles and the window are
 // built once per workgroup into LDS with sincospi (no global tables, no hidden state).
+#include <cmath>
+
 #include "mg_common.h"
 
 namespace {
@@ -323,7 +325,68 @@ static int launch_stft(const void* wav, float* out_re, float* out_im, long long 
   return MG_OK;
 }
 
+// Any other (n_fft, hop) the reference's signature admits (functions.py:38-41: wav_to_stft(wav_p, nperseg, stride)): a plain
+// radix-2 transform in LDS, one frame per workgroup -- not a tuned path (the drivers only ever use 1024 / 256), same definition:
+// periodic Hann, centre reflect padding of n_fft / 2, division by sqrt(sum w^2), bins 0 .. n_fft/2 - 1.
+__global__ void __launch_bounds__(256) stft_generic_k(const float* __restrict__ wav, float* __restrict__ out, long long L, int T, int N,
+                                                      int lgN, int hop, float inv_norm) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  c2* buf = reinterpret_cast<c2*>(smem);
+  const int t = blockIdx.x;
+  const long long base = (long long)t * hop - N / 2;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    long long s = base + n;
+    if (s < 0) s = -s;
+    if (s >= L) s = 2 * (L - 1) - s;
+    float sn, cs;
+    sincospif(2.0f * (float)n / (float)N, &sn, &cs);
+    const float w = (0.5f - 0.5f * cs) * inv_norm;
+    // bit-reversed placement: the stages below are decimation in time
+    buf[__brev((unsigned)n) >> (32 - lgN)] = c2{wav[s] * w, 0.f};
+  }
+  __syncthreads();
+  for (int st = 0; st < lgN; ++st) {
+    const int half = 1 << st;
+    for (int i = threadIdx.x; i < N / 2; i += 256) {
+      const int k = i & (half - 1), j = ((i >> st) << (st + 1)) + k;
+      float sn, cs;
+      sincospif((float)k / (float)half, &sn, &cs);  // e^{-i pi k / half}
+      const c2 a = buf[j], b = buf[j + half];
+      const c2 wb = c2{b.x * cs + b.y * sn, b.y * cs - b.x * sn};
+      buf[j] = c2{a.x + wb.x, a.y + wb.y};
+      buf[j + half] = c2{a.x - wb.x, a.y - wb.y};
+    }
+    __syncthreads();
+  }
+  for (int k = threadIdx.x; k < N / 2; k += 256) *reinterpret_cast<c2*>(out + 2 * ((size_t)k * T + t)) = buf[k];
+}
+
 }  // namespace
+
+extern "C" int mg_pcm_to_mono(const void* pcm, int kind, int channels, float* mono, int64_t L, mg_stream_t stream) {
+  MG_CHECK_ARG(pcm && mono && L > 0 && channels >= 1 && channels <= 64 && kind >= MG_PCM_F32 && kind <= MG_PCM_U8,
+               "mg_pcm_to_mono: bad arguments");
+  const long long nb = (L + 255) / 256;
+  hipLaunchKernelGGL(pcm_to_mono_k, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, (hipStream_t)stream, pcm, mono,
+                     (long long)L, channels, kind);
+  MG_CHECK_LAUNCH("mg_pcm_to_mono");
+  return MG_OK;
+}
+
+extern "C" int mg_stft_generic(const float* wav, float* out_c64, int64_t L, int n_fft, int hop, mg_stream_t stream) {
+  MG_CHECK_ARG(wav && out_c64 && hop >= 1, "mg_stft_generic: bad arguments");
+  MG_CHECK_ARG(n_fft >= 64 && n_fft <= 8192 && (n_fft & (n_fft - 1)) == 0, "mg_stft_generic: n_fft=%d is not a power of two in [64, 8192]",
+               n_fft);
+  MG_CHECK_ARG(L > n_fft / 2, "mg_stft_generic: reflect padding needs L > n_fft / 2 (got %lld)", (long long)L);
+  MG_CHECK_ARG(L / hop + 1 < (1ll << 30), "mg_stft_generic: too many frames");
+  const int T = (int)(L / hop) + 1;
+  // periodic Hann: sum w^2 = 3 N / 8
+  const float inv_norm = (float)(1.0 / sqrt(0.375 * (double)n_fft));
+  hipLaunchKernelGGL(stft_generic_k, dim3((unsigned)T), dim3(256), (size_t)n_fft * sizeof(c2), (hipStream_t)stream, wav, out_c64,
+                     (long long)L, T, n_fft, mg_ilog2(n_fft), hop, inv_norm);
+  MG_CHECK_LAUNCH("mg_stft_generic");
+  return MG_OK;
+}
 
 extern "C" int mg_stft_1024(const float* wav, float* out_re, float* out_im, int64_t L, mg_stream_t stream) {
   MG_CHECK_ARG(wav && out_re, "mg_stft_1024: bad arguments");

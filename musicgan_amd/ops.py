@@ -746,6 +746,25 @@ def codec_fwd(stft_c: torch.Tensor, bark_scale: torch.Tensor, nb_vec: int, stack
     return magn, phase
 
 
+def pcm_to_mono(pcm: torch.Tensor) -> torch.Tensor:
+    """PCM frames (L, C) / (L,) as stored -> mono float32 [L] in [-1, 1] (normalisation + mean over channels)."""
+    if not pcm.is_cuda or not pcm.is_contiguous() or pcm.dtype not in _PCM_KIND:
+        raise _lib.MusicGanHipError(f"pcm_to_mono: contiguous GPU tensor of float32 / int16 / int32 / uint8 expected, got {pcm.dtype}")
+    length, ch = pcm.shape[0], (pcm.shape[1] if pcm.dim() == 2 else 1)
+    mono = torch.empty((length,), dtype=torch.float32, device=pcm.device)
+    check(_lib.load().mg_pcm_to_mono(_p(pcm), _PCM_KIND[pcm.dtype], ch, _p(mono), length, _s()), "mg_pcm_to_mono")
+    return mono
+
+
+def stft_generic(wav_mono: torch.Tensor, n_fft: int, hop: int) -> torch.Tensor:
+    """mono fp32 [L] -> complex64 [n_fft/2, 1 + L//hop] for any power-of-two n_fft in [64, 8192] (untuned path)."""
+    _chk(wav_mono)
+    length = wav_mono.numel()
+    out = torch.empty((n_fft // 2, 1 + length // hop, 2), dtype=torch.float32, device=wav_mono.device)
+    check(_lib.load().mg_stft_generic(_p(wav_mono), _p(out), length, int(n_fft), int(hop), _s()), "mg_stft_generic")
+    return torch.view_as_complex(out)
+
+
 def crc32_of_float64(x: torch.Tensor) -> torch.Tensor:
     """x: float32 (n, ...) on the device -> int64 tensor [n] (values < 2^32) of zlib.crc32(x[i].double().numpy().tobytes())."""
     _chk(x)

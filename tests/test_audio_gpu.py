@@ -558,3 +558,31 @@ def test_device_crc32_of_the_float64_payload_equals_zlib():
         got = ops.crc32_of_float64(x.to(DEV)).cpu().tolist()
         want = [zlib.crc32(x[i].double().numpy().tobytes()) & 0xFFFFFFFF for i in range(n)]
         assert got == want, (n, per)
+
+
+def test_stft_with_other_window_and_hop_sizes():
+    """wav_to_stft's nperseg / stride arguments (functions.py:38-41) beyond the drivers' 1024 / 256: the untuned radix-2 path against
+    the oracle (float64 rfft) and torch.stft, incl. a hop that does not divide the window, stereo input and a pure tone landing on
+    its bin; sizes that are not powers of two keep raising an AssertionError."""
+    from musicgan_amd import audio
+    from oracle import audio as OA
+    rng = np.random.default_rng(8)
+    wav = (rng.random(44100, dtype=np.float32) - 0.5)
+    for n_fft, hop in ((64, 16), (256, 100), (512, 128), (2048, 512), (4096, 1000), (8192, 4096)):
+        c = audio.stft_from_waveform(torch.from_numpy(wav), nperseg=n_fft, stride=hop).cpu().numpy()
+        ref = OA.stft(wav, n_fft=n_fft, hop=hop)
+        assert c.shape == ref.shape == (n_fft // 2, 1 + wav.size // hop)
+        assert float(np.abs(c - ref).max()) <= 1e-5 * float(np.abs(ref).max()), (n_fft, hop)
+        w = torch.hann_window(n_fft)
+        ts = torch.stft(torch.from_numpy(wav), n_fft, hop_length=hop, win_length=n_fft, window=w, center=True, pad_mode="reflect",
+                        normalized=False, onesided=True, return_complex=True) / w.pow(2).sum().sqrt()
+        assert float((torch.from_numpy(c) - ts[:-1]).abs().max()) <= 1e-5 * float(ts.abs().max()), (n_fft, hop)
+    stereo = np.stack([wav, wav[::-1].copy()])
+    c = audio.stft_from_waveform(torch.from_numpy(stereo), nperseg=512, stride=64).cpu().numpy()
+    ref = OA.stft(stereo, n_fft=512, hop=64)
+    assert float(np.abs(c - ref).max()) <= 1e-5 * float(np.abs(ref).max())
+    tone = np.sin(2 * np.pi * 37 * np.arange(8192) / 256.0).astype(np.float32)  # bin 37 of a 256-point window
+    mag = np.abs(audio.stft_from_waveform(torch.from_numpy(tone), nperseg=256, stride=64).cpu().numpy())
+    assert (mag[:, 4:-4].argmax(axis=0) == 37).all()
+    with pytest.raises(AssertionError):
+        audio.stft_from_waveform(torch.from_numpy(wav), nperseg=1000, stride=250)
