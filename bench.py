@@ -156,17 +156,14 @@ def time_step(level: int, batch: int, rand_channels: int, device, steps: int, wa
     gen, disc = build_nets(level, rand_channels, device)
     og = FusedAdam(gen.parameters(), lr=1e-3, betas=(0.0, 0.9))
     od = FusedAdam(disc.parameters(), lr=1e-3, betas=(0.0, 0.9))
-    stepper = ProGANStepper(gen, disc, og, od, rand_channels)
     side = LEVEL_SIDE[level]
     rng = torch.Generator(device=device).manual_seed(seed)
+    stepper = ProGANStepper(gen, disc, og, od, rand_channels, noise=rng)
     x_real = torch.rand(batch, 2, side, side, device=device, generator=rng) * 2 - 1
 
     def one():
-        z = torch.randn(batch, rand_channels, 2, 2, device=device, generator=rng)
-        eps = torch.rand(batch, 1, 1, 1, device=device, generator=rng)
-        z2 = torch.randn(batch, rand_channels, 2, 2, device=device, generator=rng)
-        stepper.d_step(x_real, 0.5, z=z, eps=eps)
-        stepper.g_step(batch, 0.5, device, z=z2)
+        stepper.d_step(x_real, 0.5)
+        stepper.g_step(batch, 0.5, device)
 
     for _ in range(warmup):
         one()
@@ -458,18 +455,17 @@ def main():
     gen, disc = build_nets(args.level, args.rand_channels, device)
     optim_gen = FusedAdam(gen.parameters(), lr=1e-3, betas=(0.0, 0.9))
     optim_disc = FusedAdam(disc.parameters(), lr=1e-3, betas=(0.0, 0.9))
-    stepper = ProGANStepper(gen, disc, optim_gen, optim_disc, args.rand_channels)
     side = LEVEL_SIDE[args.level]
     alpha = 0.5
     data_rng = torch.Generator(device=device).manual_seed(1234 + rank)
+    # latents and the penalty's epsilon: fresh per update from this seeded generator, drawn by the stepper as
+    # train.py:143-149 / discriminator.py:166 do -- straight into the replayed graph's input buffers
+    stepper = ProGANStepper(gen, disc, optim_gen, optim_disc, args.rand_channels, noise=data_rng)
     x_real = torch.rand(args.batch, 2, side, side, device=device, generator=data_rng) * 2 - 1
 
     def one_step():
-        z = torch.randn(args.batch, args.rand_channels, 2, 2, device=device, generator=data_rng)
-        eps = torch.rand(args.batch, 1, 1, 1, device=device, generator=data_rng)
-        z2 = torch.randn(args.batch, args.rand_channels, 2, 2, device=device, generator=data_rng)
-        stepper.d_step(x_real, alpha, z=z, eps=eps)
-        stepper.g_step(args.batch, alpha, device, z=z2)
+        stepper.d_step(x_real, alpha)
+        stepper.g_step(args.batch, alpha, device)
 
     def barrier():
         if world > 1:
@@ -500,11 +496,8 @@ def main():
     if world == 1 and not args.no_cadence:
         def cycle():
             for _ in range(5):
-                z = torch.randn(args.batch, args.rand_channels, 2, 2, device=device, generator=data_rng)
-                eps = torch.rand(args.batch, 1, 1, 1, device=device, generator=data_rng)
-                stepper.d_step(x_real, alpha, z=z, eps=eps)
-            z2 = torch.randn(args.batch, args.rand_channels, 2, 2, device=device, generator=data_rng)
-            stepper.g_step(args.batch, alpha, device, z=z2)
+                stepper.d_step(x_real, alpha)
+            stepper.g_step(args.batch, alpha, device)
         cycle()
         stepper.finish()
         torch.cuda.synchronize()

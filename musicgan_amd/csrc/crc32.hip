@@ -32,27 +32,27 @@ unsigned gf2_times(const unsigned* mat, unsigned vec) {
 void gf2_square(unsigned* sq, const unsigned* mat) {
   for (int n = 0; n < 32; ++n) sq[n] = gf2_times(mat, mat[n]);
 }
-const CrcMats& crc_mats() {
-  static CrcMats M;
-  static bool done = false;
-  if (!done) {
-    unsigned a[32], b[32];
-    a[0] = 0xedb88320u;  // one zero BIT
-    for (int n = 1; n < 32; ++n) a[n] = 1u << (n - 1);
-    gf2_square(b, a);    // 2 bits
-    gf2_square(a, b);    // 4 bits
-    gf2_square(b, a);    // 8 bits = 1 byte
-    for (int i = 0; i < 8; ++i) {  // 1 byte -> 256 bytes
-      gf2_square(a, b);
-      std::memcpy(b, a, sizeof(a));
-    }
-    for (int k = 0; k < CRC_MAX_LEVELS; ++k) {
-      std::memcpy(M.m[k], b, sizeof(b));
-      gf2_square(a, b);
-      std::memcpy(b, a, sizeof(a));
-    }
-    done = true;
+CrcMats make_crc_mats() {
+  CrcMats M;
+  unsigned a[32], b[32];
+  a[0] = 0xedb88320u;  // one zero BIT
+  for (int n = 1; n < 32; ++n) a[n] = 1u << (n - 1);
+  gf2_square(b, a);    // 2 bits
+  gf2_square(a, b);    // 4 bits
+  gf2_square(b, a);    // 8 bits = 1 byte
+  for (int i = 0; i < 8; ++i) {  // 1 byte -> 256 bytes
+    gf2_square(a, b);
+    std::memcpy(b, a, sizeof(a));
   }
+  for (int k = 0; k < CRC_MAX_LEVELS; ++k) {
+    std::memcpy(M.m[k], b, sizeof(b));
+    gf2_square(a, b);
+    std::memcpy(b, a, sizeof(a));
+  }
+  return M;
+}
+const CrcMats& crc_mats() {
+  static const CrcMats M = make_crc_mats();  // (C++11: initialised once, thread-safe)
   return M;
 }
 

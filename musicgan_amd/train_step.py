@@ -59,6 +59,12 @@ class ProGANStepper:
         return torch.randn(n, self.rand_channels, self.h, self.w, device=device,
                            generator=generator if generator is not None else self.noise)
 
+    def _latent_into(self, out: torch.Tensor) -> None:
+        torch.randn(out.shape, device=out.device, generator=self.noise, out=out)
+
+    def _eps_into(self, out: torch.Tensor) -> None:
+        torch.rand(out.shape, device=out.device, generator=self.noise, out=out)
+
     def _update(self, bucket: GradBucket, net, optim) -> None:
         if self.dp:
             bucket.launch(net.parameters())
@@ -70,13 +76,17 @@ class ProGANStepper:
     def d_step(self, x_real: torch.Tensor, alpha: float, z: Optional[torch.Tensor] = None,
                eps: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         n = x_real.shape[0]
+        if self.fused_d_step and self.use_graphs:
+            # noise that is not injected is drawn straight into the replayed graph's input buffers (same generator stream, two
+            # copy launches fewer per update: at levels 3-4 an update is ~100 launches of 5-20 us)
+            return self._graphed("D", (x_real, z, eps), alpha,
+                                 draw=(None, lambda out: self._latent_into(out), lambda out: self._eps_into(out)),
+                                 shapes=(tuple(x_real.shape), (n, self.rand_channels, self.h, self.w), (n, 1, 1, 1)))
         if z is None:
             z = self._latent(n, x_real.device)
         if self.fused_d_step:
             if eps is None:
                 eps = torch.rand(n, 1, 1, 1, device=x_real.device, generator=self.noise)
-            if self.use_graphs:
-                return self._graphed("D", (x_real, z, eps), alpha)
             return self._d_step_fused(x_real, alpha, z, eps)
         if self.dp:
             self.bucket_d.wait()  # D weights final (Adam of the previous D step)
@@ -142,10 +152,11 @@ class ProGANStepper:
         return {"disc_loss": disc_loss, "grad_pen": grad_pen, "out_real_mean": stats[0], "out_fake_mean": stats[1]}
 
     def g_step(self, batch_size: int, alpha: float, device, z: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        if self.use_graphs:
+            return self._graphed("G", (z,), alpha, draw=(lambda out: self._latent_into(out),),
+                                 shapes=((batch_size, self.rand_channels, self.h, self.w),), device=device)
         if z is None:
             z = self._latent(batch_size, device)
-        if self.use_graphs:
-            return self._graphed("G", (z,), alpha)
         if self.fused_d_step:
             return self._g_step_fused(z, alpha)
         if self.dp:
@@ -214,7 +225,19 @@ class ProGANStepper:
     # ------------------------------------------------------------------ HIP-graph replay of whole updates
     _WARM_CALLS = 2
 
-    def _graphed(self, kind: str, inputs, alpha: float) -> Dict[str, torch.Tensor]:
+    def _graphed(self, kind: str, inputs, alpha: float, draw=None, shapes=None, device=None) -> Dict[str, torch.Tensor]:
+        """`inputs` may hold None where the caller did not inject noise: `draw[i](buffer)` then fills it -- into a fresh tensor while
+        the update still runs eagerly, straight into the graph's static input afterwards."""
+        if any(t is None for t in inputs):
+            dev = device if device is not None else next(t.device for t in inputs if t is not None)
+            have = self._graphs_entry_inputs(kind, shapes)
+            filled = []
+            for i, t in enumerate(inputs):
+                if t is None:
+                    t = have[i] if have is not None else torch.empty(shapes[i], dtype=torch.float32, device=dev)
+                    draw[i](t)
+                filled.append(t)
+            inputs = tuple(filled)
         net, other = (self.disc, self.gen) if kind == "D" else (self.gen, self.disc)
         opt_sig = (self.optim_disc if kind == "D" else self.optim_gen)
         opt_sig = opt_sig.capture_signature() if hasattr(opt_sig, "capture_signature") else ()
@@ -267,7 +290,8 @@ class ProGANStepper:
                     st["step"].copy_(v)
                 return run(alpha, *inputs)
         for dst, src in zip(ent["inputs"], inputs):
-            dst.copy_(src)
+            if dst is not src:  # (noise drawn above already sits in the static buffer)
+                dst.copy_(src)
         if self._fade_value != float(alpha):
             self._fade[0:1].fill_(float(alpha))
             self._fade[1:2].fill_(1.0 - float(alpha))
@@ -289,6 +313,14 @@ class ProGANStepper:
             self._update(self.bucket_d if kind == "D" else self.bucket_g, net, self.optim_disc if kind == "D" else self.optim_gen)
         out = ent["out"].clone()
         return {k: out[i] for i, k in enumerate(ent["names"])}
+
+    def _graphs_entry_inputs(self, kind: str, shapes):
+        """The static input buffers of the captured graph this call will replay, if it exists (same key as `_graphed` builds)."""
+        net = self.disc if kind == "D" else self.gen
+        opt = self.optim_disc if kind == "D" else self.optim_gen
+        sig = opt.capture_signature() if hasattr(opt, "capture_signature") else ()
+        ent = self._graphs.get((kind, self.gen.curr_layer, tuple(tuple(s) for s in shapes), tuple(id(p) for p in net.parameters()), sig))
+        return ent["inputs"] if ent is not None and "graph" in ent else None
 
     def _capture(self, ent, kind, net, other, inputs, alpha, in_line, run) -> None:
         # capture: static copies of the inputs, every weight form re-packed inside the graph (caches emptied first), the
