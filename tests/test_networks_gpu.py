@@ -463,3 +463,47 @@ def test_user_code_gradient_penalty_through_autograd_equals_the_module_path(case
         assert k in got, k
         assert float((got[k] - w).abs().max()) <= 2e-5 * float(w.abs().max()), (k, float((got[k] - w).abs().max()), float(w.abs().max()))
     assert x_i.grad is None or float(x_i.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("case", ["l3_rc32_fade", "l2_rc16_gpnorm1"])
+def test_opt_in_small_map_chains_compute_the_same_update(case, monkeypatch):
+    """MG_SMALLNET=1 (the multi-layer chains of csrc/smallnet.hip: critic tail forward / data gradient / tangent and generator
+    head forward / backward as one launch per pass; opt-in because slower) against the fp64 oracle with the same budgets as
+    the default path: a fused critic update and a generator update, level-3 (fade-in live) and level-2 cases."""
+    from musicgan_amd.optim import FusedAdam
+    from musicgan_amd.train_step import ProGANStepper
+    from oracle import progan as O
+    monkeypatch.setenv("MG_SMALLNET", "1")
+    monkeypatch.setenv("MG_GRAPHS", "0")
+    g = load(f"progan_{case}.npz")
+    alpha = float(g["alpha"])
+    z, z2 = torch.from_numpy(g["z"]).to(DEV), torch.from_numpy(g["z2"]).to(DEV)
+    x_real, eps = torch.from_numpy(g["x_real"]).to(DEV), torch.from_numpy(g["eps"]).to(DEV)
+    gs, ds = build_oracle_states(g)
+    oargs = (torch.from_numpy(g["x_real"]), torch.from_numpy(g["z"]), torch.from_numpy(g["eps"]), alpha)
+    o64 = O.d_step(gs, ds, *oargs, dtype=torch.float64, detach_fake=True)
+    o32 = O.d_step(gs, ds, *oargs, dtype=torch.float32, detach_fake=True)
+    terms = O.real_term_grads(ds, oargs[0], alpha)
+    gen, disc = build_modules(g)
+    from musicgan_amd.networks import engine
+    if len(disc._weights().blocks) >= 4:
+        assert engine.disc_tail_start(disc._weights(), x_real.shape[2], x_real.shape[3]) is not None  # the chain is really taken
+    og = FusedAdam(gen.parameters(), lr=1e-3, betas=(0.0, 0.9))
+    od = FusedAdam(disc.parameters(), lr=1e-3, betas=(0.0, 0.9))
+    od.step = og.step = lambda *a, **k: None
+    st = ProGANStepper(gen, disc, og, od, int(g["rand_channels"]))
+    m = st.d_step(x_real, alpha, z=z, eps=eps)
+    assert abs(float(m["grad_pen"]) - float(o64["grad_pen"])) <= 1e-5 * max(1.0, float(o64["grad_pen"]) / 10.0)
+    for k, ref in o64["d_grads"].items():
+        got = dict(disc.named_parameters())[k].grad
+        if float(ref.abs().max()) < 1e-12:
+            assert float(got.abs().max()) <= 1e-6
+            continue
+        assert maxabs_err(got, ref) <= grad_atol(k, o64["d_grads"], o32["d_grads"], terms), k
+    og64 = O.g_step(gs, ds, torch.from_numpy(g["z2"]), alpha, dtype=torch.float64)
+    og32 = O.g_step(gs, ds, torch.from_numpy(g["z2"]), alpha, dtype=torch.float32)
+    st.g_step(z2.shape[0], alpha, DEV, z=z2)
+    for k, ref in og64["g_grads"].items():
+        got = dict(gen.named_parameters())[k].grad
+        tol = max(GRAD_TOL, 2.0 * maxrel(og32["g_grads"][k], ref))
+        assert maxrel(got, ref) <= tol, (k, maxrel(got, ref), tol)
