@@ -19,6 +19,9 @@ HOT = [
     (r"wgrad3x3_mfma", 0),
     (r"upconv3x3_mfma", 0),
     (r"downconv4x4s2_mfma", 0),
+    (r"smallconv_k", 0),
+    (r"smallnet_k", 0),
+    (r"crc32_f64_chunks_k", 0),
     (r"stft1024_kernel", 0),
     (r"codec_row_pass", 0),
 ]
