@@ -334,6 +334,12 @@ int mg_smallnet(const mg_sn_op_t* ops, int nops, int N, int imgs_per_wg, size_t 
 int mg_conv3x3_small_supported(int N, int Cin, int Cout, int H, int W);
 int mg_conv3x3_small(const float* x, const float* wpk, const float* bias, const float* aux, float* y, float* p, int N, int Cin,
                      int Cout, int H, int W, int flags, float slope, mg_stream_t stream);
+/* The same launch with the PixelNorm of the layer in front [layers.py:11-17; generator.py:22-23,38-39: ... LeakyReLU -> PixelNorm
+ * -> (Upsample ->) Conv2d] folded into its input staging: x_raw is the UN-normalised activation, y = act(conv(PixelNorm(x_raw)) +
+ * bias); pn_p (N,Cin,Hin,Win) and pn_rn (N,1,Hin,Win) receive the normalised activation and 1 / norm (what the backward pass keeps;
+ * may be NULL).  flags: MG_CONV_UPS_IN, MG_CONV_LRELU. */
+int mg_conv3x3_small_pn(const float* x_raw, const float* wpk, const float* bias, float* y, float* pn_p, float* pn_rn, int N, int Cin,
+                        int Cout, int H, int W, int flags, float slope, mg_stream_t stream);
 
 /* ------------------------------------------------------------------ magnitude/phase codec + inverse STFT
  * mg_codec_fwd: stft_to_phase_magn [audio/functions.py:65-94].  stft_c64: interleaved complex64 [512][T] (mg_stft_1024 output);

@@ -114,6 +114,7 @@ SIGNATURES = {
     "mg_pack_multi": (c_int, [_P, c_int, _P]),
     "mg_conv3x3_small_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "mg_conv3x3_small": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
+    "mg_conv3x3_small_pn": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "mg_smallnet_packed_floats": (c_size_t, [c_int, c_int]),
     "mg_smallnet_buffer_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "mg_smallnet": (c_int, [_P, c_int, c_int, c_int, c_size_t, c_float, _P]),

@@ -517,11 +517,14 @@ struct ScArgs {
   const float* aux;
   float* y;
   float* p;
+  float* pn_p;   // SC_PN_IN: PixelNorm(x) (N, Cin, Hin, Win) and
+  float* pn_rn;  //           its per-pixel 1 / norm (N, 1, Hin, Win), written by the workgroups of out-channel tile 0 (may be NULL)
   int N, Cin, Cout, H, W, flags, G;
   int R;  // image rows per workgroup (R < H: one image per workgroup, H / R bands of it; their halo rows are staged too)
   float slope, pool_scale;
 };
 constexpr int SC_UNPOOL = 1 << 20;  // internal: y is (N, Cout, 2H, 2W) = 0.25 * result * lrelu'(aux), aux of that shape
+constexpr int SC_PN_IN = 1 << 21;   // internal: x is the un-normalised activation; PixelNorm is applied to the staged copy
 
 template <int NTW>
 __global__ void __launch_bounds__(SN_THREADS) smallconv_k(const ScArgs a) {
@@ -543,6 +546,46 @@ __global__ void __launch_bounds__(SN_THREADS) smallconv_k(const ScArgs a) {
   if (g0 < g1) F.fill(g0);
   stage_images(a.x, xs, gi, G, a.Cin, img0, a.N, a.flags & MG_CONV_UPS_IN, a.H, row0);
   __syncthreads();
+  if (a.flags & SC_PN_IN) {
+    // PixelNorm (layers.py:11-17) of the layer in front, applied to the staged pixels instead of by a launch of its own between two
+    // small convolutions: every workgroup holds ALL input channels of its pixels (it needs them for K), so the channel reduction
+    // is local -- one wave per pixel, lanes over channels, DPP sum; every out-channel tile's workgroup repeats it (a few hundred
+    // cycles), tile 0's also writes p and 1/norm for the backward pass.  Halo rows of a band are neighbours' pixels: normalised
+    // too, stored by their owners.  Up-sampled input: a staged pixel is a copy of its low-resolution one (same norm); the
+    // even-coordinate copy stores.
+    const bool ups = a.flags & MG_CONV_UPS_IN;
+    const int Hin = ups ? a.H >> 1 : a.H, Win = ups ? a.W >> 1 : a.W;
+    const int rows = gi.H + 2, npix = G * rows * gi.W;
+    for (int pi = wave; pi < npix; pi += 4) {
+      const int nl = pi / (rows * gi.W), r = pi - nl * (rows * gi.W), yy = r / gi.W, xx = r - yy * gi.W;
+      const int y = row0 + yy - 1;
+      if (y < 0 || y >= a.H || img0 + nl >= a.N) continue;  // (wave-uniform)
+      float* row = xs + (nl * gi.SPI + yy * gi.W2 + xx + 1) * gi.CS;
+      float v[3];
+      float part = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < a.Cin ? row[c] : 0.f;
+        part = fmaf(v[i], v[i], part);
+      }
+      const float tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mg_wave_sum_to_lane63(part)), 63));
+      const float rn = 1.0f / sqrtf(tot / (float)a.Cin + SN_PN_EPS);
+      const bool owner = mt == 0 && yy >= 1 && yy <= gi.H && (!ups || (((y | xx) & 1) == 0));
+      const size_t pix = (size_t)(ups ? (y >> 1) * Win + (xx >> 1) : y * Win + xx);
+      if (owner && lane == 0 && a.pn_rn != nullptr) a.pn_rn[(size_t)(img0 + nl) * (Hin * Win) + pix] = rn;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int c = lane + 64 * i;
+        if (c < a.Cin) {
+          const float pn = v[i] * rn;
+          row[c] = pn;
+          if (owner && a.pn_p != nullptr) a.pn_p[((size_t)(img0 + nl) * a.Cin + c) * (Hin * Win) + pix] = pn;
+        }
+      }
+    }
+    __syncthreads();
+  }
   const int npx = G * gi.HW;
   const int col = lane & 15, q = lane >> 4;
   int boff[NTW];
@@ -613,8 +656,24 @@ extern "C" int mg_conv3x3_small_supported(int N, int Cin, int Cout, int H, int W
          Cout <= 192 && N > 0;
 }
 
+static int small_conv_launch(const float* x, const float* wpk, const float* bias, const float* aux, float* y, float* p, float* pn_p,
+                             float* pn_rn, bool pn_in, int N, int Cin, int Cout, int H, int W, int flags, float slope,
+                             mg_stream_t stream);
+
 extern "C" int mg_conv3x3_small(const float* x, const float* wpk, const float* bias, const float* aux, float* y, float* p, int N,
                                 int Cin, int Cout, int H, int W, int flags, float slope, mg_stream_t stream) {
+  return small_conv_launch(x, wpk, bias, aux, y, p, nullptr, nullptr, false, N, Cin, Cout, H, W, flags, slope, stream);
+}
+
+extern "C" int mg_conv3x3_small_pn(const float* x_raw, const float* wpk, const float* bias, float* y, float* pn_p, float* pn_rn, int N,
+                                   int Cin, int Cout, int H, int W, int flags, float slope, mg_stream_t stream) {
+  MG_CHECK_ARG(!(flags & ~(MG_CONV_UPS_IN | MG_CONV_LRELU)), "mg_conv3x3_small_pn: flags %d (UPS_IN and LRELU only)", flags);
+  return small_conv_launch(x_raw, wpk, bias, nullptr, y, nullptr, pn_p, pn_rn, true, N, Cin, Cout, H, W, flags, slope, stream);
+}
+
+static int small_conv_launch(const float* x, const float* wpk, const float* bias, const float* aux, float* y, float* p, float* pn_p,
+                             float* pn_rn, bool pn_in, int N, int Cin, int Cout, int H, int W, int flags, float slope,
+                             mg_stream_t stream) {
   MG_CHECK_ARG(x && wpk && N > 0 && mg_conv3x3_small_supported(N, Cin, Cout, H, W), "mg_conv3x3_small: unsupported shape");
   const bool pool = flags & (MG_CONV_POOL_OUT | MG_CONV_UPSUM_OUT), unpool = flags & MG_CONV_UNPOOL;
   MG_CHECK_ARG(!(flags & ~(MG_CONV_UPS_IN | MG_CONV_LRELU | MG_CONV_MASK_AUX | MG_CONV_POOL_OUT | MG_CONV_UPSUM_OUT | MG_CONV_UNPOOL)),
@@ -625,9 +684,9 @@ extern "C" int mg_conv3x3_small(const float* x, const float* wpk, const float* b
   MG_CHECK_ARG(!unpool || (y && !pool && !(flags & (MG_CONV_MASK_AUX | MG_CONV_LRELU))), "mg_conv3x3_small: UNPOOL stands alone");
   MG_CHECK_ARG(y || pool, "mg_conv3x3_small: no output");
   ScArgs a;
-  a.x = x; a.wpk = wpk; a.bias = bias; a.aux = aux; a.y = y; a.p = p;
+  a.x = x; a.wpk = wpk; a.bias = bias; a.aux = aux; a.y = y; a.p = p; a.pn_p = pn_p; a.pn_rn = pn_rn;
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.slope = slope;
-  a.flags = (flags & (MG_CONV_UPS_IN | MG_CONV_LRELU | MG_CONV_MASK_AUX)) | (pool ? MG_CONV_POOL_OUT : 0) | (unpool ? SC_UNPOOL : 0);
+  a.flags = (flags & (MG_CONV_UPS_IN | MG_CONV_LRELU | MG_CONV_MASK_AUX)) | (pool ? MG_CONV_POOL_OUT : 0) | (unpool ? SC_UNPOOL : 0) | (pn_in ? SC_PN_IN : 0);
   a.pool_scale = (flags & MG_CONV_UPSUM_OUT) ? 1.0f : 0.25f;
   const int MT = mg_cdiv(Cout, 16), HW = H * W;
   // Images per workgroup: one, doubled while the grid is beyond ~1024 workgroups (every workgroup re-reads its out-channel tile's

@@ -341,7 +341,48 @@ def gen_forward(W: GenWeights, z: torch.Tensor, alpha: float, cache: PackCache, 
         sn.conv(2, 0, cache.get_sn(w2a, False), rc, c0, 4, 4, bias=b2a, lrelu=True).pixnorm(0, c0, 4, 4, p2a, rn2a)
         sn.conv(0, 1, cache.get_sn(w1b, False), c0, c1, 4, 4, bias=b1b, lrelu=True).pixnorm(1, c1, 4, 4, p1b, rn1b)
         sn.run(n)
-    for bi, (w1, b1, w2, b2) in enumerate(W.blocks):
+    if not head and os.environ.get("MG_PN_STAGED", "1") != "0":
+        # PixelNorm folded into the NEXT convolution's input staging wherever both neighbours are small-map launches: a conv leaves
+        # its LeakyReLU output un-normalised ("raw") and the following mg_conv3x3_small_pn normalises while staging, writing p and
+        # 1 / norm as side outputs -- four PixelNorm launches fewer per generator forward pass from level 3 on.
+        convs = []
+        for (w1, b1, w2, b2) in W.blocks:
+            convs += [(w1, b1, w1.shape[0], False), (w2, b2, w2.shape[0], True)]
+        cur, raw = x, None          # the normalised input of the next conv, or (raw) an activation whose PixelNorm is pending
+        pr = [None] * len(convs)    # (p, rn) per conv
+        for k, (w, b, cout, ups) in enumerate(convs):
+            if raw is not None:
+                probe = raw
+                if PackCache.small_ok(probe, cout, ups=ups, lrelu=True):
+                    # (without `save` only the input of the last block is still needed as a tensor: the old head reads it)
+                    need = save or (W.old_head is not None and k - 1 == len(convs) - 3)
+                    y, p_prev, rn_prev = ops.conv3x3_small_pn(raw, cache.get_sn(w, False), b, cout, ups=ups, save=need)
+                    pr[k - 1] = (p_prev, rn_prev)
+                    raw = y
+                    continue
+                cur, rn_prev = ops.pixelnorm_fwd(raw)
+                pr[k - 1] = (cur, rn_prev)
+                raw = None
+            n_, ci_, h_, w_ = cur.shape
+            if gen_conv_form(n_, ci_, cout, h_, w_, ups) == "conv+pixnorm" and PackCache.small_ok(cur, cout, ups=ups, lrelu=True):
+                raw = cache.conv(cur, w, False, b, cout, ups=ups, lrelu=True)  # its PixelNorm: by the next conv, or below
+            else:
+                cur, rn_k = cache.conv_lrelu_pixnorm(cur, w, b, cout, ups=ups)
+                pr[k] = (cur, rn_k)
+        if raw is not None:
+            cur, rn_k = ops.pixelnorm_fwd(raw)
+            pr[-1] = (cur, rn_k)
+        xin = x
+        for bi in range(len(W.blocks)):
+            (p1, rn1), (p2, rn2) = pr[2 * bi], pr[2 * bi + 1]
+            if save:
+                saved.append((xin, rn1, p1, rn2, p2))
+            x_in_last, xin = xin, p2
+        x = xin
+        blocks_iter = ()
+    else:
+        blocks_iter = W.blocks
+    for bi, (w1, b1, w2, b2) in enumerate(blocks_iter):
         ci, co = w1.shape[0], w2.shape[0]
         if head and bi == 0:
             if save:

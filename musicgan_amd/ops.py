@@ -474,6 +474,22 @@ def conv3x3_small(x, wpk, bias, cout: int, *, ups=False, lrelu=False, mask_aux=N
     return (y, p) if (pool or upsum) else y
 
 
+def conv3x3_small_pn(x_raw, wpk, bias, cout: int, *, ups=False, lrelu=True, save=True):
+    """act(conv3x3(PixelNorm(x_raw)) + bias) with the PixelNorm of the layer in front folded into the convolution's input staging
+    (mg_conv3x3_small_pn).  Returns (y, p, rn): y the new activation, p = PixelNorm(x_raw) and rn = 1 / norm of x_raw's pixels
+    (None, None without `save`)."""
+    _chk(x_raw, wpk, bias)
+    n, cin, hin, win = x_raw.shape
+    h, w = (2 * hin, 2 * win) if ups else (hin, win)
+    y = torch.empty((n, cout, h, w), dtype=torch.float32, device=x_raw.device)
+    p = torch.empty_like(x_raw) if save else None
+    rn = torch.empty((n, 1, hin, win), dtype=torch.float32, device=x_raw.device) if save else None
+    flags = (MG_CONV_UPS_IN if ups else 0) | (MG_CONV_LRELU if lrelu else 0)
+    check(_lib.load().mg_conv3x3_small_pn(_p(x_raw), _p(wpk), _p(bias), _p(y), _p(p), _p(rn), n, cin, cout, h, w, flags, SLOPE, _s()),
+          "mg_conv3x3_small_pn")
+    return y, p, rn
+
+
 def pack_smallnet(w: torch.Tensor, dgrad: bool) -> torch.Tensor:
     """Filters of a 3x3 convolution in the operand order mg_smallnet streams (MG_PACK_SMALLNET)."""
     _chk(w)

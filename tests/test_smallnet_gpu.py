@@ -278,3 +278,24 @@ def test_conv3x3_small_every_epilogue(n):
         if h <= 4 and w <= 4:
             yu = ops.conv3x3_small(d(x), wp, d(b), co, ups=True, lrelu=True)
             assert _rel(yu, lr(F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), wt.double(), b.double(), padding=1))) < 2e-6
+
+
+@pytest.mark.parametrize("n,c,h,ups", [(5, 32, 2, True), (24, 128, 4, False), (8, 128, 4, True), (3, 112, 8, False), (64, 20, 4, False)])
+def test_conv3x3_small_with_pixelnorm_folded_into_its_staging(n, c, h, ups):
+    """mg_conv3x3_small_pn: LeakyReLU(conv(PixelNorm(x_raw)) + bias) with p = PixelNorm(x_raw) and 1 / norm as side outputs, against
+    float64 (layers.py:11-17 + F.conv2d), incl. nearest-upsampled input (the norm is the low-resolution pixel's), 8x8 row bands
+    (halo rows normalised by the neighbours' workgroups too) and a channel count that is not a multiple of 16."""
+    from musicgan_amd import ops
+    gen = torch.Generator().manual_seed(77 + n)
+    co = 48
+    x = torch.randn(n, c, h, h, generator=gen)
+    wt, b = _w(co, c, gen), torch.randn(co, generator=gen) * 0.1
+    xd = x.double()
+    rn = 1.0 / torch.sqrt((xd * xd).mean(dim=1, keepdim=True) + 1e-8)
+    p = xd * rn
+    src = F.interpolate(p, scale_factor=2, mode="nearest") if ups else p
+    want = F.leaky_relu(F.conv2d(src, wt.double(), b.double(), padding=1), SLOPE)
+    y, pg, rg = ops.conv3x3_small_pn(x.to(DEV), ops.pack_smallnet(wt.to(DEV), False), b.to(DEV), co, ups=ups)
+    assert _rel(pg, p) < 2e-6 and _rel(rg, rn) < 2e-6 and _rel(y, want) < 3e-6
+    y2, p2, r2 = ops.conv3x3_small_pn(x.to(DEV), ops.pack_smallnet(wt.to(DEV), False), b.to(DEV), co, ups=ups, save=False)
+    assert p2 is None and r2 is None and torch.equal(y2, y)
