@@ -8,6 +8,7 @@
 // adds in the reference, so it runs SEQUENTIALLY per frequency row in fp32 here too (inv_phase_cumsum: one lane per row walks
 // time through LDS tiles).  Everything else is embarrassingly parallel and HBM-bound (8 B in + 8 B out per bin).
 #include "mg_common.h"
+#include "sleef_f32.h"
 
 #include <cstdint>
 
@@ -138,8 +139,14 @@ __global__ void __launch_bounds__(RT) codec_row_pass(const float2* __restrict__ 
     float m[RQ], ph[RQ];
 #pragma unroll
     for (int e = 0; e < RQ; ++e) {
+      // th.abs / th.angle with torch's own bits (sleef_f32.h); MG_CODEC_OCML_MATH keeps rocm's device library for A/B timing
+#ifdef MG_CODEC_OCML_MATH
       m[e] = hypotf(x[e].x, x[e].y) * sc;
       ph[e] = atan2f(x[e].y, x[e].x);
+#else
+      slf::abs_angle(x[e].x, x[e].y, m[e], ph[e]);
+      m[e] *= sc;
+#endif
     }
     load(it + 3, x);
     auto valid = [&](int col) { return col + lead >= 1 && col < nout; };  // 1 <= t <= T-1

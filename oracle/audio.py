@@ -46,7 +46,13 @@ def stft(wav: np.ndarray, n_fft: int = N_FFT, hop: int = STFT_STRIDE) -> np.ndar
     return spec[:-1, :].astype(np.complex64)
 
 
-def bark_scale_vector(nb_freq: int = N_FFT // 2) -> np.ndarray:
+def bark_scale_vector(nb_freq: int = N_FFT // 2, lib: str = "numpy") -> np.ndarray:
+    """functions.py:29-35.  lib="torch": the same three library calls (linspace, arcsinh, norm) made through torch on the CPU as the
+    reference makes them -- numpy's differ from them by one ulp on part of the 512 entries, i.e. on whole rows of the magnitude."""
+    if lib == "torch":
+        import torch
+        scale = 6. * torch.arcsinh(torch.linspace(20., 44100 // 2, nb_freq) / 600.)
+        return (scale / scale.norm()).numpy()
     f = np.linspace(20.0, 44100 // 2, nb_freq, dtype=np.float32)
     s = (6.0 * np.arcsinh(f / np.float32(600.0))).astype(np.float32)
     return (s / np.sqrt(np.sum(s.astype(np.float64) ** 2)).astype(np.float32)).astype(np.float32)
@@ -77,16 +83,30 @@ def _abs_angle(c: np.ndarray, lib: str):
     if isinstance(lib, tuple):  # (|X|, angle X) evaluated elsewhere, e.g. by the device's own math library: isolates the scan
         return np.asarray(lib[0], dtype=np.float32), np.asarray(lib[1], dtype=np.float32)
     if lib == "torch":
+        # ATen runs abs / angle through SLEEF's vector routines on full vectors and through libm's scalar hypotf / atan2f on the
+        # remainder elements at the end of every thread's chunk (TensorIterator's vectorized_loop), so the reference's own bits
+        # depend on the thread count of the machine: 5 or 7 instead of 8 threads moves one element of a 512 x 6151 input by an
+        # ulp, and the running sum carries it down the row.  The oracle evaluates the vector routine on EVERY element: one
+        # thread, length padded to a multiple of 64 -- what the reference computes on all but a handful of elements, and what
+        # the device restates (csrc/sleef_f32.h).
         import torch
-        t = torch.from_numpy(np.ascontiguousarray(c, dtype=np.complex64))
-        return torch.abs(t).numpy(), torch.angle(t).numpy()
+        flat = np.ascontiguousarray(c, dtype=np.complex64).reshape(-1)
+        pad = (-flat.size) % 64
+        t = torch.from_numpy(np.concatenate([flat, np.ones(pad, np.complex64)]) if pad else flat)
+        nthr = torch.get_num_threads()
+        torch.set_num_threads(1)
+        try:
+            m, a = torch.abs(t).numpy(), torch.angle(t).numpy()
+        finally:
+            torch.set_num_threads(nthr)
+        return m[:flat.size].reshape(c.shape), a[:flat.size].reshape(c.shape)
     assert lib == "numpy", lib
     return np.abs(c).astype(np.float32), np.angle(c).astype(np.float32)
 
 
 def stft_to_phase_magn(c: np.ndarray, nb_vec: int = N_VEC, lib="numpy"):
     magn, phase = _abs_angle(c, lib)
-    magn = magn * bark_scale_vector(c.shape[0])[:, None]
+    magn = magn * bark_scale_vector(c.shape[0], "torch" if isinstance(lib, str) and lib == "torch" else "numpy")[:, None]
     phase = unwrap(phase)
     phase = phase[:, 1:] - phase[:, :-1]
     magn = magn[:, 1:]

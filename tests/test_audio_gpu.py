@@ -84,13 +84,11 @@ def _c5_check_magn(g, case, magn, tol):
 def test_codec_at_config5_size_against_the_reference():
     """BASELINE config 5 at its stated size: stft_to_phase_magn (functions.py:65-94) on 103 360 frames -> 201 images against the
     REFERENCE's output on the same bits (library-independent STFT-like input whose unwrapped phase reaches 1.6e5 rad).
-    The phase image is discontinuous in its input (golden_util.c5_phase_stats): the GPU's atan2f differs from torch's by an ulp on
-    part of the bins, the exact running sum (torch.cumsum: float64 accumulator) turns that into one ulp(1e5 rad) on ~0.1 % of the
-    elements.  Bounds: >= 92 % of the sampled elements within 1e-6, none beyond 0.6 of two ulps of the unwrapped phase, <= 1 wrap flip
-    (the numpy oracle, same sum with numpy's atan2f, sits at 94 %; a float32 running sum -- rounds 1-2 -- at 0.05 %).
-    Second, the scan itself with the math library taken out: the oracle's codec fed the device's own |X| and angle(X) must
-    reproduce the kernel's images bit for bit."""
-    from golden_util import c5_phase_stats
+    The phase image is discontinuous in angle(X): one ulp of atan2f moves the float32 rounding of the running sum, which is why
+    rounds 1-3 (rocm's atan2f) matched the reference on 94 % of the elements only.  The kernel now evaluates th.abs / th.angle
+    with the algorithm of the library torch calls (csrc/sleef_f32.h) and keeps torch.cumsum's float64 accumulator, so EVERY sampled
+    element of both images must be the reference's to the bit (a float32 running sum -- rounds 1-2 -- sat at 0.05 %)."""
+    from golden_util import c5_phase_stats, c5_sample_idx
     from musicgan_amd import audio
     from oracle import audio as OA
     g, x = _c5("spec")
@@ -99,22 +97,19 @@ def test_codec_at_config5_size_against_the_reference():
     assert tuple(magn.shape) == tuple(phase.shape) == (201, 512, 512)
     frac, worst, flips, n = c5_phase_stats(g, "spec", phase.cpu().numpy())
     print(f"config-5 codec vs reference: {frac:.4%} of {n} within 1e-6, worst {worst:.3f} of the 2-ulp bound, {flips} flips")
-    # gates = measured (94.05 %, worst 0.5 of the bound, 0 flips) less a small margin, so that a regression shows
-    assert frac >= 0.92 and worst <= 0.6 and flips <= 1, (frac, worst, flips, n)
-    _c5_check_magn(g, "spec", magn, 2e-6)
+    assert frac == 1.0 and worst == 0.0 and flips == 0, (frac, worst, flips, n)
+    idx = torch.from_numpy(c5_sample_idx(phase.numel())).to(DEV)
+    assert np.array_equal(phase.reshape(-1)[idx].cpu().numpy(), g["spec|phase|samp"]), "phase samples are not the reference's bits"
+    _c5_check_magn(g, "spec", magn, 0.0)
     assert float(magn.min()) == -1.0 and float(magn.max()) == 1.0 and float(phase.min()) == -1.0 and float(phase.max()) == 1.0
     # the stacked form create_dataset uses is the same bits in one (S, 2, 512, 512) tensor
     from musicgan_amd import ops
     both = ops.codec_fwd(xd, audio.functions._bark_vector(512, xd.device), 512, stacked=True)
     assert torch.equal(both[:, 0], magn) and torch.equal(both[:, 1], phase)
     del both
-    # scan isolated from the math library
-    m_dev = (torch.abs(xd)).cpu().numpy()
-    p_dev = torch.angle(xd).cpu().numpy()
-    m_or, p_or = OA.stft_to_phase_magn(x, lib=(m_dev, p_dev))
-    same = float(np.mean(p_or == phase.cpu().numpy()))
-    print(f"scan vs oracle on the device's own angle(X): {same:.6%} bit-identical")
-    assert same >= 0.999, same
+    # and the whole of both images, not only the fixture's samples, against the oracle with torch's CPU abs / angle
+    m_or, p_or = OA.stft_to_phase_magn(x, lib="torch")
+    assert np.array_equal(p_or, phase.cpu().numpy()) and np.array_equal(m_or, magn.cpu().numpy())
 
 
 def test_waveform_to_codec_at_config5_size_against_the_reference():
@@ -204,17 +199,15 @@ def test_codec_odd_sizes_against_oracle():
         x = x.astype(np.complex64)
         xd = torch.from_numpy(x).to(DEV)
         magn, phase = audio.stft_to_phase_magn(xd, nb_vec=nb)
-        m_or, p_or = OA.stft_to_phase_magn(x, nb_vec=nb, lib=(torch.abs(xd).cpu().numpy(), torch.angle(xd).cpu().numpy()))
+        m_or, p_or = OA.stft_to_phase_magn(x, nb_vec=nb, lib="torch")  # th.abs / th.angle as the reference calls them (CPU)
         assert tuple(magn.shape) == m_or.shape == ((frames - 1) // nb, 512, nb), (frames, nb)
-        assert float(np.abs(magn.cpu().numpy() - m_or).max()) <= 2e-6, (frames, nb)
-        assert float(np.mean(phase.cpu().numpy() == p_or)) >= 0.999, (frames, nb)
-        assert float(np.abs(phase.cpu().numpy() - p_or).max()) <= 1e-4, (frames, nb)
+        assert np.array_equal(magn.cpu().numpy(), m_or), (frames, nb)
+        assert np.array_equal(phase.cpu().numpy(), p_or), (frames, nb)
 
 
 def test_codec_long_track_against_oracle():
     """2 000 frames of a tone + noise: the unwrap must reproduce the oracle's torch.cumsum-style (float64 accumulator) running
-    sum.  Gated like the ragged sizes above: with the device's own |X| and angle(X) handed to the oracle the phase image is
-    bit-identical (the only freedom left is the normalisation's last bit); the magnitude within 2 ulp of 1."""
+    sum.  Gated like the ragged sizes above: bit-identical to the oracle evaluated with torch's CPU abs / angle."""
     from musicgan_amd import audio
     from oracle import audio as OA
     rng = np.random.default_rng(3)
@@ -223,12 +216,10 @@ def test_codec_long_track_against_oracle():
     wav += (0.4 * np.sin(2 * np.pi * 880.0 * t)).astype(np.float32)
     c_ref = OA.stft(wav)
     xd = torch.from_numpy(c_ref).to(DEV)
-    m_ref, p_ref = OA.stft_to_phase_magn(c_ref, lib=(torch.abs(xd).cpu().numpy(), torch.angle(xd).cpu().numpy()))
+    m_ref, p_ref = OA.stft_to_phase_magn(c_ref, lib="torch")
     magn, phase = audio.stft_to_phase_magn(xd)
     assert tuple(magn.shape) == m_ref.shape == (3, 512, 512)
-    assert float(np.abs(magn.cpu().numpy() - m_ref).max()) <= 2e-6
-    assert float(np.mean(phase.cpu().numpy() == p_ref)) >= 0.999
-    assert float(np.abs(phase.cpu().numpy() - p_ref).max()) <= 1e-4
+    assert np.array_equal(magn.cpu().numpy(), m_ref) and np.array_equal(phase.cpu().numpy(), p_ref)
 
 
 def test_drivers_end_to_end_tiny_corpus(tmp_path):

@@ -208,3 +208,59 @@ def test_pt_template_writes_what_torch_save_writes(tmp_path):
             tpl.write(path, x.numpy(), zlib.crc32(x.numpy().tobytes()) & 0xFFFFFFFF)
             assert open(path, "rb").read() == want.getvalue()
             assert torch.equal(torch.load(path), x)
+
+
+def test_sleef_restatement_has_the_bits_of_torch_cpu_abs_and_angle(tmp_path):
+    """csrc/sleef_f32.h (what the codec kernel evaluates th.abs / th.angle with, functions.py:69-70) compiled for the host by g++
+    and compared BITWISE with torch's CPU `abs` / `angle` on complex64 -- the library the reference itself calls -- over 2 M
+    log-uniform random bins plus zeros, signed zeros, denormals, huge values, infinities and NaNs.  (The device build of the same
+    header is pinned by tests/test_audio_gpu.py against the reference's golden codec output.)"""
+    import ctypes
+    import os
+    import subprocess
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "musicgan_amd", "csrc")
+    shim = tmp_path / "shim.cpp"
+    shim.write_text('#include "sleef_f32.h"\n'
+                    'extern "C" void slf_angle_n(const float* re, const float* im, float* o, long n) '
+                    '{ for (long i = 0; i < n; ++i) o[i] = slf::atan2f_u10(im[i], re[i]); }\n'
+                    'extern "C" void slf_abs_n(const float* re, const float* im, float* o, long n) '
+                    '{ for (long i = 0; i < n; ++i) o[i] = slf::hypotf_u05(re[i], im[i]); }\n'
+                    'extern "C" void slf_both_n(const float* re, const float* im, float* m, float* a, long n) '
+                    '{ for (long i = 0; i < n; ++i) slf::abs_angle(re[i], im[i], m[i], a[i]); }\n')
+    so = str(tmp_path / "shim.so")
+    flags = ["-O2", "-ffp-contract=off", "-std=c++17", "-shared", "-fPIC", "-I", csrc]
+    with open("/proc/cpuinfo") as f:
+        if " fma " in f.read():
+            flags.append("-mfma")  # (without it __builtin_fmaf calls libm's correctly rounded fmaf: same bits, slower)
+    subprocess.run(["g++", *flags, str(shim), "-o", so], check=True)
+    lib = ctypes.CDLL(so)
+    rng = np.random.default_rng(2)
+    n = 1 << 21
+    re = (rng.standard_normal(n) * np.exp(rng.uniform(-12, 6, n))).astype(np.float32)
+    im = (rng.standard_normal(n) * np.exp(rng.uniform(-12, 6, n))).astype(np.float32)
+    sp = np.array([0, -0.0, 1, -1, np.inf, -np.inf, 1e-40, -1e-40, 3e38, -3e38, 1e-30, np.nan, 1e30, 1e-31, .5, -.5], np.float32)
+    re[:256], im[:256] = np.repeat(sp, 16), np.tile(sp, 16)
+    re[256:1256] = im[256:1256]                      # |re| == |im|
+    re[1256:9000] *= np.float32(1e-28)               # around the combined routine's range gate and into the denormals
+    im[5000:9000] *= np.float32(1e-28)
+    re[9000:12000] *= np.float32(1e27)
+    c = torch.complex(torch.from_numpy(re), torch.from_numpy(im))
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(1)  # one chunk whose length is a multiple of the vector width: ATen's vector routine on every element
+    try:                      # (the remainder elements of a thread's chunk go through libm instead: oracle/audio.py _abs_angle)
+        wants = (torch.angle(c).numpy(), torch.abs(c).numpy())
+    finally:
+        torch.set_num_threads(nthr)
+    for fn, want in zip((lib.slf_angle_n, lib.slf_abs_n), wants):
+        fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_long]
+        out = np.empty(n, np.float32)
+        fn(re.ctypes.data, im.ctypes.data, out.ctypes.data, n)
+        same = (out.view(np.uint32) == want.view(np.uint32)) | (np.isnan(out) & np.isnan(want))
+        assert bool(same.all()), [(re[i], im[i], out[i], want[i]) for i in np.nonzero(~same)[0][:5]]
+    # the codec kernel's entry: both at once, sharing the quotient (same bits)
+    m, a = np.empty(n, np.float32), np.empty(n, np.float32)
+    lib.slf_both_n.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_long]
+    lib.slf_both_n(re.ctypes.data, im.ctypes.data, m.ctypes.data, a.ctypes.data, n)
+    for out, want in ((a, wants[0]), (m, wants[1])):
+        same = (out.view(np.uint32) == want.view(np.uint32)) | (np.isnan(out) & np.isnan(want))
+        assert bool(same.all()), [(re[i], im[i], out[i], want[i]) for i in np.nonzero(~same)[0][:5]]
