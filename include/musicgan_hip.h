@@ -115,6 +115,22 @@ int mg_wino3x3_wgrad_partial(const float* x, const float* gy, float* gw, float* 
                              int Cout, int H, int W, int flags, int accumulate, int bias_n, mg_wgrad_job_t* job,
                              mg_stream_t stream);
 int mg_wino3x3_wgrad_reduce(const mg_wgrad_job_t* jobs, int n, mg_stream_t stream);
+/* _partial for the n layers of a sweep at once (the weight gradients of one backward pass: convolution_backward of every
+ * nn.Conv2d(3x3) in generator.py:9-40 / discriminator.py:8-34).  Layers of at most group_max_chunks x (number of CUs) units of work
+ * (8-tile chunks x channel blocks) whose channel blocks have the same shape share ONE launch, with their splits sized so that the
+ * group -- not every layer -- fills the chip: fewer launches, fewer and smaller slabs for the reduce.  group_max_chunks <= 0:
+ * one launch per layer, exactly as n calls of _partial.  jobs[i] belongs to d[i]; results are bitwise independent of the grouping
+ * only up to the split count (the slabs are summed in a fixed order either way: deterministic for a given grouping). */
+typedef struct {
+  const float* x;
+  const float* gy;
+  float* gw;
+  float* gb;
+  void* ws;
+  size_t ws_bytes;
+  int32_t N, Cin, Cout, H, W, flags, accumulate, bias_n;
+} mg_wgrad_desc_t;
+int mg_wino3x3_wgrad_partial_multi(const mg_wgrad_desc_t* d, int n, int group_max_chunks, mg_wgrad_job_t* jobs, mg_stream_t stream);
 /* the same split of mg_conv3x3_wgrad (the direct form's jobs carry CoutP = CinP = 0 and go to their own reduce) */
 int mg_conv3x3_wgrad_partial(const float* x, const float* gy, float* gw, float* gb, void* ws, size_t ws_bytes, int N, int Cin,
                              int Cout, int H, int W, int flags, int accumulate, int bias_n, mg_wgrad_job_t* job,

@@ -39,6 +39,12 @@ class WgradJob(Structure):
                 ("Cin", c_int), ("CoutP", c_int), ("CinP", c_int), ("accumulate", c_int)]
 
 
+class WgradDesc(Structure):
+    _fields_ = [("x", c_void_p), ("gy", c_void_p), ("gw", c_void_p), ("gb", c_void_p), ("ws", c_void_p), ("ws_bytes", c_size_t),
+                ("N", c_int), ("Cin", c_int), ("Cout", c_int), ("H", c_int), ("W", c_int), ("flags", c_int),
+                ("accumulate", c_int), ("bias_n", c_int)]
+
+
 class PackDesc(Structure):
     _fields_ = [("w", c_void_p), ("out", c_void_p), ("kind", c_int), ("Co", c_int), ("Ci", c_int), ("dgrad", c_int)]
 
@@ -77,6 +83,7 @@ SIGNATURES = {
     "mg_wino3x3_wgrad_partial": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
                                          _P]),
     "mg_wino3x3_wgrad_reduce": (c_int, [_P, c_int, _P]),
+    "mg_wino3x3_wgrad_partial_multi": (c_int, [_P, c_int, c_int, _P, _P]),
     "mg_conv3x3_wgrad_partial": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
                                          _P]),
     "mg_conv3x3_wgrad_reduce": (c_int, [_P, c_int, _P]),

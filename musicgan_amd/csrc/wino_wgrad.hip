@@ -51,15 +51,16 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // UPS: x is (N, Cin, H/2, W/2) and the convolution input is its nearest x2 up-sampling (generator.py:24-25): the 4x4 patch of tile
 // (TY, TX) is then the 3x3 low-res neighbourhood with the centre row / column doubled -- one dword per row and lane.
+// The body takes its block coordinates as arguments: `split` (slab index, blockIdx.x of a single-layer launch) and `yblk`
+// (channel block pair, blockIdx.y) -- a grouped launch (wino_wgrad_group_mfma below) derives them from a table instead.
 template <int CT, int OT, bool UPS>
-__global__ void __launch_bounds__(512) wino_wgrad_mfma(const WwArgs a) {
+__device__ __forceinline__ void ww_body(const WwArgs& a, const int split, const int yblk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = component pair
   const int col = lane & 15, rq = lane >> 4;
-  const int cb = blockIdx.y / a.nob, ob = blockIdx.y % a.nob;
+  const int cb = yblk / a.nob, ob = yblk % a.nob;
   const int c0 = cb * CT * 16, o0 = ob * OT * 16;
-  const int split = blockIdx.x;
   const int HW = a.H * a.W;
   const int Ht = a.H >> 1, Wt = a.W >> 1;
 
@@ -307,6 +308,34 @@ __global__ void __launch_bounds__(512) wino_wgrad_mfma(const WwArgs a) {
   bsum += __shfl_xor(bsum, 2);
   bsum += __shfl_xor(bsum, 4);
   if (cb == 0 && t == 0 && chs < OT * 16 && o0 + chs < a.CoutP) a.slab_b[(size_t)split * a.CoutP + o0 + chs] = bsum;
+}
+
+template <int CT, int OT, bool UPS>
+__global__ void __launch_bounds__(512) wino_wgrad_mfma(const WwArgs a) {
+  ww_body<CT, OT, UPS>(a, blockIdx.x, blockIdx.y);
+}
+
+// ---- several layers in ONE launch.  At small batch / on small maps a layer's weight gradient is a 10-30 us launch of a few dozen
+// to 256 workgroups, a step has ten of them back to back, and every one is split over ~256 workgroups just to fill the chip, each
+// split writing (and the reduce re-reading) a full 9-tap slab of the filter.  Layers whose blocks have the same shape <CT, OT, UPS>
+// share a launch: workgroup b looks its layer up in a table of at most WW_GROUP entries (first[] = prefix sums of workgroups) and
+// runs that layer's body; the host sizes the splits so that the GROUP fills the chip once (mg_wino3x3_wgrad_partial_multi).
+constexpr int WW_GROUP = 10;
+struct WwGroup {
+  int n;
+  int first[WW_GROUP + 1];
+  int nsplit[WW_GROUP];
+  WwArgs a[WW_GROUP];
+};
+
+template <int CT, int OT, bool UPS>
+__global__ void __launch_bounds__(512) wino_wgrad_group_mfma(const WwGroup g) {
+  int j = 0;
+#pragma unroll 1
+  while (j + 1 < g.n && (int)blockIdx.x >= g.first[j + 1]) ++j;
+  const int local = (int)blockIdx.x - g.first[j];
+  const int ns = g.nsplit[j];
+  ww_body<CT, OT, UPS>(g.a[j], local % ns, local / ns);
 }
 
 // ---- narrow blocks (CT + OT <= 4 channel tiles): same algorithm and LDS layout as wino_wgrad_mfma above, re-balanced for blocks
@@ -746,6 +775,68 @@ int dispatch_ww(int CT, int OT, const WwArgs& a, dim3 grid, hipStream_t s) {
   return MG_EINVAL;
 }
 
+template <int CT, int OT, bool UPS>
+int launch_ww_group(const WwGroup& g, hipStream_t s) {
+  static MgPerDevice once;
+  if (mg_first_use_on_device(once)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_wgrad_group_mfma<CT, OT, UPS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  hipLaunchKernelGGL((wino_wgrad_group_mfma<CT, OT, UPS>), dim3(g.first[g.n]), dim3(512), (size_t)2 * STAGE * sizeof(float), s, g);
+  MG_CHECK_LAUNCH("mg_wino3x3_wgrad_partial_multi");
+  return MG_OK;
+}
+
+// the block shapes of the layers that are ever small (>= 96 channels: blocks of 3 or 4 channel tiles)
+bool ww_groupable(int CT, int OT) { return CT >= 3 && OT >= 3; }
+
+template <bool UPS>
+int dispatch_ww_group(int CT, int OT, const WwGroup& g, hipStream_t s) {
+  switch (CT * 10 + OT) {
+    case 33: return launch_ww_group<3, 3, UPS>(g, s);
+    case 34: return launch_ww_group<3, 4, UPS>(g, s);
+    case 43: return launch_ww_group<4, 3, UPS>(g, s);
+    case 44: return launch_ww_group<4, 4, UPS>(g, s);
+  }
+  mg_set_error("mg_wino3x3_wgrad_partial_multi: internal tile error (CT=%d, OT=%d)", CT, OT);
+  return MG_EINVAL;
+}
+
+// arguments of one layer -> plan + kernel arguments (pointers, byte limits); shared by the single and the grouped entry point
+int prepare_ww(const float* x, const float* gy, const float* gw, const void* ws, size_t ws_bytes, int N, int Cin, int Cout, int H,
+               int W, int flags, int bias_n, WwPlan& pl) {
+  MG_CHECK_ARG(x && gy && gw && ws && N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "mg_wino3x3_wgrad: bad arguments");
+  MG_CHECK_ARG((H % 2 == 0) && (W % 2 == 0), "mg_wino3x3_wgrad: H=%d W=%d must be even", H, W);
+  MG_CHECK_ARG(!(flags & ~MG_CONV_UPS_IN), "mg_wino3x3_wgrad: unknown flag");
+  const bool ups = (flags & MG_CONV_UPS_IN) != 0;
+  MG_CHECK_ARG((long long)N * Cin * H * W < (1ll << 29) && (long long)N * Cout * H * W < (1ll << 29),
+               "mg_wino3x3_wgrad: tensor too large for 32-bit byte offsets");
+  plan_ww(N, Cin, Cout, H, W, pl);
+  if (ws_bytes < pl.ws_floats * sizeof(float)) {
+    mg_set_error("mg_wino3x3_wgrad: workspace %zu < %zu bytes", ws_bytes, pl.ws_floats * sizeof(float));
+    return MG_EWORKSPACE;
+  }
+  WwArgs& a = pl.a;
+  a.x = x; a.gy = gy;
+  a.slab = reinterpret_cast<float*>(const_cast<void*>(ws));
+  a.slab_b = a.slab + (size_t)pl.nsplit * 9 * a.CinP * a.CoutP;
+  a.bias_n = (bias_n <= 0 || bias_n > N) ? N : bias_n;
+  a.x_bytes = (unsigned)((size_t)N * Cin * (ups ? (H / 2) * (W / 2) : H * W) * 4);
+  a.gy_bytes = (unsigned)((size_t)N * Cout * H * W * 4);
+  return MG_OK;
+}
+
+void fill_job(const WwPlan& pl, float* gw, float* gb, int accumulate, mg_wgrad_job_t* job) {
+  const WwArgs& a = pl.a;
+  job->slab = a.slab; job->slab_b = a.slab_b; job->gw = gw; job->gb = gb;
+  job->nsplit = pl.nsplit; job->Cout = a.Cout; job->Cin = a.Cin; job->CoutP = a.CoutP; job->CinP = a.CinP; job->accumulate = accumulate;
+}
+
+int launch_single_ww(const WwPlan& pl, bool ups, hipStream_t s) {
+  dim3 grid(pl.nsplit, pl.ncb * pl.a.nob);
+  return ups ? dispatch_ww<true>(pl.CT, pl.OT, pl.a, grid, s) : dispatch_ww<false>(pl.CT, pl.OT, pl.a, grid, s);
+}
+
 }  // namespace
 
 extern "C" size_t mg_wino3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W) {
@@ -757,31 +848,71 @@ extern "C" size_t mg_wino3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int
 extern "C" int mg_wino3x3_wgrad_partial(const float* x, const float* gy, float* gw, float* gb, void* ws, size_t ws_bytes, int N,
                                         int Cin, int Cout, int H, int W, int flags, int accumulate, int bias_n,
                                         mg_wgrad_job_t* job, mg_stream_t stream) {
-  MG_CHECK_ARG(x && gy && gw && ws && job && N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "mg_wino3x3_wgrad: bad arguments");
-  MG_CHECK_ARG((H % 2 == 0) && (W % 2 == 0), "mg_wino3x3_wgrad: H=%d W=%d must be even", H, W);
-  MG_CHECK_ARG(!(flags & ~MG_CONV_UPS_IN), "mg_wino3x3_wgrad: unknown flag");
-  const bool ups = (flags & MG_CONV_UPS_IN) != 0;
-  MG_CHECK_ARG((long long)N * Cin * H * W < (1ll << 29) && (long long)N * Cout * H * W < (1ll << 29),
-               "mg_wino3x3_wgrad: tensor too large for 32-bit byte offsets");
+  MG_CHECK_ARG(job, "mg_wino3x3_wgrad: bad arguments");
   WwPlan pl;
-  plan_ww(N, Cin, Cout, H, W, pl);
-  if (ws_bytes < pl.ws_floats * sizeof(float)) {
-    mg_set_error("mg_wino3x3_wgrad: workspace %zu < %zu bytes", ws_bytes, pl.ws_floats * sizeof(float));
-    return MG_EWORKSPACE;
-  }
-  WwArgs& a = pl.a;
-  a.x = x; a.gy = gy;
-  a.slab = reinterpret_cast<float*>(ws);
-  a.slab_b = a.slab + (size_t)pl.nsplit * 9 * a.CinP * a.CoutP;
-  a.bias_n = (bias_n <= 0 || bias_n > N) ? N : bias_n;
-  a.x_bytes = (unsigned)((size_t)N * Cin * (ups ? (H / 2) * (W / 2) : H * W) * 4);
-  a.gy_bytes = (unsigned)((size_t)N * Cout * H * W * 4);
-  hipStream_t s = (hipStream_t)stream;
-  dim3 grid(pl.nsplit, pl.ncb * a.nob);
-  const int rc = ups ? dispatch_ww<true>(pl.CT, pl.OT, a, grid, s) : dispatch_ww<false>(pl.CT, pl.OT, a, grid, s);
+  int rc = prepare_ww(x, gy, gw, ws, ws_bytes, N, Cin, Cout, H, W, flags, bias_n, pl);
   if (rc != MG_OK) return rc;
-  job->slab = a.slab; job->slab_b = a.slab_b; job->gw = gw; job->gb = gb;
-  job->nsplit = pl.nsplit; job->Cout = Cout; job->Cin = Cin; job->CoutP = a.CoutP; job->CinP = a.CinP; job->accumulate = accumulate;
+  rc = launch_single_ww(pl, (flags & MG_CONV_UPS_IN) != 0, (hipStream_t)stream);
+  if (rc != MG_OK) return rc;
+  fill_job(pl, gw, gb, accumulate, job);
+  return MG_OK;
+}
+
+extern "C" int mg_wino3x3_wgrad_partial_multi(const mg_wgrad_desc_t* d, int n, int group_max_chunks, mg_wgrad_job_t* jobs,
+                                              mg_stream_t stream) {
+  MG_CHECK_ARG(d && jobs && n > 0 && n <= 64, "mg_wino3x3_wgrad_partial_multi: bad arguments (n = %d, at most 64 layers)", n);
+  hipStream_t s = (hipStream_t)stream;
+  WwPlan pl[64];
+  int key[64];  // > 0: candidate for a grouped launch, layers with equal keys share one
+  const int n_cu = mg_cu_count();
+  for (int i = 0; i < n; ++i) {
+    const int rc = prepare_ww(d[i].x, d[i].gy, d[i].gw, d[i].ws, d[i].ws_bytes, d[i].N, d[i].Cin, d[i].Cout, d[i].H, d[i].W, d[i].flags,
+                              d[i].bias_n, pl[i]);
+    if (rc != MG_OK) return rc;
+    const long long work = (long long)pl[i].a.nblk * pl[i].ncb * pl[i].a.nob;  // chunks x channel blocks
+    const bool small = group_max_chunks > 0 && ww_groupable(pl[i].CT, pl[i].OT) && work <= (long long)group_max_chunks * n_cu;
+    key[i] = small ? (pl[i].CT * 10 + pl[i].OT) * 2 + ((d[i].flags & MG_CONV_UPS_IN) ? 1 : 0) : 0;
+  }
+  for (int i = 0; i < n; ++i) {
+    if (key[i] <= 0) {
+      if (key[i] == 0) {  // (< 0: already launched as part of a group)
+        const int rc = launch_single_ww(pl[i], (d[i].flags & MG_CONV_UPS_IN) != 0, s);
+        if (rc != MG_OK) return rc;
+      }
+      continue;
+    }
+    int idx[WW_GROUP], m = 0;
+    for (int j = i; j < n && m < WW_GROUP; ++j)
+      if (key[j] == key[i]) idx[m++] = j;
+    if (m == 1) {
+      const int rc = launch_single_ww(pl[i], (d[i].flags & MG_CONV_UPS_IN) != 0, s);
+      if (rc != MG_OK) return rc;
+      continue;
+    }
+    // the splits of the group: equal chunks per workgroup P, about one workgroup per CU over the whole group
+    long long work = 0;
+    for (int k = 0; k < m; ++k) work += (long long)pl[idx[k]].a.nblk * pl[idx[k]].ncb * pl[idx[k]].a.nob;
+    const int P = (int)((work + n_cu - 1) / n_cu);
+    WwGroup g;
+    g.n = m;
+    g.first[0] = 0;
+    for (int k = 0; k < m; ++k) {
+      WwPlan& q = pl[idx[k]];
+      int ns = mg_cdiv(q.a.nblk, P);
+      if (ns > q.nsplit) ns = q.nsplit;  // (the workspace was sized for the single-layer plan)
+      q.a.per = mg_cdiv(q.a.nblk, ns);
+      q.nsplit = mg_cdiv(q.a.nblk, q.a.per);
+      q.a.slab_b = q.a.slab + (size_t)q.nsplit * 9 * q.a.CinP * q.a.CoutP;
+      g.a[k] = q.a;
+      g.nsplit[k] = q.nsplit;
+      g.first[k + 1] = g.first[k] + q.nsplit * q.ncb * q.a.nob;
+    }
+    const int CT = pl[i].CT, OT = pl[i].OT;
+    const int rc = (key[i] & 1) ? dispatch_ww_group<true>(CT, OT, g, s) : dispatch_ww_group<false>(CT, OT, g, s);
+    if (rc != MG_OK) return rc;
+    for (int k = 0; k < m; ++k) key[idx[k]] = -1;
+  }
+  for (int i = 0; i < n; ++i) fill_job(pl[i], d[i].gw, d[i].gb, d[i].accumulate, &jobs[i]);
   return MG_OK;
 }
 

@@ -296,6 +296,12 @@ def wino_wgrad_supported(n: int, cin: int, cout: int, h: int, w: int, *, ups=Fal
     return n * h * w >= int(os.environ.get("MG_WINO_WGRAD_MIN_PIXELS", "64"))
 
 
+def wgrad_group_chunks() -> int:
+    """MG_WGRAD_GROUP: layers of at most this many 8-tile chunks per workgroup (at one workgroup per CU) share a launch with the
+    other small layers of their block shape; 0 = one launch per layer."""
+    return int(os.environ.get("MG_WGRAD_GROUP", "32"))
+
+
 class WgradDefer:
     """Collects the slab reductions of the Winograd weight gradients of one sweep (conv3x3_wgrad(..., defer=this)) and runs them
     in ONE launch (`flush`).  Each deferred layer keeps its own workspace alive until then; the i-th layer of a sweep reuses the
@@ -305,9 +311,10 @@ class WgradDefer:
         self._bufs = []
         self._jobs = []      # Winograd form
         self._jobs_d = []    # direct form
+        self._lazy = []      # Winograd form, matrix kernel not launched yet: (descriptor, tensors it points into)
 
     def workspace(self, nbytes: int, device) -> torch.Tensor:
-        i = len(self._jobs) + len(self._jobs_d)
+        i = len(self._jobs) + len(self._jobs_d) + len(self._lazy)
         if i == len(self._bufs):
             self._bufs.append(torch.empty(nbytes, dtype=torch.uint8, device=device))
         elif self._bufs[i].numel() < nbytes or self._bufs[i].device != device:
@@ -317,12 +324,23 @@ class WgradDefer:
     def add(self, job, direct: bool = False) -> None:
         (self._jobs_d if direct else self._jobs).append(job)
 
+    def add_lazy(self, desc, keep) -> None:
+        self._lazy.append((desc, keep))
+
     def reset(self) -> None:
         """Drop collected jobs without running them (an aborted graph capture: their pointers died with the capture's pool)."""
-        self._jobs, self._jobs_d = [], []
+        self._jobs, self._jobs_d, self._lazy = [], [], []
 
     def flush(self) -> None:
         lib = _lib.load()
+        if self._lazy:
+            # the matrix kernels of the whole sweep: small layers with equal block shapes share a launch (include/musicgan_hip.h)
+            descs = (_lib.WgradDesc * len(self._lazy))(*[d for d, _ in self._lazy])
+            jobs = (_lib.WgradJob * len(self._lazy))()
+            check(lib.mg_wino3x3_wgrad_partial_multi(ctypes.cast(descs, ctypes.c_void_p), len(self._lazy), wgrad_group_chunks(),
+                                                     ctypes.cast(jobs, ctypes.c_void_p), _s()), "mg_wino3x3_wgrad_partial_multi")
+            self._jobs += list(jobs)
+            self._lazy = []
         for jobs, fn, what in ((self._jobs, lib.mg_wino3x3_wgrad_reduce, "mg_wino3x3_wgrad_reduce"),
                                (self._jobs_d, lib.mg_conv3x3_wgrad_reduce, "mg_conv3x3_wgrad_reduce")):
             if jobs:
@@ -340,6 +358,10 @@ def conv3x3_wgrad(x, gy, gw, gb, *, ups=False, accumulate=False, bias_n: int = 0
     lib = _lib.load()
     if defer is not None and not accumulate and wino_wgrad_supported(n, cin, cout, h, w, ups=ups):
         ws = defer.workspace(lib.mg_wino3x3_wgrad_ws_bytes(n, cin, cout, h, w), x.device)
+        if wgrad_group_chunks() > 0:
+            defer.add_lazy(_lib.WgradDesc(_p(x), _p(gy), _p(gw), _p(gb), _p(ws), ws.numel(), n, cin, cout, h, w,
+                                          MG_CONV_UPS_IN if ups else 0, 0, int(bias_n)), (x, gy, gw, gb, ws))
+            return
         job = _lib.WgradJob()
         check(lib.mg_wino3x3_wgrad_partial(_p(x), _p(gy), _p(gw), _p(gb), _p(ws), ws.numel(), n, cin, cout, h, w,
                                            MG_CONV_UPS_IN if ups else 0, 0, int(bias_n), ctypes.byref(job), _s()),

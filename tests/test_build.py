@@ -15,6 +15,7 @@ HOT = [
     (r"wino3x3_mfmaILi1ELi[23]ELi2E", 0),
     (r"wino3x3_mfmaILi1ELi2ELi4E", 0),
     (r"wino_wgrad_mfma", 0),
+    (r"wino_wgrad_group_mfma", 0),
     (r"conv3x3_mfma", 0),
     (r"wgrad3x3_mfma", 0),
     (r"upconv3x3_mfma", 0),

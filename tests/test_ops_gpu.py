@@ -718,10 +718,12 @@ def test_conv1x1_few_out_split_channels(case):
            ref, 2e-6)
 
 
-def test_group_means_and_deferred_wgrad_reduce():
+def test_group_means_and_deferred_wgrad_reduce(monkeypatch):
     """mg_group_means (score means + Wasserstein losses, one launch) against torch, and the deferred one-launch weight-gradient
-    reduction (Winograd and direct jobs mixed in one sweep) bit-identical to the immediate form."""
+    reduction (Winograd and direct jobs mixed in one sweep) bit-identical to the immediate form (layers launched one by one:
+    a grouped launch chooses other split counts, test_grouped_wgrad_launch)."""
     ops = _ops()
+    monkeypatch.setenv("MG_WGRAD_GROUP", "0")
     g = torch.Generator().manual_seed(84)
     for groups, n in ((3, 5), (3, 64), (1, 300), (2, 1000)):
         s = torch.randn(groups * n, 1, generator=g) * 7
@@ -747,3 +749,51 @@ def test_group_means_and_deferred_wgrad_reduce():
     defer.flush()
     for (a, b), (c, d) in zip(want, got):
         assert torch.equal(a, c) and torch.equal(b, d)
+
+
+@pytest.mark.parametrize("n", [24, 5])
+def test_grouped_wgrad_launch(n, monkeypatch):
+    """mg_wino3x3_wgrad_partial_multi: the weight gradients of a whole sweep, small layers with equal block shapes sharing one
+    launch (splits sized for the group), large ones launched alone -- every layer against fp64 autograd (weight, bias of the first
+    samples), against the one-launch-per-layer form, and twice for determinism.  Shapes: the <= 16x16 end of both networks
+    (generator.py:15-40 incl. up-sampled inputs, discriminator.py:14-34), a 128x128 layer that must stay alone, a ragged one."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(91)
+    layers = [(144, 160, 2, 2, False), (144, 144, 4, 4, False), (128, 144, 4, 4, False), (128, 128, 8, 8, False),
+              (112, 128, 8, 8, False), (128, 112, 8, 8, True), (112, 112, 8, 8, False), (96, 112, 16, 16, False),
+              (112, 96, 16, 16, True), (96, 96, 16, 16, False), (48, 64, 128, 128, False), (100, 120, 6, 10, False),
+              (160, 144, 4, 4, True), (144, 160, 2, 2, False)]
+    data = []
+    for ci, co, h, w, ups in layers:
+        nn = 2 if h >= 128 else n
+        x = torch.randn(nn, ci, h // 2 if ups else h, w // 2 if ups else w, generator=g)
+        gy = torch.randn(nn, co, h, w, generator=g)
+        xin = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
+        wt = torch.zeros(co, ci, 3, 3, dtype=torch.float64, requires_grad=True)
+        (F.conv2d(xin.double(), wt, None, padding=1) * gy.double()).sum().backward()
+        nb = max(1, nn // 3)
+        data.append((x.to(DEV), gy.to(DEV), ups, nb, wt.grad, gy[:nb].double().sum(dim=(0, 2, 3))))
+
+    def sweep(group):
+        monkeypatch.setenv("MG_WGRAD_GROUP", str(group))
+        defer = ops.WgradDefer()
+        outs = []
+        for x, gy, ups, nb, _, _ in data:
+            gw = torch.full((gy.shape[1], x.shape[1], 3, 3), float("nan"), device=DEV)
+            gb = torch.full((gy.shape[1],), float("nan"), device=DEV)
+            ops.conv3x3_wgrad(x, gy, gw, gb, ups=ups, bias_n=nb, defer=defer)
+            outs.append((gw, gb))
+        if group > 0:  # (layers of fewer than 64 pixels take the direct form at once)
+            n_wino = sum(ops.wino_wgrad_supported(gy.shape[0], x.shape[1], gy.shape[1], gy.shape[2], gy.shape[3], ups=u)
+                         for x, gy, u, _, _, _ in data)
+            assert len(defer._lazy) == n_wino >= 10 and not defer._jobs
+        defer.flush()
+        return outs
+
+    grouped, again, single = sweep(32), sweep(32), sweep(0)
+    for (gw, gb), (gw2, gb2), (gw1, gb1), (_, _, _, _, want_w, want_b) in zip(grouped, again, single, data):
+        assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+        report("grouped wgrad gw", gw, want_w, 3e-6)
+        report("grouped wgrad gb", gb, want_b, 3e-6)
+        report("grouped vs single gw", gw, gw1.double(), 2e-6)
+        assert torch.equal(gb.cpu(), gb1.cpu()) or float((gb - gb1).abs().max()) <= 2e-6 * float(gb1.abs().max())
