@@ -317,25 +317,37 @@ __global__ void __launch_bounds__(512) wino_wgrad_mfma(const WwArgs a) {
 
 // ---- several layers in ONE launch.  At small batch / on small maps a layer's weight gradient is a 10-30 us launch of a few dozen
 // to 256 workgroups, a step has ten of them back to back, and every one is split over ~256 workgroups just to fill the chip, each
-// split writing (and the reduce re-reading) a full 9-tap slab of the filter.  Layers whose blocks have the same shape <CT, OT, UPS>
-// share a launch: workgroup b looks its layer up in a table of at most WW_GROUP entries (first[] = prefix sums of workgroups) and
-// runs that layer's body; the host sizes the splits so that the GROUP fills the chip once (mg_wino3x3_wgrad_partial_multi).
-constexpr int WW_GROUP = 10;
+// split writing (and the reduce re-reading) a full 9-tap slab of the filter.  The small layers of a sweep share a launch: workgroup
+// b looks its layer up in a table of at most WW_GROUP entries (first[] = prefix sums of workgroups) and runs that layer's body --
+// the block shapes <CT, OT, UPS> of layers that are ever small (>= 96 channels: 3 or 4 channel tiles per block) are all inlined
+// here; the host sizes the splits so that the GROUP fills the chip once (mg_wino3x3_wgrad_partial_multi).
+constexpr int WW_GROUP = 16;
 struct WwGroup {
   int n;
   int first[WW_GROUP + 1];
   int nsplit[WW_GROUP];
+  int var[WW_GROUP];  // (CT * 10 + OT) * 2 + UPS
   WwArgs a[WW_GROUP];
 };
 
-template <int CT, int OT, bool UPS>
 __global__ void __launch_bounds__(512) wino_wgrad_group_mfma(const WwGroup g) {
   int j = 0;
 #pragma unroll 1
   while (j + 1 < g.n && (int)blockIdx.x >= g.first[j + 1]) ++j;
   const int local = (int)blockIdx.x - g.first[j];
   const int ns = g.nsplit[j];
-  ww_body<CT, OT, UPS>(g.a[j], local % ns, local / ns);
+  const int split = local % ns, yblk = local / ns;
+  switch (g.var[j]) {
+    case 66: ww_body<3, 3, false>(g.a[j], split, yblk); break;
+    case 67: ww_body<3, 3, true>(g.a[j], split, yblk); break;
+    case 68: ww_body<3, 4, false>(g.a[j], split, yblk); break;
+    case 69: ww_body<3, 4, true>(g.a[j], split, yblk); break;
+    case 86: ww_body<4, 3, false>(g.a[j], split, yblk); break;
+    case 87: ww_body<4, 3, true>(g.a[j], split, yblk); break;
+    case 88: ww_body<4, 4, false>(g.a[j], split, yblk); break;
+    case 89: ww_body<4, 4, true>(g.a[j], split, yblk); break;
+    default: break;
+  }
 }
 
 // ---- narrow blocks (CT + OT <= 4 channel tiles): same algorithm and LDS layout as wino_wgrad_mfma above, re-balanced for blocks
@@ -775,32 +787,19 @@ int dispatch_ww(int CT, int OT, const WwArgs& a, dim3 grid, hipStream_t s) {
   return MG_EINVAL;
 }
 
-template <int CT, int OT, bool UPS>
 int launch_ww_group(const WwGroup& g, hipStream_t s) {
   static MgPerDevice once;
   if (mg_first_use_on_device(once)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_wgrad_group_mfma<CT, OT, UPS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_wgrad_group_mfma), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
   }
-  hipLaunchKernelGGL((wino_wgrad_group_mfma<CT, OT, UPS>), dim3(g.first[g.n]), dim3(512), (size_t)2 * STAGE * sizeof(float), s, g);
+  hipLaunchKernelGGL(wino_wgrad_group_mfma, dim3(g.first[g.n]), dim3(512), (size_t)2 * STAGE * sizeof(float), s, g);
   MG_CHECK_LAUNCH("mg_wino3x3_wgrad_partial_multi");
   return MG_OK;
 }
 
-// the block shapes of the layers that are ever small (>= 96 channels: blocks of 3 or 4 channel tiles)
+// the block shapes inlined in wino_wgrad_group_mfma
 bool ww_groupable(int CT, int OT) { return CT >= 3 && OT >= 3; }
-
-template <bool UPS>
-int dispatch_ww_group(int CT, int OT, const WwGroup& g, hipStream_t s) {
-  switch (CT * 10 + OT) {
-    case 33: return launch_ww_group<3, 3, UPS>(g, s);
-    case 34: return launch_ww_group<3, 4, UPS>(g, s);
-    case 43: return launch_ww_group<4, 3, UPS>(g, s);
-    case 44: return launch_ww_group<4, 4, UPS>(g, s);
-  }
-  mg_set_error("mg_wino3x3_wgrad_partial_multi: internal tile error (CT=%d, OT=%d)", CT, OT);
-  return MG_EINVAL;
-}
 
 // arguments of one layer -> plan + kernel arguments (pointers, byte limits); shared by the single and the grouped entry point
 int prepare_ww(const float* x, const float* gy, const float* gw, const void* ws, size_t ws_bytes, int N, int Cin, int Cout, int H,
@@ -873,44 +872,56 @@ extern "C" int mg_wino3x3_wgrad_partial_multi(const mg_wgrad_desc_t* d, int n, i
     const bool small = group_max_chunks > 0 && ww_groupable(pl[i].CT, pl[i].OT) && work <= (long long)group_max_chunks * n_cu;
     key[i] = small ? (pl[i].CT * 10 + pl[i].OT) * 2 + ((d[i].flags & MG_CONV_UPS_IN) ? 1 : 0) : 0;
   }
-  for (int i = 0; i < n; ++i) {
-    if (key[i] <= 0) {
-      if (key[i] == 0) {  // (< 0: already launched as part of a group)
-        const int rc = launch_single_ww(pl[i], (d[i].flags & MG_CONV_UPS_IN) != 0, s);
-        if (rc != MG_OK) return rc;
-      }
-      continue;
-    }
+  for (;;) {
     int idx[WW_GROUP], m = 0;
-    for (int j = i; j < n && m < WW_GROUP; ++j)
-      if (key[j] == key[i]) idx[m++] = j;
-    if (m == 1) {
-      const int rc = launch_single_ww(pl[i], (d[i].flags & MG_CONV_UPS_IN) != 0, s);
-      if (rc != MG_OK) return rc;
-      continue;
-    }
-    // the splits of the group: equal chunks per workgroup P, about one workgroup per CU over the whole group
+    for (int j = 0; j < n && m < WW_GROUP; ++j)
+      if (key[j] > 0) idx[m++] = j;
+    if (m < 2) break;
+    // The splits of the group: about the same TIME per workgroup (a chunk of a <CT, OT> block costs ~ CT * OT MFMA groups + its
+    // staging), at most one workgroup per CU over the whole group -- a 257th workgroup would run alone after the others.
+    auto cost = [&](int i) { return pl[i].CT * pl[i].OT + 6; };
     long long work = 0;
-    for (int k = 0; k < m; ++k) work += (long long)pl[idx[k]].a.nblk * pl[idx[k]].ncb * pl[idx[k]].a.nob;
-    const int P = (int)((work + n_cu - 1) / n_cu);
+    for (int k = 0; k < m; ++k) work += (long long)pl[idx[k]].a.nblk * pl[idx[k]].ncb * pl[idx[k]].a.nob * cost(idx[k]);
+    long long budget = (work + n_cu - 1) / n_cu;  // cost units per workgroup
+    int ns[WW_GROUP], total;
+    for (;;) {
+      total = 0;
+      bool floor_reached = true;  // every layer at one split: nothing left to shrink
+      for (int k = 0; k < m; ++k) {
+        const WwPlan& q = pl[idx[k]];
+        long long per = budget / cost(idx[k]);
+        if (per < 1) per = 1;
+        int v = (int)((q.a.nblk + per - 1) / per);
+        if (v > q.nsplit) v = q.nsplit;  // (the workspace was sized for the single-layer plan)
+        ns[k] = v;
+        floor_reached = floor_reached && v == 1;
+        total += v * q.ncb * q.a.nob;
+      }
+      if (total <= n_cu || floor_reached) break;
+      budget += (budget + 15) / 16;
+    }
     WwGroup g;
     g.n = m;
     g.first[0] = 0;
     for (int k = 0; k < m; ++k) {
       WwPlan& q = pl[idx[k]];
-      int ns = mg_cdiv(q.a.nblk, P);
-      if (ns > q.nsplit) ns = q.nsplit;  // (the workspace was sized for the single-layer plan)
-      q.a.per = mg_cdiv(q.a.nblk, ns);
+      q.a.per = mg_cdiv(q.a.nblk, ns[k]);
       q.nsplit = mg_cdiv(q.a.nblk, q.a.per);
       q.a.slab_b = q.a.slab + (size_t)q.nsplit * 9 * q.a.CinP * q.a.CoutP;
       g.a[k] = q.a;
       g.nsplit[k] = q.nsplit;
+      g.var[k] = key[idx[k]];
       g.first[k + 1] = g.first[k] + q.nsplit * q.ncb * q.a.nob;
     }
-    const int CT = pl[i].CT, OT = pl[i].OT;
-    const int rc = (key[i] & 1) ? dispatch_ww_group<true>(CT, OT, g, s) : dispatch_ww_group<false>(CT, OT, g, s);
+    const int rc = launch_ww_group(g, s);
     if (rc != MG_OK) return rc;
     for (int k = 0; k < m; ++k) key[idx[k]] = -1;
+  }
+  for (int i = 0; i < n; ++i) {
+    if (key[i] >= 0) {  // large, of a block shape that is not inlined in the group kernel, or alone
+      const int rc = launch_single_ww(pl[i], (d[i].flags & MG_CONV_UPS_IN) != 0, s);
+      if (rc != MG_OK) return rc;
+    }
   }
   for (int i = 0; i < n; ++i) fill_job(pl[i], d[i].gw, d[i].gb, d[i].accumulate, &jobs[i]);
   return MG_OK;
