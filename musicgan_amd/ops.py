@@ -299,7 +299,7 @@ def wino_wgrad_supported(n: int, cin: int, cout: int, h: int, w: int, *, ups=Fal
 def wgrad_group_chunks() -> int:
     """MG_WGRAD_GROUP: layers of at most this many 8-tile chunks per workgroup (at one workgroup per CU) share a launch with the
     other small layers of their block shape; 0 = one launch per layer."""
-    return int(os.environ.get("MG_WGRAD_GROUP", "16"))
+    return int(os.environ.get("MG_WGRAD_GROUP", "32"))
 
 
 class WgradDefer:
