@@ -155,6 +155,11 @@ size_t mg_conv3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W);
 int mg_conv3x3_wgrad(const float* x, const float* gy, float* gw, float* gb, void* ws, size_t ws_bytes, int N, int Cin,
                      int Cout, int H, int W, int flags, int accumulate, int bias_n, mg_stream_t stream);
 
+/* the same on 1x1 maps (the last critic conv after the final AvgPool2d, discriminator.py:14-34): x (N,Cin,1,1), gy (N,Cout,1,1);
+ * only the centre tap is non-zero.  No workspace, no reduce; float64 accumulation in sample order (deterministic). */
+int mg_conv3x3_wgrad_1x1map(const float* x, const float* gy, float* gw, float* gb, int N, int Cin, int Cout, int accumulate,
+                            int bias_n, mg_stream_t stream);
+
 /* ------------------------------------------------------------------ 1x1 convolutions (stem 2->C, head C->2)
  * Replaces MagPhaseLayer [discriminator.py:37-50] and ToMagnPhaseLayer [generator.py:43-52].  One of Cin/Cout must be <= 4.
  */

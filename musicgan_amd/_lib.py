@@ -84,6 +84,7 @@ SIGNATURES = {
                                          _P]),
     "mg_wino3x3_wgrad_reduce": (c_int, [_P, c_int, _P]),
     "mg_wino3x3_wgrad_partial_multi": (c_int, [_P, c_int, c_int, _P, _P]),
+    "mg_conv3x3_wgrad_1x1map": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "mg_conv3x3_wgrad_partial": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
                                          _P]),
     "mg_conv3x3_wgrad_reduce": (c_int, [_P, c_int, _P]),

@@ -356,6 +356,11 @@ def conv3x3_wgrad(x, gy, gw, gb, *, ups=False, accumulate=False, bias_n: int = 0
     n, cout, h, w = gy.shape
     cin = x.shape[1]
     lib = _lib.load()
+    if h == 1 and w == 1 and not ups and os.environ.get("MG_WGRAD_1X1MAP", "1") != "0":
+        # (complete at once: nothing is left for defer.flush())
+        check(lib.mg_conv3x3_wgrad_1x1map(_p(x), _p(gy), _p(gw), _p(gb), n, cin, cout, int(accumulate), int(bias_n), _s()),
+              "mg_conv3x3_wgrad_1x1map")
+        return
     if defer is not None and not accumulate and wino_wgrad_supported(n, cin, cout, h, w, ups=ups):
         ws = defer.workspace(lib.mg_wino3x3_wgrad_ws_bytes(n, cin, cout, h, w), x.device)
         if wgrad_group_chunks() > 0:

@@ -797,3 +797,30 @@ def test_grouped_wgrad_launch(n, monkeypatch):
         report("grouped wgrad gb", gb, want_b, 3e-6)
         report("grouped vs single gw", gw, gw1.double(), 2e-6)
         assert torch.equal(gb.cpu(), gb1.cpu()) or float((gb - gb1).abs().max()) <= 2e-6 * float(gb1.abs().max())
+
+
+@pytest.mark.parametrize("n,ci,co", [(24, 160, 160), (192, 160, 144), (5, 17, 33), (1, 8, 8)])
+def test_conv3x3_wgrad_on_1x1_maps(n, ci, co, monkeypatch):
+    """mg_conv3x3_wgrad_1x1map (the last critic conv's weight gradient, discriminator.py:14-34): centre tap = gy^T x, the other eight
+    taps exactly zero, bias gradient over the first samples only, accumulate mode, inside a deferred sweep (complete before the
+    flush), and against the MFMA kernel it replaces."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(12)
+    x, gy = torch.randn(n, ci, 1, 1, generator=g), torch.randn(n, co, 1, 1, generator=g)
+    want = gy.double().reshape(n, co).t() @ x.double().reshape(n, ci)
+    nb = max(1, n // 3)
+    gw, gb = torch.full((co, ci, 3, 3), float("nan"), device=DEV), torch.full((co,), float("nan"), device=DEV)
+    defer = ops.WgradDefer()
+    ops.conv3x3_wgrad(x.to(DEV), gy.to(DEV), gw, gb, bias_n=nb, defer=defer)
+    assert not defer._lazy and not defer._jobs and not defer._jobs_d
+    report("1x1-map wgrad centre tap", gw[:, :, 1, 1], want, 1e-6)
+    rest = gw.clone()
+    rest[:, :, 1, 1] = 0
+    assert float(rest.abs().max()) == 0.0
+    report("1x1-map wgrad bias", gb, gy[:nb].double().sum(dim=(0, 2, 3)), 1e-6)
+    ops.conv3x3_wgrad(x.to(DEV), gy.to(DEV), gw, None, accumulate=True)
+    report("1x1-map wgrad accumulate", gw[:, :, 1, 1], 2 * want, 1e-6)
+    monkeypatch.setenv("MG_WGRAD_1X1MAP", "0")
+    gw0 = torch.empty_like(gw)
+    ops.conv3x3_wgrad(x.to(DEV), gy.to(DEV), gw0, None)
+    report("1x1-map wgrad vs the MFMA kernel", gw0, gw.double() / 2, 3e-6)
