@@ -269,9 +269,13 @@ class ProGANStepper:
                 return run(alpha, *inputs)
             opt = self.optim_disc if kind == "D" else self.optim_gen
             mirrors = [(st, st["step"].clone()) for st in opt.state.values() if "step" in st]
+            caller_stream = torch.cuda.current_stream()
             try:
                 self._capture(ent, kind, net, other, inputs, alpha, in_line, run)
             except (RuntimeError, torch.cuda.OutOfMemoryError) as e:
+                # A capture that HIP itself invalidated (an illegal call while capturing) leaves torch.cuda.graph's exit half done:
+                # the current stream is still the capture stream, which stays unusable.  Back to the caller's stream first.
+                torch.cuda.set_stream(caller_stream)
                 # e.g. the graph's private activation pool does not fit next to the other update's: run this update eagerly
                 # from now on rather than fail the training run (the eager path is the same kernels, launched one by one)
                 import warnings
@@ -338,7 +342,8 @@ class ProGANStepper:
         graph = torch.cuda.CUDAGraph()
         if in_line:
             # thread_local: loader threads (pinned-memory staging, uploads on their own stream) keep working during the capture
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            # (a capture stream of its own: torch's shared default one would stay broken after an invalidated capture)
+            with torch.cuda.graph(graph, stream=torch.cuda.Stream(device=inputs[0].device), capture_error_mode="thread_local"):
                 m = run(FadeIn(alpha, dev=self._fade), *ent["inputs"], captured=True)
                 ent["names"] = list(m.keys())
                 ent["out"] = torch.stack([m[k].reshape(()) for k in ent["names"]])

@@ -283,11 +283,14 @@ def test_graph_replay_is_bit_identical_to_eager_updates(monkeypatch):
         assert torch.equal(s_graph[k], s_eager[k]), k
 
 
-def test_failed_graph_capture_falls_back_to_bit_identical_eager_updates(monkeypatch):
+@pytest.mark.parametrize("how", ["raise", "invalidate"])
+def test_failed_graph_capture_falls_back_to_bit_identical_eager_updates(how, monkeypatch):
     """a capture that fails half way -- here: the one-launch weight-gradient reduction raises while the stream
-    is capturing -- has already marked every packed weight layout as fresh (the pack kernels were captured, never run) and left
-    deferred reduction jobs that point into the discarded graph pool.  The eager fallback must not inherit either: the whole
-    trajectory equals the MG_GRAPHS=0 one bit for bit."""
+    is capturing ("raise": what an out-of-memory in the graph's pool looks like), or does something HIP forbids during a capture
+    and thereby invalidates it ("invalidate": a device synchronisation; the runtime then fails every later call on the stream until
+    the capture is ended and the error state read) -- has already marked every packed weight layout as fresh (the pack kernels
+    were captured, never run) and left deferred reduction jobs that point into the discarded graph pool.  The eager fallback must
+    not inherit any of it: the whole trajectory equals the MG_GRAPHS=0 one bit for bit."""
     import warnings
 
     import bench
@@ -320,6 +323,8 @@ def test_failed_graph_capture_falls_back_to_bit_identical_eager_updates(monkeypa
 
     def flush(self):
         if torch.cuda.is_current_stream_capturing():
+            if how == "invalidate":
+                torch.cuda.synchronize()  # illegal during a capture: raises and leaves the capture invalidated
             raise RuntimeError("injected: capture fails inside the weight-gradient sweep")
         return real_flush(self)
     l_eager, s_eager = run(False)
