@@ -657,7 +657,23 @@ __device__ __forceinline__ void wino_wgrad_reduce_body(const float* __restrict__
 #pragma unroll
   for (int s = 0; s < 9; ++s) m[s] = 0.f;
   if (e < total) {
-    for (int k = kl; k < nsplit; k += 8) {
+    // four slabs' worth of loads (36) in flight, then their adds in slab order: as a plain loop hipcc waits for each slab's nine
+    // loads before it requests the next one -- nsplit / 8 memory round trips in a row (the sum and its order are unchanged)
+    int k = kl;
+    for (; k + 24 < nsplit; k += 32) {
+      float v[4][9];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* src = slab + (size_t)(k + 8 * u) * 9 * total + e;
+#pragma unroll
+        for (int s = 0; s < 9; ++s) v[u][s] = src[(size_t)s * total];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int s = 0; s < 9; ++s) m[s] += v[u][s];
+    }
+    for (; k < nsplit; k += 8) {
       const float* src = slab + (size_t)k * 9 * total + e;
 #pragma unroll
       for (int s = 0; s < 9; ++s) m[s] += src[(size_t)s * total];

@@ -9,10 +9,11 @@ for c in $CASES; do
   L=${c%%:*}; B=${c##*:}
   D=$R/gpurun_out/r04_trace_l${L}_bs${B}
   rm -rf $D
+  python3 $R/bench.py --level $L --batch $B --steps 160 --warmup 40 --no-extra --no-cpu-baseline --no-cadence > $R/gpurun_out/r04_unprofiled_run_l${L}_bs${B}.json 2>/dev/null || exit 1
   rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 $R/bench.py --level $L --batch $B --steps 160 --warmup 40 --no-extra --no-cpu-baseline --no-cadence > $R/gpurun_out/r04_profiled_run_l${L}_bs${B}.json 2>/dev/null || exit 1
   cp $D/*/*kernel_stats.csv $R/gpurun_out/r04_bench_l${L}_bs${B}_kernel_stats.csv
   f=$(ls $D/*/*kernel_trace.csv | head -1)
-  python3 $R/tools/trace_table.py $f 45 $R/gpurun_out/r04_profiled_run_l${L}_bs${B}.json > $R/gpurun_out/r04_trace_table_l${L}_bs${B}.txt
+  python3 $R/tools/trace_table.py $f 45 $R/gpurun_out/r04_profiled_run_l${L}_bs${B}.json $R/gpurun_out/r04_unprofiled_run_l${L}_bs${B}.json > $R/gpurun_out/r04_trace_table_l${L}_bs${B}.txt
   head -1 $R/gpurun_out/r04_trace_table_l${L}_bs${B}.txt
   rm -rf $D
 done

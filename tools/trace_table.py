@@ -1,5 +1,6 @@
 """Per-kernel table of a rocprofv3 --kernel-trace CSV (steady-state tail of the run), grouped by kernel name and workgroup count.
-    python tools/trace_table.py TRACE.csv [top] [BENCH.json of the same (profiled) run: its ms_per_step is printed beside the busy time]"""
+    python tools/trace_table.py TRACE.csv [top] [BENCH.json of the same (profiled) run: its ms_per_step is printed beside the busy
+    time] [BENCH.json of an un-profiled run of the same configuration]"""
 import collections
 import csv
 import re
@@ -25,6 +26,9 @@ if len(sys.argv) > 3:
     import json
     d = json.loads([ln for ln in open(sys.argv[3]) if ln.startswith("{")][-1])
     line += f"; ms_per_step of the same (profiled) run {d['ms_per_step']:.3f} (busy / that = {tot / steps / 1e6 / d['ms_per_step']:.3f})"
+if len(sys.argv) > 4:  # the same configuration on the same box right before, without the profiler
+    u = json.loads([ln for ln in open(sys.argv[4]) if ln.startswith("{")][-1])
+    line += f"; un-profiled run just before on the same box {u['ms_per_step']:.3f} ms (busy / that = {tot / steps / 1e6 / u['ms_per_step']:.3f})"
 print(line)
 for (k, g), (cnt, t) in sorted(c.items(), key=lambda kv: -kv[1][1])[:top]:
     print(f"  {k:50s} WGs {g:6d} {cnt / steps:5.1f}/step {t / cnt / 1e3:7.1f} us  {t / steps / 1e3:7.1f} us/step {100 * t / tot:5.1f}%")
