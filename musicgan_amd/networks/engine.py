@@ -115,7 +115,7 @@ class PackCache:
     @staticmethod
     def small_ok(x: torch.Tensor, cout: int, **kw) -> bool:
         """Whether `conv` routes this call to ops.conv3x3_small: supported epilogue (no PixelNorm / tile masks), output map within
-        MG_SMALLCONV_MAX_SIDE (default 8) and few enough pixels to be latency-bound (MG_SMALLCONV_MAX_PIXELS, default 3072 up to 4x4, 1536 at 8x8)."""
+        MG_SMALLCONV_MAX_SIDE (default 8) and few enough pixels to be latency-bound (MG_SMALLCONV_MAX_PIXELS, default 3072 up to 4x4, 2048 at 8x8)."""
         if kw.get("pixnorm") or kw.get("mask_out") or kw.get("unpool_mask") is not None or kw.get("want_y", True) is False:
             return False
         m = kw.get("mask_aux")
@@ -126,8 +126,8 @@ class PackCache:
             h, wd = 2 * h, 2 * wd
         side = int(os.environ.get("MG_SMALLCONV_MAX_SIDE", "8"))
         # measured against the direct / Winograd kernels (tools/ab_smallconv.py): ahead up to 192 images at 2x2 / 4x4 (whole images
-        # per workgroup), up to 24 images at 8x8 (row bands); beyond that each layer is throughput- not latency-bound
-        cap = int(os.environ.get("MG_SMALLCONV_MAX_PIXELS", "3072" if h * wd <= 16 else "1536"))
+        # per workgroup), up to 32 images at 8x8 (row bands); beyond that each layer is throughput- not latency-bound
+        cap = int(os.environ.get("MG_SMALLCONV_MAX_PIXELS", "3072" if h * wd <= 16 else "2048"))
         if h > side or wd > side or n * h * wd > cap:
             return False
         return ops.conv3x3_small_supported(n, cin, cout, h, wd)
