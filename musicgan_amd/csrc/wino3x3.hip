@@ -766,6 +766,18 @@ int wino_run(WinoArgs& a, bool pn, hipStream_t s) {
   if (wt == 2 && !pn && cfg > 2 && getenv("MG_WINO_CFG") == nullptr &&
       ((long long)N * Ht * Wt + 31) / 32 * mg_cdiv(nt, cfg) < n_cu && mg_cdiv(nt, 2) * 2 <= a.NT)
     cfg = 2;
+  // Few 64-tile blocks per CU (the 48- and 64-channel layers at the reference's batch of 6: 128x128 / 64x64 maps at levels 6-7):
+  // the one-workgroup-per-CU tilings idle through most of their last round and have nobody to overlap their vector phases with;
+  // two out-channel tiles per four-wave workgroup, several per CU, are 5-18 % ahead there (tools/tune_wino.py 6 6 and 7 6:
+  // 64 channels up to 4.5 blocks per CU, 48 channels at 1.5 but not at 4.5; at 16 per CU -- level 5, batch 64 -- the large tilings win)
+  const char* few = getenv("MG_WINO_FEW");  // measurement switch: 0 = keep the large tilings
+  if (!pn && !narrow && getenv("MG_WINO_CFG") == nullptr && getenv("MG_WINO_WT") == nullptr && (few == nullptr || atoi(few) != 0)) {
+    const long long b64 = (long long)N * Ht * Wt / 64;
+    if (((cfg == 4 && b64 < 6ll * n_cu) || (cfg == 3 && 2 * b64 < 5ll * n_cu)) && mg_cdiv(nt, 2) * 2 <= a.NT) {
+      cfg = 2;
+      wt = 2;
+    }
+  }
   const int tpb = wt * 16;
   a.TBW = mg_pow2_ceil(Wt) < 16 ? mg_pow2_ceil(Wt) : 16;  // 16 tiles = 32 pixels = one 128-byte line per row and channel
   a.TBH = mg_pow2_ceil(Ht) < tpb / a.TBW ? mg_pow2_ceil(Ht) : tpb / a.TBW;
