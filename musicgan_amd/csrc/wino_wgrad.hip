@@ -643,28 +643,34 @@ __global__ void __launch_bounds__(512, 4) wino_wgrad_narrow_mfma(const WwArgs a)
   if (cb == 0 && t == 0 && ys >= 0 && ys < OT * 16 && o0 + ys < a.CoutP) a.slab_b[(size_t)split * a.CoutP + o0 + ys] = bsum;
 }
 
-// Sum the split-K slabs (already transformed to the 9 taps by the partial kernel) in a fixed order.  Block = 64 consecutive (c, o)
-// pairs x 8 split-lanes (a thread sums every 8th split of the 9 taps: enough loads in flight for what is a pure latency problem),
-// LDS-combined as a fixed tree => deterministic.
-__device__ __forceinline__ void wino_wgrad_reduce_body(const float* __restrict__ slab, const float* __restrict__ slab_b, int nsplit,
-                                                       float* __restrict__ gw, float* __restrict__ gb, int Cout, int Cin,
-                                                       int CoutP, int CinP, int accumulate, int block) {
-  __shared__ float red[8][9][64];
-  const int el = threadIdx.x & 63, kl = threadIdx.x >> 6;  // 64 (c, o) pairs x 8 split-lanes
-  const int e = block * 64 + el;  // e = c * CoutP + o over the padded block
+// Sum the split-K slabs (already transformed to the 9 taps by the partial kernel) in a fixed order.  Block = EL consecutive (c, o)
+// pairs x KL split-lanes, EL * KL = 512 (a thread sums every KL-th split of the 9 taps, four slabs of loads in flight: this is a
+// pure latency problem), LDS-combined as a fixed tree => deterministic.  KL = 8 normally; 32 for the layers with few filter
+// elements and hundreds of splits (16..48-channel layers on 256x256 / 512x512 maps): at 8 lanes their 8 workgroups walked 64 slabs
+// each while the chip waited -- and their bias sum, 512 loads four at a time in ONE thread per out-channel, took 86 us at level 7.
+// The bias gradient is summed the same way by the threads of in-channel 0.
+__host__ __device__ inline int ww_reduce_lanes(int nsplit, int total) { return (nsplit >= 128 && total <= 8192) ? 32 : 8; }
+
+template <int KL>
+__device__ __forceinline__ void wino_wgrad_reduce_lanes(const float* __restrict__ slab, const float* __restrict__ slab_b, int nsplit,
+                                                        float* __restrict__ gw, float* __restrict__ gb, int Cout, int Cin,
+                                                        int CoutP, int CinP, int accumulate, int block, float (*red)[512]) {
+  constexpr int EL = 512 / KL;
+  const int el = threadIdx.x % EL, kl = threadIdx.x / EL;
+  const int e = block * EL + el;  // e = c * CoutP + o over the padded block
   const int total = CinP * CoutP;
-  float m[9];
+  float m[10];  // 9 taps + the bias gradient (threads of in-channel 0: e = o)
 #pragma unroll
-  for (int s = 0; s < 9; ++s) m[s] = 0.f;
+  for (int s = 0; s < 10; ++s) m[s] = 0.f;
   if (e < total) {
     // four slabs' worth of loads (36) in flight, then their adds in slab order: as a plain loop hipcc waits for each slab's nine
-    // loads before it requests the next one -- nsplit / 8 memory round trips in a row (the sum and its order are unchanged)
+    // loads before it requests the next one -- nsplit / KL memory round trips in a row
     int k = kl;
-    for (; k + 24 < nsplit; k += 32) {
+    for (; k + 3 * KL < nsplit; k += 4 * KL) {
       float v[4][9];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const float* src = slab + (size_t)(k + 8 * u) * 9 * total + e;
+        const float* src = slab + (size_t)(k + KL * u) * 9 * total + e;
 #pragma unroll
         for (int s = 0; s < 9; ++s) v[u][s] = src[(size_t)s * total];
       }
@@ -673,51 +679,78 @@ __device__ __forceinline__ void wino_wgrad_reduce_body(const float* __restrict__
 #pragma unroll
         for (int s = 0; s < 9; ++s) m[s] += v[u][s];
     }
-    for (; k < nsplit; k += 8) {
+    for (; k < nsplit; k += KL) {
       const float* src = slab + (size_t)k * 9 * total + e;
 #pragma unroll
       for (int s = 0; s < 9; ++s) m[s] += src[(size_t)s * total];
     }
+    if (gb != nullptr && e < CoutP) {  // c == 0: this thread's share of the bias slabs of out-channel o = e
+      int kb = kl;
+      for (; kb + 7 * KL < nsplit; kb += 8 * KL) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = slab_b[(size_t)(kb + KL * u) * CoutP + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m[9] += v[u];
+      }
+      for (; kb < nsplit; kb += KL) m[9] += slab_b[(size_t)kb * CoutP + e];
+    }
   }
 #pragma unroll
-  for (int s = 0; s < 9; ++s) red[kl][s][el] = m[s];
+  for (int s = 0; s < 10; ++s) red[s][kl * EL + el] = m[s];
   __syncthreads();
   if (kl != 0 || e >= total) return;
   const int c = e / CoutP, o = e % CoutP;
+  auto lanes = [&](int s) {  // fixed pairwise tree over the KL split-lanes
+    float t[KL];
+#pragma unroll
+    for (int q = 0; q < KL; ++q) t[q] = red[s][q * EL + el];
+#pragma unroll
+    for (int w = 1; w < KL; w *= 2)
+#pragma unroll
+      for (int q = 0; q < KL; q += 2 * w) t[q] += t[q + w];
+    return t[0];
+  };
   if (c < Cin && o < Cout) {
     float* dst = gw + ((size_t)o * Cin + c) * 9;
 #pragma unroll
     for (int s = 0; s < 9; ++s) {
-      const float w = ((red[0][s][el] + red[1][s][el]) + (red[2][s][el] + red[3][s][el])) +
-                      ((red[4][s][el] + red[5][s][el]) + (red[6][s][el] + red[7][s][el]));
+      const float w = lanes(s);
       dst[s] = accumulate ? dst[s] + w : w;
     }
   }
   if (gb != nullptr && c == 0 && o < Cout) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int k = 0;
-    for (; k + 3 < nsplit; k += 4) {
-      s0 += slab_b[(size_t)k * CoutP + o];
-      s1 += slab_b[(size_t)(k + 1) * CoutP + o];
-      s2 += slab_b[(size_t)(k + 2) * CoutP + o];
-      s3 += slab_b[(size_t)(k + 3) * CoutP + o];
-    }
-    for (; k < nsplit; ++k) s0 += slab_b[(size_t)k * CoutP + o];
-    const float s = (s0 + s1) + (s2 + s3);
-    gb[o] = accumulate ? gb[o] + s : s;
+    const float sb = lanes(9);
+    gb[o] = accumulate ? gb[o] + sb : sb;
   }
+}
+
+__device__ __forceinline__ void wino_wgrad_reduce_body(const float* __restrict__ slab, const float* __restrict__ slab_b, int nsplit,
+                                                       float* __restrict__ gw, float* __restrict__ gb, int Cout, int Cin,
+                                                       int CoutP, int CinP, int accumulate, int block) {
+  __shared__ float red[10][512];
+  if (ww_reduce_lanes(nsplit, CinP * CoutP) == 32)
+    wino_wgrad_reduce_lanes<32>(slab, slab_b, nsplit, gw, gb, Cout, Cin, CoutP, CinP, accumulate, block, red);
+  else
+    wino_wgrad_reduce_lanes<8>(slab, slab_b, nsplit, gw, gb, Cout, Cin, CoutP, CinP, accumulate, block, red);
 }
 
 // One launch for the reduce of SEVERAL layers (the weight-gradient sweep of an update ends with one of these per layer: 8 launches of
 // ~20 us each, latency-bound, at level 5): jobs travel by value, blockIdx.y selects the job, blocks past a job's extent return.
 constexpr int WW_JOBS = 40;
 struct WwJobs {
+  int n;
+  int first[WW_JOBS + 1];  // prefix sums of the jobs' block counts: workgroup b belongs to the job with first[i] <= b < first[i + 1]
   mg_wgrad_job_t j[WW_JOBS];
 };
 __global__ void __launch_bounds__(512) wino_wgrad_reduce_multi(const WwJobs jobs) {
-  const mg_wgrad_job_t j = jobs.j[blockIdx.y];
-  if ((int)blockIdx.x * 64 >= j.CinP * j.CoutP) return;
-  wino_wgrad_reduce_body(j.slab, j.slab_b, j.nsplit, j.gw, j.gb, j.Cout, j.Cin, j.CoutP, j.CinP, j.accumulate, blockIdx.x);
+  // (a 2-D grid of "largest job x jobs" launched ~10x the workgroups a sweep needs: 19 us for the slabs of level 3)
+  int i = 0;
+#pragma unroll 1
+  while (i + 1 < jobs.n && (int)blockIdx.x >= jobs.first[i + 1]) ++i;
+  const mg_wgrad_job_t j = jobs.j[i];
+  wino_wgrad_reduce_body(j.slab, j.slab_b, j.nsplit, j.gw, j.gb, j.Cout, j.Cin, j.CoutP, j.CinP, j.accumulate,
+                         (int)blockIdx.x - jobs.first[i]);
 }
 
 struct WwPlan {
@@ -948,15 +981,16 @@ extern "C" int mg_wino3x3_wgrad_reduce(const mg_wgrad_job_t* jobs, int n, mg_str
   for (int first = 0; first < n; first += WW_JOBS) {
     const int m = n - first < WW_JOBS ? n - first : WW_JOBS;
     WwJobs c;
-    int most = 0;
+    c.n = m;
+    c.first[0] = 0;
     for (int i = 0; i < m; ++i) {
       c.j[i] = jobs[first + i];
       MG_CHECK_ARG(c.j[i].slab && c.j[i].gw && c.j[i].nsplit > 0 && c.j[i].CinP > 0 && c.j[i].CoutP > 0,
                    "mg_wino3x3_wgrad_reduce: bad job %d", first + i);
-      const int blocks = mg_cdiv(c.j[i].CinP * c.j[i].CoutP, 64);
-      if (blocks > most) most = blocks;
+      const int total = c.j[i].CinP * c.j[i].CoutP;
+      c.first[i + 1] = c.first[i] + mg_cdiv(total, 512 / ww_reduce_lanes(c.j[i].nsplit, total));
     }
-    hipLaunchKernelGGL(wino_wgrad_reduce_multi, dim3(most, m), dim3(512), 0, (hipStream_t)stream, c);
+    hipLaunchKernelGGL(wino_wgrad_reduce_multi, dim3(c.first[m]), dim3(512), 0, (hipStream_t)stream, c);
     MG_CHECK_LAUNCH("mg_wino3x3_wgrad_reduce");
   }
   return MG_OK;
