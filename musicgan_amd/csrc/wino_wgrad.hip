@@ -931,7 +931,12 @@ extern "C" int mg_wino3x3_wgrad_partial_multi(const mg_wgrad_desc_t* d, int n, i
     auto cost = [&](int i) { return pl[i].CT * pl[i].OT + 6; };
     long long work = 0;
     for (int k = 0; k < m; ++k) work += (long long)pl[idx[k]].a.nblk * pl[idx[k]].ncb * pl[idx[k]].a.nob * cost(idx[k]);
-    long long budget = (work + n_cu - 1) / n_cu;  // cost units per workgroup
+    int slots = n_cu;
+    {
+      const char* e = getenv("MG_WGRAD_GROUP_SLOTS");  // measurement switch: workgroups per group launch in units of 1/4 of the CUs
+      if (e != nullptr && atoi(e) > 0) slots = n_cu * atoi(e) / 4;
+    }
+    long long budget = (work + slots - 1) / slots;  // cost units per workgroup
     int ns[WW_GROUP], total;
     for (;;) {
       total = 0;
@@ -946,7 +951,7 @@ extern "C" int mg_wino3x3_wgrad_partial_multi(const mg_wgrad_desc_t* d, int n, i
         floor_reached = floor_reached && v == 1;
         total += v * q.ncb * q.a.nob;
       }
-      if (total <= n_cu || floor_reached) break;
+      if (total <= slots || floor_reached) break;
       budget += (budget + 15) / 16;
     }
     WwGroup g;
