@@ -13,15 +13,13 @@
 // Pinned by tests/test_host_cpu.py (this header compiled by g++, 4 M random + special inputs against torch.angle / torch.abs on the
 // CPU, bitwise) and by tests/test_audio_gpu.py (the device build against the reference's golden codec output).
 //
-// Compiles as HIP device code (the codec kernel) and as plain C++ (the CPU pin); floating-point contraction must be OFF
-// (musicgan_amd/_build.py passes -ffp-contract=off; the test passes it to g++).
+// Device code for the codec kernel; the CPU pin compiles the same text with g++ (SLF_FN defined as `static inline`).  Floating-point
+// contraction must be OFF (musicgan_amd/_build.py passes -ffp-contract=off; the test passes it to g++).
 #pragma once
 #include <math.h>
 
-#if defined(__HIPCC__)
+#ifndef SLF_FN  // the CPU pin defines it as `static inline` before including this file
 #define SLF_FN __device__ __forceinline__
-#else
-#define SLF_FN static inline
 #endif
 
 namespace slf {

@@ -220,7 +220,7 @@ def test_sleef_restatement_has_the_bits_of_torch_cpu_abs_and_angle(tmp_path):
     import subprocess
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "musicgan_amd", "csrc")
     shim = tmp_path / "shim.cpp"
-    shim.write_text('#include "sleef_f32.h"\n'
+    shim.write_text('#define SLF_FN static inline\n#include "sleef_f32.h"\n'
                     'extern "C" void slf_angle_n(const float* re, const float* im, float* o, long n) '
                     '{ for (long i = 0; i < n; ++i) o[i] = slf::atan2f_u10(im[i], re[i]); }\n'
                     'extern "C" void slf_abs_n(const float* re, const float* im, float* o, long n) '
