@@ -227,10 +227,9 @@ def create_dataset(audio_path: str, dataset_output_dir: str, *, packed: bool = T
     nb_vec = audio.N_VEC
     if world > 1:
         th.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        from scipy.io import wavfile
         counts = []
         for p in w_p:
-            _, data = wavfile.read(p, mmap=True)
+            data, _ = audio.wavio.load_pcm(p)
             counts.append(_nb_samples(data.shape[0], nb_vec))
     t_setup = time.perf_counter()
     mine = [f_i for f_i in range(len(w_p)) if world == 1 or f_i % world == rank]

@@ -264,3 +264,36 @@ def test_sleef_restatement_has_the_bits_of_torch_cpu_abs_and_angle(tmp_path):
     for out, want in ((a, wants[0]), (m, wants[1])):
         same = (out.view(np.uint32) == want.view(np.uint32)) | (np.isnan(out) & np.isnan(want))
         assert bool(same.all()), [(re[i], im[i], out[i], want[i]) for i in np.nonzero(~same)[0][:5]]
+
+
+def test_aiff_and_au_files_load_like_wav_files(tmp_path):
+    """`th_audio.load` (functions.py:43) reads whatever torchaudio can; without torchaudio the uncompressed containers are read
+    here: AIFF and Sun AU (big-endian linear PCM, 8 / 16 / 24 / 32 bits) through the standard library -- same normalisation as
+    a WAV file of the same samples (torchaudio.load(normalize=True): v / 2^(bits-1)), `load_pcm` keeps them integer for the
+    device path, anything codec-backed raises."""
+    import aifc
+    import sunau
+    from musicgan_amd.audio import wavio
+    rng = np.random.default_rng(5)
+    frames, ch = 1000, 2
+    for width in (1, 2, 3, 4):
+        bits = 8 * width
+        v = rng.integers(-(1 << (bits - 1)), (1 << (bits - 1)) - 1, (frames, ch), dtype=np.int64)
+        raw = b"".join(int(s).to_bytes(width, "big", signed=True) for s in v.reshape(-1))
+        want = (v.astype(np.float64) / float(1 << (bits - 1))).astype(np.float32).T
+        for mod, ext in ((aifc, ".aiff"), (sunau, ".au")):
+            path = str(tmp_path / f"t{bits}{ext}")
+            with mod.open(path, "wb") as f:
+                f.setnchannels(ch)
+                f.setsampwidth(width)
+                f.setframerate(44100)
+                if mod is sunau:
+                    f.setcomptype("NONE", "not compressed")  # (the module's default is u-law)
+                f.writeframes(raw)
+            x, sr = wavio.load(path)
+            assert sr == 44100 and tuple(x.shape) == (ch, frames) and x.dtype == torch.float32
+            assert np.array_equal(x.numpy(), want), (bits, ext)
+            pcm, sr = wavio.load_pcm(path)
+            assert pcm.shape == (frames, ch) and pcm.dtype == (np.int16 if width <= 2 else np.int32)
+    with pytest.raises(ValueError, match="flac"):
+        wavio.load(str(tmp_path / "song.flac"))
