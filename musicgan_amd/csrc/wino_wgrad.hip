@@ -928,7 +928,12 @@ extern "C" int mg_wino3x3_wgrad_partial_multi(const mg_wgrad_desc_t* d, int n, i
     if (m < 2) break;
     // The splits of the group: about the same TIME per workgroup (a chunk of a <CT, OT> block costs ~ CT * OT MFMA groups + its
     // staging), at most one workgroup per CU over the whole group -- a 257th workgroup would run alone after the others.
-    auto cost = [&](int i) { return pl[i].CT * pl[i].OT + 6; };
+    int fixed = 6;
+    {
+      const char* e = getenv("MG_WGRAD_GROUP_FIXED");  // measurement switch: the per-chunk staging term of the cost model
+      if (e != nullptr && atoi(e) >= 0) fixed = atoi(e);
+    }
+    auto cost = [&](int i) { return pl[i].CT * pl[i].OT + fixed; };
     long long work = 0;
     for (int k = 0; k < m; ++k) work += (long long)pl[idx[k]].a.nblk * pl[idx[k]].ncb * pl[idx[k]].a.nob * cost(idx[k]);
     int slots = n_cu;
