@@ -471,7 +471,9 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
-    for _ in range(args.warmup):
+    # W untimed steps as asked -- and never fewer than four: an update runs eagerly twice and is captured as a HIP graph on its
+    # third call (train_step.py), which must not fall into the timed region
+    for _ in range(max(args.warmup, 4)):
         one_step()
     stepper.finish()
     barrier()
