@@ -500,33 +500,49 @@ int dispatch_wgrad(const WgradPlan& pl, hipStream_t s) {
 __global__ void __launch_bounds__(256) wgrad3x3_1x1map_k(const float* __restrict__ x, const float* __restrict__ gy,
                                                         float* __restrict__ gw, float* __restrict__ gb, int N, int Cin, int Cout,
                                                         int accumulate, int bias_n) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= Cin * Cout) return;
-  const int o = e / Cin, c = e - o * Cin;
+  // workgroup = 32 (o, c) pairs x 8 slices of the samples (one thread walking 192 samples is 24 memory round trips in a row);
+  // the slices' float64 partial sums meet in LDS and are added in slice order
+  __shared__ double red[2][8][32];
+  const int pl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + pl;
+  const bool live = e < Cin * Cout;
+  const int o = live ? e / Cin : 0, c = live ? e - o * Cin : 0;
+  const int per = (N + 7) / 8;
+  const int n_lo = sl * per, n_hi = n_lo + per < N ? n_lo + per : N;
   double acc = 0.0, accb = 0.0;
-  for (int n0 = 0; n0 < N; n0 += 8) {
+  for (int n0 = n_lo; n0 < n_hi; n0 += 8) {
     float xv[8], gv[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {  // loads first, arithmetic second (samples past N re-read sample 0 and count for nothing)
-      const int n = n0 + u < N ? n0 + u : 0;
+    for (int u = 0; u < 8; ++u) {  // loads first, arithmetic second (samples past the slice re-read its first one and count for nothing)
+      const int n = n0 + u < n_hi ? n0 + u : n_lo;
       xv[u] = x[(size_t)n * Cin + c];
       gv[u] = gy[(size_t)n * Cout + o];
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      if (n0 + u < N) {
+      if (n0 + u < n_hi) {
         acc += (double)gv[u] * (double)xv[u];
         if (n0 + u < bias_n) accb += (double)gv[u];
       }
     }
   }
+  red[0][sl][pl] = acc;
+  red[1][sl][pl] = accb;
+  __syncthreads();
+  if (sl != 0 || !live) return;
+  double tw = 0.0, tb = 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    tw += red[0][k][pl];
+    tb += red[1][k][pl];
+  }
   float* w9 = gw + (size_t)e * 9;
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
-    const float v = t == 4 ? (float)acc : 0.f;
+    const float v = t == 4 ? (float)tw : 0.f;
     w9[t] = accumulate ? w9[t] + v : v;
   }
-  if (gb && c == 0) gb[o] = accumulate ? gb[o] + (float)accb : (float)accb;
+  if (gb && c == 0) gb[o] = accumulate ? gb[o] + (float)tb : (float)tb;
 }
 
 }  // namespace
@@ -536,7 +552,7 @@ extern "C" int mg_conv3x3_wgrad_1x1map(const float* x, const float* gy, float* g
   MG_CHECK_ARG(x && gy && gw && N > 0 && Cin > 0 && Cout > 0, "mg_conv3x3_wgrad_1x1map: bad arguments");
   MG_CHECK_ARG((long long)Cin * Cout < (1ll << 27), "mg_conv3x3_wgrad_1x1map: too many filters");
   const int bn = (bias_n <= 0 || bias_n > N) ? N : bias_n;
-  hipLaunchKernelGGL(wgrad3x3_1x1map_k, dim3(mg_cdiv(Cin * Cout, 256)), dim3(256), 0, (hipStream_t)stream, x, gy, gw, gb, N, Cin, Cout,
+  hipLaunchKernelGGL(wgrad3x3_1x1map_k, dim3(mg_cdiv(Cin * Cout, 32)), dim3(256), 0, (hipStream_t)stream, x, gy, gw, gb, N, Cin, Cout,
                      accumulate, bn);
   MG_CHECK_LAUNCH("mg_conv3x3_wgrad_1x1map");
   return MG_OK;
