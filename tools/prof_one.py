@@ -39,6 +39,9 @@ elif case == "dg16":   # level-7 critic, first conv: data gradient 32 -> 16 chan
 elif case == "fw16":   # level-7 critic, first conv forward: 16 -> 32 @512x512 + lrelu + pool over 18 images
     x = R(18, 16, 512, 512); up = ops.pack_wino3x3(R(32, 16, 3, 3) * 0.05, False); b = R(32)
     fn = lambda: ops.conv3x3(x, None, b, 32, lrelu=True, pool=True, wino=up)
+elif case == "fwm16":  # the same layer as the critic's forward pass runs it: + tile mask out, the full-resolution y never written
+    x = R(18, 16, 512, 512); up = ops.pack_wino3x3(R(32, 16, 3, 3) * 0.05, False); b = R(32)
+    fn = lambda: ops.conv3x3(x, None, b, 32, lrelu=True, pool=True, wino=up, mask_out=True)
 elif case == "codec":
     from musicgan_amd import audio
     c = ops.stft_1024(torch.rand(44100 * 600, device=dev) - 0.5)
