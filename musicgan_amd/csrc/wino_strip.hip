@@ -20,7 +20,8 @@
 //     sign, mask selects as bit-field inserts, pooled outputs summed in the lane (a lane's 2x2 tile IS one pooled pixel);
 //   * the eight waves of a workgroup take vertically adjacent tile rows (the two halo rows they share come out of the CU's own
 //     cache), consecutive workgroups of an XCD horizontally adjacent blocks; the next chunk's rows -- at a block's last chunk:
-//     the first chunk of the wave's next block -- are requested before the current chunk's MFMAs are issued.
+//     the first chunk of the wave's next block -- are requested before the current chunk's MFMAs are issued; the kernel is
+//     specialised per epilogue kind so that its block loop is straight-line code.
 // A hardware rule found on the way (gfx950): a VGPR written by a vector instruction inside INLINE ASSEMBLY and read as an MFMA
 // source by the next instructions needs wait states the compiler only inserts for instructions it scheduled itself -- without
 // them the MFMA reads the old register contents (wrong sums, no fault).  The packed transforms below therefore end in `s_nop`.
@@ -266,6 +267,7 @@ __global__ void __launch_bounds__(64 * NWAVE, 1) wino3x3_strip(const WinoArgs a)
     }
   };
 
+  auto acc_fence = [&]() __attribute__((always_inline)) {};
   // lane parts of the epilogue's offsets (bytes inside one image of Cout x H x W / Cout x Ht x Wt)
   const int ly = ((rq * 4) * HW + 2 * col) * 4;
   const int lpo = ((rq * 4) * PP + col) * 4;
@@ -297,6 +299,12 @@ __global__ void __launch_bounds__(64 * NWAVE, 1) wino3x3_strip(const WinoArgs a)
     block_geometry();
     load_rows(0);
     mfma_chunk(a.nchunk - 1, F_{});
+    // the next block's first chunk is transformed BEFORE this block's stores are issued: a wait for loads that have stores behind
+    // them is a wait for those stores too (one counter on gfx9; the compiler waits vmcnt(0) whenever both kinds are pending)
+    __builtin_amdgcn_sched_barrier(0);
+    acc_fence();
+    transform_rows();
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---------------------------------------------------------------- epilogue
     {
@@ -516,9 +524,6 @@ __global__ void __launch_bounds__(64 * NWAVE, 1) wino3x3_strip(const WinoArgs a)
       }
     }
     if (item >= nitems) break;
-    __builtin_amdgcn_sched_barrier(0);  // (left alone the scheduler pulls this transform up into the epilogue and spills)
-    transform_rows();
-    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -578,23 +583,28 @@ int strip_kind(const WinoArgs& a) {  // the dispatch of wino_epilogue.h, by name
 
 }  // namespace
 
-// Whether wino_run (wino3x3.hip) hands this call to the strip kernel: whole 8-channel chunks, whole 16-channel out tiles (at most
-// three), whole 16-tile blocks per tile row, the filter bank within LDS, every plane within 32-bit byte offsets, and enough tile
-// blocks that every wave of the chip walks several of them (MG_WINO_STRIP=0: never; =2: whenever the shape allows).
+// Whether wino_run (wino3x3.hip) hands this call to the strip kernel.  Shape: whole 16-channel chunk pairs, whole 16-channel out tiles (at
+// most three), whole 16-tile blocks per tile row, whole groups of 8 tile rows, the filter bank within LDS, every plane within 32-bit
+// byte offsets, masked kinds bias-free, PixelNorm without y.  Choice (tools/ab_wino_strip.py, profiles/r05_ab_wino_strip.txt): two
+// out-channel tiles -- 32 channels, both in one wave at two waves per SIMD -- are 8-28 % ahead of wino3x3.hip from ~4 000 tile
+// blocks on; three tiles (192 accumulators, one wave per SIMD) only where the outputs are pooled (1/4 of the stores) and every wave
+// walks many blocks; one tile (16 out-channels: the 32 -> 16 data gradient) is memory-latency-bound in both kernels and stays.
+// MG_WINO_STRIP=0: never; =2: whenever the shape allows (tests, A/B).
 bool mgi_wino_strip_takes(const WinoArgs& a, bool pn) {
   const char* e = getenv("MG_WINO_STRIP");
   if (e != nullptr && atoi(e) == 0) return false;
   const int nt = a.Cout / 16;
-  if ((a.Cin % WCC) != 0 || (a.Cout % 16) != 0 || nt > 3 || (a.W % 32) != 0 || (a.H % 2) != 0) return false;
+  if ((a.Cin % 16) != 0 || (a.Cout % 16) != 0 || nt > 3 || (a.W % 32) != 0 || ((a.H / 2) % 8) != 0 || (a.H % 2) != 0) return false;
   if (pn && (nt > 2 || a.y != nullptr)) return false;  // (PixelNorm: all channels of a pixel in one wave, p and rn only)
-  if ((a.Cin % 16) != 0) return false;                 // at least two chunks per block (the loop's first and last are peeled)
-  if (((a.H / 2) % 8) != 0) return false;              // whole groups of vertically adjacent tile rows per workgroup
   if ((a.flags & (MG_CONV_MASK_AUX | MG_CONV_UNPOOL | WF_BLEND_BWD)) && a.bias != nullptr) return false;  // masked kinds: bias-free
   if ((size_t)(a.Cin / WCC) * nt * 8192 > 160 * 1024) return false;
   if ((long long)a.Cout * a.H * a.W * 16 >= (1ll << 31) || (long long)a.Cin * a.H * a.W * 4 >= (1ll << 31)) return false;
+  if (e != nullptr && atoi(e) > 1) return true;
   const long long blocks = (long long)a.N * (a.H / 2) * (a.W / 32);
-  const long long min_blocks = e != nullptr && atoi(e) > 1 ? 1 : 8ll * 8 * mg_cu_count();
-  return blocks >= min_blocks;
+  if (nt == 2) return blocks >= 4096;
+  const bool pooled_only = (a.flags & MG_CONV_MASK_OUT) || ((a.flags & MG_CONV_MASK_BYTES) && !(a.flags & WF_BLEND));
+  if (nt == 3) return pooled_only && blocks >= 16384;
+  return false;
 }
 
 int mgi_wino_strip_run(WinoArgs& a, hipStream_t s) {

@@ -14,6 +14,8 @@ HOT = [
     (r"wino3x3_mfmaILi1ELi3ELi4E", 16),   # 12-wave tiling at its 168-register ceiling: three spilled dwords outside the MFMA loop
     (r"wino3x3_mfmaILi1ELi[23]ELi2E", 0),
     (r"wino3x3_mfmaILi1ELi2ELi4E", 0),
+    (r"wino3x3_stripILi[12]E", 0),        # one / two out-channel tiles per wave: two waves per SIMD, everything in registers
+    (r"wino3x3_stripILi3E", 0),           # three tiles: 192 accumulators, one wave per SIMD (AGPRs, no scratch)
     (r"wino_wgrad_mfma", 0),
     (r"wino_wgrad_group_mfma", 0),
     (r"conv3x3_mfma", 0),
