@@ -177,6 +177,28 @@ def time_step(level: int, batch: int, rand_channels: int, device, steps: int, wa
     return e0.elapsed_time(e1) / steps
 
 
+def step_roofline(fpi: float, xfpi: float, ips_per_gpu: float) -> dict:
+    """`frac` = `achieved` / `peak` with achieved = the FLOPs the MFMA pipe really EXECUTES per second (Winograd / sub-pixel passes
+    count 1/2.25): a fraction of the machine, never above 1.  `algorithmic_frac` counts the direct-convolution FLOPs the step
+    replaces (SURVEY 8(d)'s 4*Gf + 12*Df definition) -- an efficiency figure that may exceed `frac` by up to 2.25x."""
+    return {"bound": "mfma", "achieved": xfpi * ips_per_gpu / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": xfpi * ips_per_gpu / 1e12 / MFMA_F32_PEAK_TFLOPS,
+            "algorithmic_achieved": fpi * ips_per_gpu / 1e12,
+            "algorithmic_frac": fpi * ips_per_gpu / 1e12 / MFMA_F32_PEAK_TFLOPS,
+            "basis": f"{xfpi / 1e9:.2f} executed / {fpi / 1e9:.2f} algorithmic GFLOP per image x images/s per GPU"}
+
+
+def step_traffic(level: int, batch: int):
+    """Whole-step HBM bytes (rocprofv3 PMC over D+G steps: FETCH_SIZE x 2 + WRITE_SIZE summed over every dispatch, collected by
+    tools/measure_step_traffic.sh and committed under profiles/) beside SURVEY 8(d)'s ~0.7 GB / image estimate."""
+    tpath = os.path.join(ROOT, "profiles", f"traffic_step_l{level}.json")
+    if not os.path.exists(tpath):
+        return None
+    with open(tpath) as f:
+        rec = json.load(f)
+    return rec if rec.get("batch") == batch else None
+
+
 def level_record(device, rand_channels: int, level: int, batch: int, steps: int, warmup: int, what: str):
     """One more (level, batch) with the headline's step and accounting: BASELINE.json configs[0..1] and the levels a real run of
     the reference lives at -- it trains at batch 6 (train.py:43) and spends 65 % of its scheduled FLOPs at level 6 and everything
@@ -187,10 +209,7 @@ def level_record(device, rand_channels: int, level: int, batch: int, steps: int,
     fpi, xfpi = flops_per_image(level, rand_channels), executed_flops_per_image(level, rand_channels, batch)
     return {"workload": f"ProGAN level {level} WGAN-GP D+G step, 2x{side}x{side}, batch {batch}, alpha 0.5 ({what})",
             "value": ips, "unit": "images/s", "ms_per_step": ms, "steps": steps, "warmup": warmup,
-            "roofline": {"bound": "mfma", "achieved": fpi * ips / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": fpi * ips / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                         "executed_frac": xfpi * ips / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                         "basis": f"{fpi / 1e9:.2f} algorithmic / {xfpi / 1e9:.2f} executed GFLOP per image"}}
+            "roofline": step_roofline(fpi, xfpi, ips)}
 
 
 def stft_record(device, cpu: bool):
@@ -315,7 +334,12 @@ def create_dataset_and_train_records(device, rand_channels: int):
                             "writer_threads": stats["writer_threads"], "writer_busy_thread_s": stats["writer_busy_s"]}}
         stats, out["create_dataset_e2e"] = record("track_[01].wav", data, nfiles)
         try:
-            _, out["create_dataset_e2e_8_files"] = record("track_*.wav", os.path.join(tmp, "data8"), nlong)
+            st8, out["create_dataset_e2e_8_files"] = record("track_*.wav", os.path.join(tmp, "data8"), nlong)
+            # the bound of this box, measured in the same run and the same scratch directory, and how much of it the loop reaches
+            probe = host_io_probe(device, tmp, st8["writer_threads"])
+            rec8 = out["create_dataset_e2e_8_files"]
+            rec8["roofline"] = {"bound": "host io", "achieved": rec8["files_per_s_after_setup"], "peak": probe["bound_files_per_s"],
+                                "unit": "files/s", "frac": rec8["files_per_s_after_setup"] / probe["bound_files_per_s"], "probe": probe}
         except OSError as e:  # (scratch space: the record is optional)
             out["create_dataset_e2e_8_files"] = {"skipped": str(e)}
         shutil.rmtree(os.path.join(tmp, "data8"), ignore_errors=True)
@@ -346,6 +370,75 @@ def create_dataset_and_train_records(device, rand_channels: int):
             "images_per_s": 64 * (last - first) / dt, "dataset_samples": stats["samples"]}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def host_io_probe(device, scratch_dir: str, threads: int, samples_per_thread: int = 48) -> dict:
+    """What bounds create_dataset end to end on THIS box (BASELINE configs[4]; reference create_dataset.py:34-64 leaves 201 float64
+    (2,512,512) .pt files = 843 MB per 10-minute file behind, ours additionally the 421 MB float32 side-car): (a) the pinned
+    device-to-host rate in the loop's 64 MiB chunks, one and two copy streams; (b) the writer path of one sample -- float32 ->
+    float64 (numpy), `writev` of the 8 MiB .pt file, `pwrite` of the 4 MiB side-car row -- on one thread and on `threads` threads,
+    in the scratch directory the record uses.  bound per file = max(421 MB / D2H rate, 201 samples / writer-path rate)."""
+    import threading
+    chunk_bytes = 32 * 2 * 512 * 512 * 4
+    src = torch.empty(chunk_bytes // 4, dtype=torch.float32, device=device).normal_()
+    pins = [torch.empty(chunk_bytes // 4, dtype=torch.float32).pin_memory() for _ in range(4)]
+    out = {"chunk_MiB": chunk_bytes >> 20}
+    for nstreams in (1, 2):
+        streams = [torch.cuda.Stream(device=device) for _ in range(nstreams)]
+        reps = 16
+        for k in range(2):  # (first round: warm-up)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(reps):
+                with torch.cuda.stream(streams[i % nstreams]):
+                    pins[i % 4].copy_(src, non_blocking=True)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        out[f"d2h_GB_per_s_{nstreams}_stream{'s' if nstreams > 1 else ''}"] = reps * chunk_bytes / dt / 1e9
+    # the writer threads' own native call (mg_pt_write_samples: side-car row + widening + writev, 8 samples per call, no interpreter
+    # lock) on pinned chunks the copy engine has just filled -- cold for the CPU; every thread its own side-car file, as the shards
+    import ctypes
+    from musicgan_amd import _lib
+    lib = _lib.load()
+    prefix, suffix = b"p" * 1024, b"s" * 600  # (the container's bytes around the payload: about the sizes of fast_pt.PtTemplate's)
+    row_floats = 2 * 512 * 512
+    batches = max(1, samples_per_thread // 8)
+
+    def writer(tid, busy):
+        side = os.open(os.path.join(scratch_dir, f"probe_side_{tid}.bin"), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        t0 = time.perf_counter()
+        for bi in range(batches):
+            r0 = ((tid * 3 + bi) % 4) * 8
+            paths = b"\0".join(os.fsencode(os.path.join(scratch_dir, f"probe_{tid}_{bi * 8 + k}.pt")) for k in range(8)) + b"\0"
+            rc = lib.mg_pt_write_samples(ctypes.c_void_p(pins[(tid + bi) % 4].data_ptr() + r0 * row_floats * 4), 8, row_floats, paths,
+                                         prefix, len(prefix), suffix * 8, len(suffix), side, bi * 8 * row_floats * 4)
+            assert rc == 0
+        busy[tid] = time.perf_counter() - t0
+        os.close(side)
+
+    for nthr in (1, threads):
+        busy = [0.0] * nthr
+        ths = [threading.Thread(target=writer, args=(t, busy)) for t in range(nthr)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        wall = time.perf_counter() - t0
+        out[f"writer_path_samples_per_s_{nthr}_thread{'s' if nthr > 1 else ''}"] = nthr * batches * 8 / wall
+        out[f"writer_path_ms_per_sample_{nthr}_thread{'s' if nthr > 1 else ''}"] = 1e3 * sum(busy) / (nthr * batches * 8)
+        for t in range(nthr):
+            for i in range(batches * 8):
+                os.remove(os.path.join(scratch_dir, f"probe_{t}_{i}.pt"))
+            os.remove(os.path.join(scratch_dir, f"probe_side_{t}.bin"))
+    d2h = max(out["d2h_GB_per_s_1_stream"], out["d2h_GB_per_s_2_streams"])
+    per_file_d2h = 201 * 2 * 512 * 512 * 4 / (d2h * 1e9)
+    per_file_write = 201 / out[f"writer_path_samples_per_s_{threads}_thread{'s' if threads > 1 else ''}"]
+    out.update({"threads": threads, "bound_s_per_file_d2h": per_file_d2h, "bound_s_per_file_writer_path": per_file_write,
+                "bound_files_per_s": 1.0 / max(per_file_d2h, per_file_write),
+                "basis": "per 10-minute file: 421 MB over the measured pinned D2H rate; 201 samples over the measured rate of the writer "
+                         "path (widen to float64 + writev 8 MiB .pt + pwrite 4 MiB side-car row) on the writer threads; the larger one"})
     return out
 
 
@@ -411,6 +504,25 @@ def cpu_baseline(level: int, rand_channels: int, batch: int, iters: int):
                       f"(forward/backward only, reference-as-executed work incl. its non-detached D step)"}
 
 
+def launch_ranks(n: int, argv) -> int:
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1 --master-port <free> bench.py argv` as
+    a child process with inherited stdout / stderr; returns its exit code.  MG_BENCH_LAUNCHER (a command line) replaces
+    `python -m torch.distributed.run` -- the CPU test suite puts a recording stub there."""
+    import shlex
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    launcher = os.environ.get("MG_BENCH_LAUNCHER")
+    head = shlex.split(launcher) if launcher else [sys.executable, "-m", "torch.distributed.run"]
+    cmd = head + ["--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                  os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: RCCL between processes needs it on this image)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -427,6 +539,11 @@ def main():
                     help="skip the 5 critic : 1 generator `secondary` record (profiling runs: the trace then holds D+G steps only)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start one rank per GPU ourselves -- as a CHILD process and before this
+        # process has touched the GPU (an exec, or a fork after HIP initialisation, takes the node down on this pool) -- and pass
+        # rank 0's JSON line and the exit code through.
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -485,10 +602,17 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    ranks_seen, rank_ms = 1, [1e3 * elapsed / args.steps] * 2  # [fastest, slowest] rank
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        dd = torch.distributed
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        tmin = t.clone()
+        ones = torch.ones(1, dtype=torch.float32, device=device)
+        dd.all_reduce(t, op=dd.ReduceOp.MAX)
+        dd.all_reduce(tmin, op=dd.ReduceOp.MIN)
+        dd.all_reduce(ones, op=dd.ReduceOp.SUM)  # a sum of ones over the data-path backend: the ranks that really took part
         elapsed = float(t.item())
+        ranks_seen, rank_ms = int(round(float(ones.item()))), [1e3 * float(tmin.item()) / args.steps, 1e3 * elapsed / args.steps]
     ms_per_step = 1e3 * elapsed / args.steps
     images_per_s = world * args.batch * args.steps / elapsed
 
@@ -550,28 +674,25 @@ def main():
     if rank == 0:
         fpi = flops_per_image(args.level, args.rand_channels)
         xfpi = executed_flops_per_image(args.level, args.rand_channels, args.batch)
-        achieved = fpi * images_per_s / world / 1e12
         dom = dominant_kernel_probe(device, args.batch)
         line = {
             "metric": f"spectrogram-images/sec G+D step, 2x{side}x{side} bs{args.batch}",
             "value": images_per_s, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ranks_seen": ranks_seen, "ms_per_step_fastest_rank": rank_ms[0], "ms_per_step_slowest_rank": rank_ms[1],
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"ProGAN level {args.level} WGAN-GP D+G step, 2x{side}x{side}, "
                                    f"batch {args.batch}/GPU, rand_channels {args.rand_channels}, alpha 0.5 (fade-in live), "
                                    f"Adam(1e-3,(0,0.9)) on both nets, random-init weights",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_F32_PEAK_TFLOPS,
-                         "executed_frac": xfpi * images_per_s / world / 1e12 / MFMA_F32_PEAK_TFLOPS,
+            "roofline": {**step_roofline(fpi, xfpi, images_per_s / world),
+                         # HBM bytes of ONE launch of the dominant kernel (per launch, like `dominant_kernel`), and of the whole step
                          "traffic": (dom.get("hbm_traffic") or {}).get("bytes_per_launch"),
-                         "basis": f"whole step, per GPU: {fpi / 1e9:.2f} algorithmic GFLOP/image (4*Gf+12*Df) x images/s; "
-                                  f"executed_frac: {xfpi / 1e9:.2f} GFLOP/image actually issued to the MFMA pipe "
-                                  f"(Winograd / sub-pixel passes count 1/2.25); traffic: HBM bytes of ONE dominant launch, NOT "
-                                  f"measured in this run -- read from profiles/traffic_dominant_kernel.json (rocprofv3 PMC passes, "
-                                  f"tools/measure_traffic.sh, last re-measured in round 4)",
-                         # frac = FLOPs the kernel EXECUTES over the peak (a fraction of the machine); algorithmic_frac counts the
-                         # direct-convolution FLOPs it replaces (2.25x as many) and may exceed 1
+                         "step_traffic": step_traffic(args.level, args.batch),
+                         "traffic_basis": "NOT measured in this run: rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, separate passes) read "
+                                          "from profiles/traffic_dominant_kernel.json (tools/measure_traffic.sh) and "
+                                          "profiles/traffic_step_l5.json (tools/measure_step_traffic.sh), re-measured in round 5",
+                         # dominant launch, timed live with HIP events on its stream: frac = executed FLOPs over the peak
                          "dominant_kernel": {**dom, "frac": dom["executed_tflops"] / MFMA_F32_PEAK_TFLOPS,
                                              "algorithmic_frac": dom["tflops"] / MFMA_F32_PEAK_TFLOPS}},
         }
@@ -595,10 +716,11 @@ def main():
             line["stft"] = stft_record(device, cpu=False)
             line.update(create_dataset_and_train_records(device, args.rand_channels))
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.level, args.rand_channels, args.cpu_batch, iters=3)
+            # 1 warm-up + 1 timed step each (~20 s at level 5): a bounded sample, and the driver's GPU-load sampler still sees the GPU
+            line["cpu_baseline"] = cpu_baseline(args.level, args.rand_channels, args.cpu_batch, iters=1)
             if extra:
-                line["l4_bs32"]["cpu_baseline"] = cpu_baseline(4, args.rand_channels, 32, iters=3)
-                line["l3_bs8"]["cpu_baseline"] = cpu_baseline(3, args.rand_channels, 8, iters=3)
+                line["l4_bs32"]["cpu_baseline"] = cpu_baseline(4, args.rand_channels, 32, iters=1)
+                line["l3_bs8"]["cpu_baseline"] = cpu_baseline(3, args.rand_channels, 8, iters=2)
                 wav = torch.rand(44100 * 600, device=device, generator=torch.Generator(device=device).manual_seed(7)) - 0.5
                 line["stft"]["cpu_baseline"] = stft_cpu_baseline(wav)
         print(json.dumps(line), flush=True)

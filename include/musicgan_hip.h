@@ -388,6 +388,15 @@ int mg_codec_inv(const float* magn_phase, const float* bark_scale, float* wav_ou
 size_t mg_crc32_f64_ws_bytes(int n, int64_t floats_per_sample);
 int mg_crc32_f64(const float* x, uint32_t* crc_out, void* ws, size_t ws_bytes, int n, int64_t floats_per_sample, mg_stream_t stream);
 
+/* HOST function (no GPU work): the writer threads' per-sample work of create_dataset [create_dataset.py:52-62, th.save(magn_phase.to(
+ * th.float64), path)] for n consecutive float32 samples `rows` (row_floats each, e.g. a slice of a pinned chunk): widen to float64 and
+ * write file i as  prefix | float64 payload | suffixes[i*suffix_len ...]  (the zip container of th.save around the payload, from
+ * musicgan_amd.fast_pt.PtTemplate) to the i-th NUL-terminated path in `paths`; side_fd >= 0: also pwrite the float32 row at
+ * side_off + i * row_floats * 4 of that file (the fast loader's side-car).  Thread-safe; bound through ctypes it runs without the
+ * interpreter lock. */
+int mg_pt_write_samples(const float* rows, int n, int64_t row_floats, const char* paths, const unsigned char* prefix, int64_t prefix_len,
+                        const unsigned char* suffixes, int64_t suffix_len, int side_fd, int64_t side_off);
+
 /* Per-batch input transform of the training loop, fused: ChannelMinMaxNorm -> ChangeRange(-1,1) -> Resize(S) (bilinear with
  * anti-aliasing, align_corners = False: torchvision's tensor path) [audio/transforms.py:4-40, utils.py:70-86, train.py:138-140].
  * x (N,2,H,W) float64 (x_is_f64 != 0: cast to float32 on read, == x.to(th.float)) or float32; out (N,2,S,S) float32, S <= H, W. */

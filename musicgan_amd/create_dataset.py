@@ -25,6 +25,19 @@ from . import audio
 from .audio import dataset as _ds
 
 CHUNK_SAMPLES = 32  # samples per pinned chunk (64 MiB of float32)
+RING_CHUNKS = 6     # pinned chunks in flight between the copy streams and the writer threads
+
+
+def host_cpus() -> int:
+    """CPUs this process may really use: min(affinity mask, cgroup cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
 
 
 def _nb_samples(nb_frames_wav: int, nb_vec: int) -> int:
@@ -33,7 +46,8 @@ def _nb_samples(nb_frames_wav: int, nb_vec: int) -> int:
 
 
 def _remove_sidecar(folder: str) -> None:
-    for name in (_ds.PACKED_META, _ds.PACKED_BIN, _ds.PACKED_BIN + ".tmp"):  # meta first: a reader never sees meta without data
+    shards = [os.path.basename(p) for p in glob.glob(join(glob.escape(folder), _ds.PACKED_BIN + ".*"))]
+    for name in [_ds.PACKED_META, _ds.PACKED_BIN] + shards:  # meta first: a reader never sees meta without data
         try:
             os.remove(join(folder, name))
         except FileNotFoundError:
@@ -41,8 +55,12 @@ def _remove_sidecar(folder: str) -> None:
 
 
 class _Writers:
-    """`n` threads that widen a float32 sample to float64 and th.save it (create_dataset.py:52-62); the first failure is kept and
-    re-raised by `close()` / the next `submit()`."""
+    """`n` threads that widen float32 samples to float64 and write them as `.pt` files (create_dataset.py:52-62); the first failure
+    is kept and re-raised by `close()` / the next `submit()`.  A job is a run of consecutive rows of one pinned chunk.  With a
+    template (fast_pt.PtTemplate) the per-sample work -- side-car row, widening, container prefix | payload | suffix -- is ONE native
+    call per job (`mg_pt_write_samples`, made without the interpreter lock); the Python left per sample is the 600-byte suffix."""
+
+    JOB_ROWS = 8
 
     def __init__(self, n: int, template=None):
         self.q: "queue.Queue" = queue.Queue(maxsize=4 * n)
@@ -55,31 +73,40 @@ class _Writers:
             t.start()
 
     def _run(self):
+        import ctypes
+        from . import _lib
         while True:
             job = self.q.get()
             if job is None:
                 return
-            chunk, row, path, side_fd, side_off, crc = job
+            chunk, row, paths, side_fd, side_off, check_first = job
             try:
                 if self.err is None:
                     chunk.event.synchronize()  # the chunk's device-to-host copy has landed
                     t0 = time.perf_counter()
-                    if side_fd is not None:  # the float32 side-car row of this sample, at its place in the array file
-                        view = memoryview(chunk.host[row].numpy()).cast("B")
-                        done = 0
-                        while done < len(view):
-                            done += os.pwrite(side_fd, view[done:], side_off + done)
-                    # widened by numpy on this thread: torch's intra-op pool under 16 writer threads made `.to(float64)` of
-                    # one 4 MiB sample cost 20-50 ms (over-subscription) against 0.6 ms here
-                    wide = chunk.host[row].numpy().astype("float64")
-                    if self.template is not None and crc is not None:
-                        if crc < 0:  # spot check (first sample of a file): the GPU's CRC against zlib's on the same bytes
+                    n = len(paths)
+                    if self.template is not None:
+                        tp = self.template
+                        crcs = [int(v) & 0xFFFFFFFF for v in chunk.crc[row:row + n].tolist()]  # from the GPU, came with the samples
+                        if check_first:  # spot check (first sample of a file): the GPU's CRC against zlib's on the same bytes
                             import zlib
-                            crc = -crc - 1
-                            assert zlib.crc32(wide) & 0xFFFFFFFF == crc, f"device CRC-32 of {path} disagrees with zlib"
-                        self.template.write(path, wide, crc)  # the bytes th.save would write, without its serializer / CRC pass
+                            wide = chunk.host[row].numpy().astype("float64")
+                            assert zlib.crc32(wide) & 0xFFFFFFFF == crcs[0], f"device CRC-32 of {paths[0]} disagrees with zlib"
+                        suffixes = b"".join(tp.suffix(c) for c in crcs)
+                        rows = chunk.host[row:row + n]
+                        _lib.check(_lib.load().mg_pt_write_samples(
+                            ctypes.c_void_p(rows.data_ptr()), n, rows[0].numel(), b"\0".join(os.fsencode(p) for p in paths) + b"\0",
+                            tp.prefix, len(tp.prefix), suffixes, len(suffixes) // n, -1 if side_fd is None else side_fd, side_off),
+                            "mg_pt_write_samples")
                     else:
-                        th.save(th.from_numpy(wide), path)
+                        for i, path in enumerate(paths):
+                            arr = chunk.host[row + i].numpy()
+                            if side_fd is not None:  # the float32 side-car row of this sample, at its place in the array file
+                                view, done = memoryview(arr).cast("B"), 0
+                                while done < len(view):
+                                    done += os.pwrite(side_fd, view[done:], side_off + i * arr.nbytes + done)
+                            # (numpy, not torch: its intra-op pool under 16 writer threads made `.to(float64)` cost 20-50 ms a sample)
+                            th.save(th.from_numpy(arr.astype("float64")), path)
                     with self._lock:
                         self.busy_s += time.perf_counter() - t0
             except BaseException as e:  # noqa: BLE001  (kept for the submitting thread)
@@ -87,11 +114,12 @@ class _Writers:
             finally:
                 chunk.release()
 
-    def submit(self, chunk, row, path, side_fd=None, side_off=0, crc=None):
+    def submit(self, chunk, row, paths, side_fd=None, side_off=0, check_first=False):
+        """`paths`: the files of rows row .. row + len(paths) - 1 of `chunk` (side-car rows consecutive from byte `side_off`)."""
         if self.err is not None:
             raise self.err
         chunk.acquire()
-        self.q.put((chunk, row, path, side_fd, side_off, crc))
+        self.q.put((chunk, row, list(paths), side_fd, side_off, check_first))
 
     def close(self):
         for _ in self.threads:
@@ -196,6 +224,7 @@ class _Chunk:
 
     def __init__(self, nb_vec: int, ring: "queue.Queue"):
         self.host = th.empty((CHUNK_SAMPLES, 2, audio.N_FFT // 2, nb_vec), dtype=th.float32).pin_memory()
+        self.crc = th.empty((CHUNK_SAMPLES,), dtype=th.int64).pin_memory()  # CRC-32 of each sample's float64 bytes (mg_crc32_f64)
         self.event = th.cuda.Event()
         self._ring, self._refs, self._lock = ring, 0, threading.Lock()
 
@@ -242,10 +271,18 @@ def create_dataset(audio_path: str, dataset_output_dir: str, *, packed: bool = T
     dev = th.device("cuda", th.cuda.current_device())
     # started first: it reads and uploads file 0 while the chunk ring below is being page-locked
     loader = _Loader([w_p[f_i] for f_i in mine], dev)
-    n_thr = writer_threads or max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4))
+    # writer threads: one per CPU this process may use (at most 16) -- divided by the ranks sharing the host: 8 ranks x 16 threads
+    # on the cores of one node only take turns (the widen + write path is memory-bandwidth-bound)
+    cpus = host_cpus()
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    n_thr = writer_threads or max(1, min(16, cpus // local_world))
     ring: "queue.Queue" = queue.Queue()
-    for _ in range(4):
+    for _ in range(RING_CHUNKS):
         ring.put(_Chunk(nb_vec, ring))
+    # device-to-host copies go out on two streams of their own, alternating by chunk: the loop's stream never waits for a copy
+    # (it used to carry them, and the per-file `.cpu()` of the CRCs then waited for 421 MB of copies each time)
+    copy_streams = [th.cuda.Stream(device=dev) for _ in range(2)]
+    n_chunks = 0
     # th.save's output for a (2, 512, nb_vec) float64 tensor as a template (checked against th.save at construction; None: keep
     # calling th.save): the container's CRC-32 then comes from the GPU (mg_crc32_f64) instead of one host core per sample
     template = None
@@ -260,9 +297,12 @@ def create_dataset(audio_path: str, dataset_output_dir: str, *, packed: bool = T
     if packed and world == 1:
         # written row by row by the writer threads (os.pwrite at row idx): one thread streaming 421 MB per file was the
         # slowest stage of the loop
-        side = os.open(join(dataset_output_dir, _ds.PACKED_BIN + ".tmp"), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        # into PACKED_SHARDS files, blocks of PACKED_BLOCK_ROWS rows dealt round-robin: concurrent writes to ONE file take turns on
+        # its inode lock (0.25 ms per 2 MiB row = 20 files/s however many threads write)
+        side = [os.open(join(dataset_output_dir, _ds.shard_name(k, _ds.PACKED_SHARDS) + ".tmp"), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+                for k in range(_ds.PACKED_SHARDS)]
     t_start = time.perf_counter()
-    t_setup = t_start - t_setup  # pinned ring (4 x 64 MiB page-locked) + writer threads: paid once per call
+    t_setup = t_start - t_setup  # pinned ring (RING_CHUNKS x 64 MiB page-locked) + writer threads: paid once per call
     t_gpu = t_load = t_wait = t_drain = t_loader = 0.0
     row_bytes = 2 * (audio.N_FFT // 2) * nb_vec * 4
     idx = n_files = 0
@@ -290,22 +330,41 @@ def create_dataset(audio_path: str, dataset_output_dir: str, *, packed: bool = T
             crcs = None
             if template is not None:
                 from . import ops
-                crcs = ops.crc32_of_float64(both).cpu().tolist()  # (one small synchronising copy per file)
+                crcs = ops.crc32_of_float64(both)  # int64 [S] on the device; it travels with the samples, no host sync here
+            produced = th.cuda.Event()
+            produced.record()  # codec (+ CRC) of this file queued: the copy streams start behind it
             for c0 in range(0, both.size()[0], CHUNK_SAMPLES):
                 t2 = time.perf_counter()
                 chunk = ring.get()
                 t_wait += time.perf_counter() - t2
                 n = min(CHUNK_SAMPLES, both.size()[0] - c0)
                 chunk.acquire()  # held by this loop until everything that reads the chunk has been queued
-                chunk.host[:n].copy_(both[c0:c0 + n], non_blocking=True)
-                chunk.event.record()
-                for r in range(n):
-                    name = f"magn_phase_{idx}.pt"
-                    # side-car rows in idx order == AudioDataset order only after the sort in _finish_sidecar
-                    crc = None if crcs is None else (-crcs[c0 + r] - 1 if c0 + r == 0 else crcs[c0 + r])
-                    writers.submit(chunk, r, join(dataset_output_dir, name), side, len(names) * row_bytes, crc)
-                    names.append(name)
-                    idx += 1
+                cs = copy_streams[n_chunks % 2]
+                n_chunks += 1
+                with th.cuda.stream(cs):
+                    cs.wait_event(produced)
+                    chunk.host[:n].copy_(both[c0:c0 + n], non_blocking=True)
+                    if crcs is not None:
+                        chunk.crc[:n].copy_(crcs[c0:c0 + n], non_blocking=True)
+                        crcs.record_stream(cs)
+                    both.record_stream(cs)
+                    chunk.event.record(cs)
+                r0 = 0
+                while r0 < n:
+                    # a job = consecutive rows of this chunk inside ONE block of side-car rows (global row = len(names); rows in idx
+                    # order == AudioDataset order only after the sort in _finish_sidecar)
+                    g_row = len(names)
+                    m = min(n - r0, _ds.PACKED_BLOCK_ROWS - g_row % _ds.PACKED_BLOCK_ROWS)
+                    batch = [f"magn_phase_{idx + k}.pt" for k in range(m)]
+                    fd, off = None, 0
+                    if side is not None:
+                        k_sh, local = _ds.shard_of_row(g_row, _ds.PACKED_SHARDS, _ds.PACKED_BLOCK_ROWS)
+                        fd, off = side[k_sh], local * row_bytes
+                    writers.submit(chunk, r0, [join(dataset_output_dir, b) for b in batch], fd, off,
+                                   check_first=crcs is not None and c0 + r0 == 0)
+                    names.extend(batch)
+                    idx += m
+                    r0 += m
                 chunk.release()
             t_gpu += time.perf_counter() - t1
         t_loader = loader.busy_s
@@ -321,7 +380,8 @@ def create_dataset(audio_path: str, dataset_output_dir: str, *, packed: bool = T
             except BaseException:  # noqa: BLE001  (the original error is the one to report)
                 pass
         if side is not None:
-            os.close(side)
+            for fd in side:
+                os.close(fd)
             if not ok:
                 _remove_sidecar(dataset_output_dir)
     if side is not None:
@@ -338,19 +398,29 @@ def _finish_sidecar(folder: str, names_in_write_order) -> None:
     """The rows were streamed in write order (idx 0, 1, 2, ...); AudioDataset / the loader index samples in file-NAME order
     (plain string sort, as the reference does: magn_phase_10.pt < magn_phase_2.pt).  The meta file carries the row of every
     sorted name, so the stream never has to be permuted on disk."""
-    tmp = join(folder, _ds.PACKED_BIN + ".tmp")
+    k = _ds.PACKED_SHARDS
+    tmps = [join(folder, _ds.shard_name(i, k) + ".tmp") for i in range(k)]
+
+    def drop():
+        for t in tmps:
+            try:
+                os.remove(t)
+            except FileNotFoundError:
+                pass
     if not names_in_write_order:
-        os.remove(tmp)
+        drop()
         return
     order = sorted(range(len(names_in_write_order)), key=lambda i: names_in_write_order[i])
     files = [names_in_write_order[i] for i in order]
     if tuple(files) != _ds._sample_files(folder):
         # the directory also holds magn_phase_*.pt files of an earlier, longer run: AudioDataset would serve them too (as the
         # reference's does), so no side-car describes this directory -- the loader then takes the reference path
-        os.remove(tmp)
+        drop()
         return
-    os.replace(tmp, join(folder, _ds.PACKED_BIN))
+    for i, t in enumerate(tmps):
+        os.replace(t, join(folder, _ds.shard_name(i, k)))
     with open(join(folder, _ds.PACKED_META), "w") as fh:
         json.dump({"count": len(files), "shape": list(_ds._SAMPLE_SHAPE), "dtype": "float32", "files": files, "rows": order,
+                   "shards": k, "block_rows": _ds.PACKED_BLOCK_ROWS,
                    "sizes": [os.path.getsize(join(folder, f)) for f in files],
                    "probes": [_ds.file_probe(join(folder, f)) for f in files]}, fh)

@@ -1,0 +1,88 @@
+// Host side of create_dataset's writer threads (no kernel in this file): widen float32 samples to float64 and write each as one
+// `.pt` file = container prefix + payload + per-sample suffix (fast_pt.PtTemplate: the bytes th.save would write -- the reference's
+// `th.save(magn_phase.to(th.float64), ...)`, /root/reference/music_gan/create_dataset.py:52-62), plus the float32 side-car row.
+// Called through ctypes, which releases the interpreter lock for the duration: with the per-sample work in Python 16 writer
+// threads took turns on the lock (4.0 ms of thread time per sample against 0.85 ms for the same system calls made from C).
+#include <cerrno>
+#include <cstdlib>
+#include <cstring>
+#include <fcntl.h>
+#include <sys/uio.h>
+#include <unistd.h>
+
+#include "mg_common.h"
+
+namespace {
+
+bool write_all(int fd, struct iovec* iov, int cnt) {
+  while (cnt > 0) {
+    ssize_t w = writev(fd, iov, cnt);
+    if (w < 0) {
+      if (errno == EINTR) continue;
+      return false;
+    }
+    while (cnt > 0 && (size_t)w >= iov->iov_len) {
+      w -= iov->iov_len;
+      ++iov;
+      --cnt;
+    }
+    if (cnt > 0) {
+      iov->iov_base = static_cast<char*>(iov->iov_base) + w;
+      iov->iov_len -= w;
+    }
+  }
+  return true;
+}
+
+bool pwrite_all(int fd, const char* p, size_t n, off_t off) {
+  while (n > 0) {
+    ssize_t w = pwrite(fd, p, n, off);
+    if (w < 0) {
+      if (errno == EINTR) continue;
+      return false;
+    }
+    p += w;
+    n -= w;
+    off += w;
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" int mg_pt_write_samples(const float* rows, int n, int64_t row_floats, const char* paths, const unsigned char* prefix,
+                                   int64_t prefix_len, const unsigned char* suffixes, int64_t suffix_len, int side_fd,
+                                   int64_t side_off) {
+  MG_CHECK_ARG(rows && n > 0 && row_floats > 0 && paths && prefix && suffixes && prefix_len >= 0 && suffix_len >= 0,
+               "mg_pt_write_samples: bad arguments");
+  double* wide = static_cast<double*>(malloc((size_t)row_floats * sizeof(double)));
+  MG_CHECK_ARG(wide != nullptr, "mg_pt_write_samples: out of memory");
+  const char* path = paths;
+  int rc = MG_OK;
+  for (int i = 0; i < n && rc == MG_OK; ++i) {
+    const float* src = rows + (size_t)i * row_floats;
+    if (side_fd >= 0 && !pwrite_all(side_fd, reinterpret_cast<const char*>(src), (size_t)row_floats * 4, (off_t)(side_off + (int64_t)i * row_floats * 4))) {
+      mg_set_error("mg_pt_write_samples: side-car write failed: %s", strerror(errno));
+      rc = MG_EINVAL;
+      break;
+    }
+    for (int64_t k = 0; k < row_floats; ++k) wide[k] = (double)src[k];
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) {
+      mg_set_error("mg_pt_write_samples: cannot open %s: %s", path, strerror(errno));
+      rc = MG_EINVAL;
+      break;
+    }
+    struct iovec iov[3] = {{const_cast<unsigned char*>(prefix), (size_t)prefix_len},
+                           {wide, (size_t)row_floats * sizeof(double)},
+                           {const_cast<unsigned char*>(suffixes + (size_t)i * suffix_len), (size_t)suffix_len}};
+    if (!write_all(fd, iov, 3)) {
+      mg_set_error("mg_pt_write_samples: write to %s failed: %s", path, strerror(errno));
+      rc = MG_EINVAL;
+    }
+    close(fd);
+    path += strlen(path) + 1;
+  }
+  free(wide);
+  return rc;
+}

@@ -39,6 +39,7 @@ class GradBucket:
         self._work = None
         self._stream: Optional[torch.cuda.Stream] = None
         self._done: Optional[torch.cuda.Event] = None
+        self.copied = False
 
     @property
     def grad_scale(self) -> float:
@@ -98,23 +99,36 @@ class GradBucket:
             flat = torch.cat([p.grad.reshape(-1) for p in plist])
             if self.world > 1:
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        off = 0
-        for p in plist:
-            n = p.numel()
-            p.grad = flat[off:off + n].view_as(p)
-            off += n
+        if flat is not self._own:  # (slices of the own buffer already ARE the gradients, in the layout's order)
+            off = 0
+            for p in plist:
+                n = p.numel()
+                p.grad = flat[off:off + n].view_as(p)
+                off += n
         self._flat = flat
+        self.copied = flat is not self._own  # (tests: the data-parallel steppers must never flatten by copy)
 
     def _as_own_flat(self, plist) -> Optional[torch.Tensor]:
-        """The flat_sink() buffer if the gradients of `plist` are exactly its consecutive slices (then nothing is copied)."""
+        """The flat_sink() buffer if the gradients of `plist` are exactly its slices (then nothing is copied).  In ANY order:
+        `launch` walks `net.parameters()` (registration order) while `flat_sink` lays the buffer out in the engine's order
+        (`GenWeights.tensors()`: blocks, head, old head) -- a consecutive-order test fails for the generator and every update then
+        pays a torch.cat on the side stream."""
         if self._own is None:
             return None
-        off, base = 0, self._own.data_ptr()
+        base, size = self._own.data_ptr(), self._own.numel()
+        spans = []
         for p in plist:
-            if p.grad.data_ptr() != base + 4 * off or not p.grad.is_contiguous():
+            off = p.grad.data_ptr() - base
+            if off < 0 or off % 4 or not p.grad.is_contiguous() or p.grad.dtype != torch.float32:
                 return None
-            off += p.numel()
-        return self._own if off == self._own.numel() else None
+            spans.append((off // 4, p.numel()))
+        spans.sort()
+        end = 0
+        for off, n in spans:  # disjoint slices that tile the buffer
+            if off != end:
+                return None
+            end = off + n
+        return self._own if end == size else None
 
     def stream(self) -> Optional[torch.cuda.Stream]:
         return self._stream

@@ -237,7 +237,8 @@ def test_drivers_end_to_end_tiny_corpus(tmp_path):
     wavio.save(str(wav_dir / "short.wav"), torch.rand(1, 256 * 100, generator=rng) - 0.5, 44100)  # < 512 frames: skipped
     musicgan_amd.create_dataset(str(wav_dir / "*.wav"), str(data_dir))
     assert sorted(os.listdir(data_dir)) == sorted([f"magn_phase_{i}.pt" for i in range(4)] +  # 2 files x 2 samples
-                                                  ["magn_phase_f32.bin", "magn_phase_f32.json"])  # + the loader's side-car
+                                                  [f"magn_phase_f32.bin.{k}" for k in range(16)] +  # + the loader's side-car
+                                                  ["magn_phase_f32.json"])                        #   (16 shard files)
     files = sorted(f for f in os.listdir(data_dir) if f.endswith(".pt"))
     sample = torch.load(str(data_dir / files[0]))
     assert sample.dtype == torch.float64 and tuple(sample.shape) == (2, 512, 512)
@@ -533,7 +534,7 @@ def test_create_dataset_sidecar_is_rebuilt_not_reused(tmp_path):
     finally:
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
             del os.environ[k]
-    assert not audio.has_packed(str(out)) and not os.path.exists(str(out / "magn_phase_f32.bin"))
+    assert not audio.has_packed(str(out)) and not [f for f in os.listdir(str(out)) if f.startswith("magn_phase_f32")]
 
 
 def test_device_crc32_of_the_float64_payload_equals_zlib():

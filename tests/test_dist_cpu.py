@@ -94,3 +94,20 @@ def test_single_process_bucket_is_identity():
     b.wait()
     for p, g in zip(ps, gs):
         assert torch.equal(p.grad, g)
+
+
+def test_own_flat_buffer_is_recognised_in_any_parameter_order():
+    """GradBucket.flat_sink lays the buffer out in the engine's tensor order; launch() walks net.parameters().  The buffer must be
+    recognised as "already flat" whenever the gradients are exactly its disjoint slices, whatever order they are listed in."""
+    from musicgan_amd.dist import GradBucket
+    ps = [torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(2, 2))]
+    b = GradBucket()
+    flat, layout = b.flat_sink([ps[2], ps[0], ps[1]])  # engine order != registration order
+    assert flat.numel() == 21
+    for p in ps:
+        off, n = layout[id(p)]
+        p.grad = flat[off:off + n].view_as(p)
+    assert b._as_own_flat(ps) is flat and b._as_own_flat(list(reversed(ps))) is flat
+    assert b._as_own_flat(ps[:2]) is None  # a slice missing
+    ps[1].grad = torch.zeros(5)
+    assert b._as_own_flat(ps) is None      # a gradient living elsewhere

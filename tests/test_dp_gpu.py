@@ -67,6 +67,10 @@ def test_data_parallel_path_is_bit_identical_to_single_process(one_rank_nccl, mo
     live = [p for p in st_dp.disc.parameters() if p.grad is not None]
     assert flat is not None and sum(p.numel() for p in live) == flat.numel()
     assert all(flat.data_ptr() <= p.grad.data_ptr() < flat.data_ptr() + 4 * flat.numel() for p in live)
+    # ... for BOTH networks, and neither exchange flattened by copy (the generator's parameter order differs from its engine layout:
+    # a consecutive-order test used to fail there and every generator update paid a torch.cat on the side stream)
+    assert st_dp.bucket_d.copied is False and st_dp.bucket_g.copied is False
+    assert st_dp.bucket_g._flat is st_dp.bucket_g._own and st_dp.bucket_d._flat is st_dp.bucket_d._own
 
 
 def test_bench_runs_under_torchrun_as_the_driver_launches_it(tmp_path):

@@ -144,12 +144,21 @@ def test_packed_sidecar_index_and_invalidation(tmp_path):
     samples = [(torch.rand(*shape, generator=rng) * 2 - 1) for _ in range(n)]
     for i, x in enumerate(samples):
         torch.save(x.double(), os.path.join(folder, f"magn_phase_{i}.pt"))
-    # what create_dataset does: rows streamed in write order into .tmp, then _finish_sidecar
-    with open(os.path.join(folder, ds.PACKED_BIN + ".tmp"), "wb") as fh:
-        for x in samples:
-            fh.write(x.numpy().tobytes())
+    # what create_dataset does: rows streamed in write order into the shards' .tmp files (blocks of PACKED_BLOCK_ROWS rows dealt
+    # round-robin over PACKED_SHARDS files), then _finish_sidecar
+    def stream(rows):
+        fds = [open(os.path.join(folder, ds.shard_name(k, ds.PACKED_SHARDS) + ".tmp"), "wb") for k in range(ds.PACKED_SHARDS)]
+        for r, x in enumerate(rows):
+            k, local = ds.shard_of_row(r, ds.PACKED_SHARDS, ds.PACKED_BLOCK_ROWS)
+            fds[k].seek(local * x.numel() * 4)
+            fds[k].write(x.numpy().tobytes())
+        for fh in fds:
+            fh.close()
+    stream(samples)
     cd._finish_sidecar(folder, [f"magn_phase_{i}.pt" for i in range(n)])
     assert ds.has_packed(folder)
+    meta = json.load(open(os.path.join(folder, ds.PACKED_META)))
+    assert meta["shards"] == ds.PACKED_SHARDS and os.path.getsize(os.path.join(folder, ds.shard_name(1, ds.PACKED_SHARDS))) == 4 * samples[0].numel() * 4
     packed, ref = ds.PackedAudioDataset(folder), ds.AudioDataset(folder)
     names = sorted(f"magn_phase_{i}.pt" for i in range(n))
     assert names[2] == "magn_phase_10.pt" and len(packed) == len(ref) == n
@@ -180,13 +189,12 @@ def test_packed_sidecar_index_and_invalidation(tmp_path):
     torch.save(samples[0].double(), os.path.join(folder, "magn_phase_12.pt"))         # one more file
     assert not ds.has_packed(folder)
     # a run that wrote fewer files than the directory holds leaves no side-car (the loader then takes the reference path)
-    with open(os.path.join(folder, ds.PACKED_BIN + ".tmp"), "wb") as fh:
-        fh.write(samples[0].numpy().tobytes())
+    stream(samples[:1])
     cd._remove_sidecar(folder)
-    with open(os.path.join(folder, ds.PACKED_BIN + ".tmp"), "wb") as fh:
-        fh.write(samples[0].numpy().tobytes())
+    assert not [f for f in os.listdir(folder) if f.startswith(ds.PACKED_BIN)]
+    stream(samples[:1])
     cd._finish_sidecar(folder, ["magn_phase_0.pt"])
-    assert not ds.has_packed(folder) and not os.path.exists(os.path.join(folder, ds.PACKED_BIN + ".tmp"))
+    assert not ds.has_packed(folder) and not [f for f in os.listdir(folder) if f.endswith(".tmp")]
 
 
 def test_pt_template_writes_what_torch_save_writes(tmp_path):
@@ -297,3 +305,77 @@ def test_aiff_and_au_files_load_like_wav_files(tmp_path):
             assert pcm.shape == (frames, ch) and pcm.dtype == (np.int16 if width <= 2 else np.int32)
     with pytest.raises(ValueError, match="flac"):
         wavio.load(str(tmp_path / "song.flac"))
+
+
+def test_bench_with_gpus_n_and_no_launcher_starts_the_ranks_as_a_child_process(tmp_path):
+    """`python bench.py --gpus 8` the way the driver runs N = 1 (no torchrun, no WORLD_SIZE): bench.py must start
+    `python -m torch.distributed.run --nproc-per-node 8 ... bench.py <same flags>` itself, as a child, BEFORE it touches the GPU
+    (this container has none: reaching `torch.cuda.is_available()` would exit with "needs an MI355X"), hand its stdout through and
+    return its exit code.  MG_BENCH_LAUNCHER swaps the launcher for a recording stub."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stub = tmp_path / "stub_launcher.py"
+    stub.write_text("import json, os, sys\n"
+                    f"json.dump({{'argv': sys.argv[1:], 'ipc': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}}, open({str(tmp_path / 'seen.json')!r}, 'w'))\n"
+                    "print(json.dumps({'metric': 'from the stub', 'n_gpus': 8}))\n"
+                    "sys.exit(7)\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["MG_BENCH_LAUNCHER"] = f"{sys.executable} {stub}"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, cwd=root, timeout=300)
+    assert r.returncode == 7, r.stderr[-2000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1]) == {"metric": "from the stub", "n_gpus": 8}
+    seen = json.load(open(tmp_path / "seen.json"))
+    argv = seen["argv"]
+    assert "--nnodes=1" in argv and "--nproc-per-node=8" in argv
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and int(argv[argv.index("--master-port") + 1]) > 0
+    i = argv.index(os.path.join(root, "bench.py"))
+    assert argv[i + 1:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"]
+    assert seen["ipc"] == "0"
+    # under a launcher (RANK set) it does not spawn again: it goes on to the GPU check, which fails here
+    env2 = dict(env, RANK="0", WORLD_SIZE="8", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], capture_output=True, text=True, env=env2,
+                        cwd=root, timeout=300)
+    assert r2.returncode != 0 and "needs an MI355X" in (r2.stderr + r2.stdout)
+
+
+def test_native_sample_writer_writes_what_torch_save_writes(tmp_path):
+    """mg_pt_write_samples (the writer threads' native call, host code only): n float32 rows -> n `.pt` files byte-identical to
+    `th.save(row.to(th.float64))` (reference create_dataset.py:52-62) + the float32 side-car rows at their offsets."""
+    import ctypes
+    import io
+    import os
+    import zlib
+    from musicgan_amd import _lib
+    from musicgan_amd.fast_pt import PtTemplate
+    shape = (2, 16, 8)
+    tp = PtTemplate(shape)
+    assert tp.ok
+    g = torch.Generator().manual_seed(3)
+    rows = torch.randn(5, *shape, generator=g)
+    rows[1, 0, 0, 0], rows[2, 1, 3, 3] = -0.0, 1e-42  # signed zero, a denormal
+    paths = [str(tmp_path / f"s_{i}.pt") for i in range(5)]
+    crcs = [zlib.crc32(r.double().numpy().tobytes()) & 0xFFFFFFFF for r in rows]
+    suffixes = b"".join(tp.suffix(c) for c in crcs)
+    side = os.open(str(tmp_path / "side.bin"), os.O_RDWR | os.O_CREAT, 0o644)
+    off0 = 3 * rows[0].numel() * 4  # the batch starts at side-car row 3
+    rc = _lib.load().mg_pt_write_samples(ctypes.c_void_p(rows.data_ptr()), 5, rows[0].numel(),
+                                         b"\0".join(os.fsencode(p) for p in paths) + b"\0", tp.prefix, len(tp.prefix), suffixes,
+                                         len(suffixes) // 5, side, off0)
+    assert rc == 0
+    for i, p in enumerate(paths):
+        ref = io.BytesIO()  # (th.save names the archive's root after its target: a stream gives the template's "archive")
+        torch.save(rows[i].to(torch.float64), ref)
+        assert open(p, "rb").read() == ref.getvalue(), i
+        assert torch.equal(torch.load(p), rows[i].double())
+    got = np.fromfile(str(tmp_path / "side.bin"), dtype=np.float32)
+    assert got.size == 8 * rows[0].numel() and np.array_equal(got[3 * rows[0].numel():].view(np.uint32),
+                                                              rows.numpy().reshape(-1).view(np.uint32))
+    os.close(side)
+    # an unwritable path is an error, not a crash
+    rc = _lib.load().mg_pt_write_samples(ctypes.c_void_p(rows.data_ptr()), 1, rows[0].numel(), os.fsencode(str(tmp_path / "no" / "x.pt")) + b"\0",
+                                         tp.prefix, len(tp.prefix), suffixes, len(suffixes) // 5, -1, 0)
+    assert rc != 0 and b"cannot open" in _lib.load().mg_last_error()
