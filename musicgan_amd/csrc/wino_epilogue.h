@@ -81,8 +81,7 @@
           for (int q = 0; q < 4; ++q) on[g][q] *= ((mb >> q) & 1u) ? 1.f : a.slope;
         }
         if constexpr (MOUT) {
-          const unsigned mb = (on[g][0] > 0.f ? 1u : 0u) | (on[g][1] > 0.f ? 2u : 0u) | (on[g][2] > 0.f ? 4u : 0u) |
-                              (on[g][3] > 0.f ? 8u : 0u);
+          const unsigned mb = ((mg_pos_bit(on[g][0]) | (mg_pos_bit(on[g][1]) << 1)) | (mg_pos_bit(on[g][2]) << 2)) | (mg_pos_bit(on[g][3]) << 3);
           if (act) a.mo[ti] = (unsigned char)mb;
         }
       }

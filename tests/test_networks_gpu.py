@@ -283,11 +283,13 @@ def _oracle_full_step(level, batch):
     return _ORACLE_CACHE[key]
 
 
-@pytest.mark.parametrize("level,batch", [(5, 2), (4, 32)])
+@pytest.mark.parametrize("level,batch", [(5, 2), (4, 32), (6, 1), (7, 1), (5, 16)])
 def test_full_size_step_against_fp64_oracle(level, batch, conv_mode):
     """BASELINE.json's shapes against the ORACLE (not against another HIP path): the headline level 5 (2x128x128; batch 2 -- the
-    critic then runs on 6 images, every kernel on the tiling it uses at batch 64) and configs[1] in full (level 4, 2x64x64,
-    batch 32), through the product's training path -- ProGANStepper's fused critic step and its generator step: generated
+    critic then runs on 6 images, every kernel on the tiling it uses at batch 64 -- and batch 16: 48 images through the critic),
+    configs[1] in full (level 4, 2x64x64, batch 32), and the levels the reference trains at (6 and 7, 2x256x256 / 2x512x512,
+    one image: the few-channel tilings that only exist there -- wino3x3_mfma<1,1,2> / <1,3,2>, wino3x3_strip, the narrow
+    weight-gradient kernels; reference shapes generator.py:67-76, discriminator.py:60-70), through the product's training path -- ProGANStepper's fused critic step and its generator step: generated
     images, critic scores' means, both losses, the penalty, every critic gradient and every generator gradient."""
     import bench
     from musicgan_amd.optim import FusedAdam
