@@ -107,17 +107,23 @@ __global__ void __launch_bounds__(64 * NWAVE, 1) wino3x3_strip(const WinoArgs a)
   int bx = first % a.blocks_x, gy = (first / a.blocks_x) % groups_y, n0 = first / (a.blocks_x * groups_y);
   int item = first;
   int by = gy * NWAVE + wave;  // = tile row of this wave's block
+  auto step = [&](int& item_, int& bx_, int& gy_, int& n_) __attribute__((always_inline)) {
+    item_ += G;
+    bx_ += dbx;
+    const int c1 = bx_ >= a.blocks_x ? 1 : 0;
+    bx_ -= c1 * a.blocks_x;
+    gy_ += dgy + c1;
+    const int c2 = gy_ >= groups_y ? 1 : 0;
+    gy_ -= c2 * groups_y;
+    n_ += dn + c2;
+  };
   auto advance = [&]() __attribute__((always_inline)) {
-    item += G;
-    bx += dbx;
-    const int c1 = bx >= a.blocks_x ? 1 : 0;
-    bx -= c1 * a.blocks_x;
-    gy += dgy + c1;
-    const int c2 = gy >= groups_y ? 1 : 0;
-    gy -= c2 * groups_y;
-    n0 += dn + c2;
+    step(item, bx, gy, n0);
     by = gy * NWAVE + wave;
   };
+  // (Measured and not kept: a second walker two blocks ahead pulling that block's two new rows into the L2 with 16-byte loads nobody
+  // waits for -- +3 % on 16 -> 32 @512, +15 % on the 32 -> 16 data gradient: what the memory system costs these launches is not
+  // the latency of L2 misses, profiles/r05_ab_wino_strip.txt.)
 
   // input rows: lane part = own pixel pair of channel 2 rq; the halo pixels one float to the left / right.  Rows outside the image
   // (uniform per wave: the first row of tile row 0, the last of tile row Ht - 1, everything of a tile row beyond the image) are read
@@ -137,7 +143,7 @@ __global__ void __launch_bounds__(64 * NWAVE, 1) wino3x3_strip(const WinoArgs a)
     for (int r = 0; r < 4; ++r) {
       const int Y = 2 * by - 1 + r;
       rowoff[r] = Y * a.W * 4;
-      rowrec[r] = (item < nitems && Y >= 0 && Y < a.H) ? a.Cin * HW * 4 : 0;  // (behind the last segment: nothing is fetched)
+      rowrec[r] = (item < nitems && Y >= 0 && Y < a.H && !(a.TBN & 2)) ? a.Cin * HW * 4 : 0;  // (behind the last item: nothing is fetched)
     }
   };
 
@@ -315,7 +321,7 @@ __global__ void __launch_bounds__(64 * NWAVE, 1) wino3x3_strip(const WinoArgs a)
       const int W4 = a.W * 4;
       auto rs = [&](const void* base, size_t img_elems, int esize) __attribute__((always_inline)) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base)) + (size_t)en0 * img_elems * esize,
-                                                 0, (int)(img_elems * esize), 0x00020000);
+                                                 0, (a.TBN & 4) ? 0 : (int)(img_elems * esize), 0x00020000);
       };
       const size_t full = (size_t)a.Cout * HW, pooled_n = (size_t)a.Cout * PP;
       auto store_rows = [&](__amdgpu_buffer_rsrc_t r, const f32x4 (&r4)[4], int ni) __attribute__((always_inline)) {
@@ -612,6 +618,12 @@ int mgi_wino_strip_run(WinoArgs& a, hipStream_t s) {
   a.nchunk = a.Cin / WCC;
   a.NT = pack_wino_nt_padded(a.Cout);
   a.TBW = 16; a.TBH = 1; a.TBN = 1; a.lgTBW = 4; a.lgTBH = 0;
+  {
+    // measurement switch (ablation): 2 = every input row through a zero-record descriptor (reads return 0, nothing is fetched),
+    // 4 = every epilogue access likewise (stores dropped, masks read as 0), 6 = both: what is left is issue time
+    const char* e = getenv("MG_WINO_STRIP_ABLATE");
+    if (e != nullptr) a.TBN |= atoi(e) & 6;
+  }
   a.blocks_x = a.W / 32; a.blocks_y = a.H / 2; a.blocks_n = a.N;
   // out-channel tiles per wave: all of them (NIW = nt: the input transform is done once) or ONE with the tiles on grid.y (half
   // the registers, twice the waves per SIMD, the input read and transformed once per tile); PixelNorm needs all channels in a wave
