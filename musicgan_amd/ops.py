@@ -107,7 +107,9 @@ def wino3x3_supported(n: int, cout: int, h: int, w: int, *, ups=False, pixnorm=F
     tiles = (h // 2) * (w // 2)
     if max(cin, cout, 1) * h * w * max(1, 64 // max(tiles, 1)) >= (1 << 29):  # images per 64-tile block x one image's planes
         return False
-    return n * h * w >= int(os.environ.get("MG_WINO_MIN_PIXELS", "8192"))  # fewer 2x2 tiles do not fill the chip
+    # fewer 2x2 tiles do not fill the chip (r05 sweep 8192 / 4096 / 2048: level 3 batch 8 1.381 / 1.360 / 1.372 ms, level 4 batch 32
+    # 3.843 / 3.826 / 3.832, levels 6-7 unchanged: the 16x16 layers of 24 images move from the direct kernel to this one)
+    return n * h * w >= int(os.environ.get("MG_WINO_MIN_PIXELS", "4096"))
 
 
 def _chk_tilemask(m, shape):
