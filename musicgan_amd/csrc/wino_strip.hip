@@ -362,6 +362,7 @@ __global__ void __launch_bounds__(64 * NWAVE, 1) wino3x3_strip(const WinoArgs a)
         const auto rp = rs(a.p, pooled_n, 4), rm = rs(a.mo, pooled_n, 1);
 #pragma unroll
         for (int ni = 0; ni < NIW; ++ni) {
+          if ((ct0 + ni) * 16 >= a.Cout) continue;  // (a padding tile of the last workgroup row: zero filters, nothing to write)
           f32x4 r4[4];
           xform(ni, r4);
           activate(ni, r4);
@@ -372,6 +373,7 @@ __global__ void __launch_bounds__(64 * NWAVE, 1) wino3x3_strip(const WinoArgs a)
         const auto rp = rs(a.p, pooled_n, 4), rm = rs(a.mi, pooled_n, 1);
 #pragma unroll
         for (int ni = 0; ni < NIW; ++ni) {
+          if ((ct0 + ni) * 16 >= a.Cout) continue;  // (a padding tile of the last workgroup row: zero filters, nothing to write)
           unsigned mb[4];
           load_mask_bytes(rm, mb, ni);
           f32x4 r4[4];
@@ -384,6 +386,7 @@ __global__ void __launch_bounds__(64 * NWAVE, 1) wino3x3_strip(const WinoArgs a)
         const auto ry = rs(a.y, full, 4), rp = rs(a.p, pooled_n, 4);
 #pragma unroll
         for (int ni = 0; ni < NIW; ++ni) {
+          if ((ct0 + ni) * 16 >= a.Cout) continue;  // (a padding tile of the last workgroup row: zero filters, nothing to write)
           f32x4 r4[4];
           xform(ni, r4);
           activate(ni, r4);
@@ -394,6 +397,7 @@ __global__ void __launch_bounds__(64 * NWAVE, 1) wino3x3_strip(const WinoArgs a)
         const auto ry = rs(a.y, full, 4), rx = rs(a.aux, full, 4), rp = rs(a.p, pooled_n, 4);
 #pragma unroll
         for (int ni = 0; ni < NIW; ++ni) {
+          if ((ct0 + ni) * 16 >= a.Cout) continue;  // (a padding tile of the last workgroup row: zero filters, nothing to write)
           f32x4 ax[4];
           load_rows_f(rx, ax, ni);
           f32x4 r4[4];
@@ -417,6 +421,7 @@ __global__ void __launch_bounds__(64 * NWAVE, 1) wino3x3_strip(const WinoArgs a)
         const float qh = 0.25f, ql = 0.25f * slope;
 #pragma unroll
         for (int ni = 0; ni < NIW; ++ni) {
+          if ((ct0 + ni) * 16 >= a.Cout) continue;  // (a padding tile of the last workgroup row: zero filters, nothing to write)
           unsigned mw[4][2];
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4)
@@ -454,6 +459,7 @@ __global__ void __launch_bounds__(64 * NWAVE, 1) wino3x3_strip(const WinoArgs a)
         const float bca = a.coef[0], bcb = a.coef[1];
 #pragma unroll
         for (int ni = 0; ni < NIW; ++ni) {
+          if ((ct0 + ni) * 16 >= a.Cout) continue;  // (a padding tile of the last workgroup row: zero filters, nothing to write)
           f32x4 o4[4];
           load_rows_f(ro, o4, ni);
           unsigned mb[4] = {15u, 15u, 15u, 15u};
@@ -473,6 +479,7 @@ __global__ void __launch_bounds__(64 * NWAVE, 1) wino3x3_strip(const WinoArgs a)
         const float ca = a.coef[0], cb = a.coef[1];
 #pragma unroll
         for (int ni = 0; ni < NIW; ++ni) {
+          if ((ct0 + ni) * 16 >= a.Cout) continue;  // (a padding tile of the last workgroup row: zero filters, nothing to write)
           f32x4 o4[4];
           load_rows_f(ro, o4, ni);
           unsigned mb[4];
@@ -578,6 +585,33 @@ int launch_strip_kind(const WinoArgs& a, int kind, dim3 grid, hipStream_t s) {
   }
 }
 
+// Out-channel tiles per wave for a layer of nt tiles, or 0 = leave the call to wino3x3.hip.  Two wherever there are two or more (128
+// accumulators, two waves per SIMD; further tile pairs go to further workgroup rows, grid.y, which read and transform the input
+// again; an odd count ends in a padding tile of zero filters), one for 16 out-channels, three (192 accumulators, one wave per SIMD)
+// for exactly 48 channels with pooled outputs.  The choice follows tools/ab_wino_strip.py (profiles/r05_ab_wino_strip.txt), us per
+// launch against wino3x3.hip:  32 channels 0.72-0.92 from ~4 000 tile blocks on;  64 channels (the dominant launches of level 5:
+// 48->64 @128 x 192 images 929 -> 782) 0.81-0.94 and 80 / 96 channels 0.89-0.97 from ~4 000 blocks on;  48 channels 0.86 with
+// pooled outputs (three tiles per wave) and 0.91 with the un-pooling epilogue, 0.98-1.01 otherwise: not taken;  16 channels (the
+// 32 -> 16 data gradient) 1.03-1.06: not taken.  `force` (MG_WINO_STRIP=2: tests, A/B): whatever the shape allows.
+// MG_WINO_STRIP_NIW (1 / 2 / 3) overrides the tile count per wave (measurements).
+int strip_plan(const WinoArgs& a, bool pn, bool force) {
+  const int nt = a.Cout / 16;
+  const long long blocks = (long long)a.N * (a.H / 2) * (a.W / 32);
+  const bool pooled_only = (a.flags & MG_CONV_MASK_OUT) || ((a.flags & MG_CONV_MASK_BYTES) && !(a.flags & WF_BLEND));
+  int niw = 0;
+  if (nt == 1) niw = force ? 1 : 0;
+  else if (nt == 2) niw = (force || blocks >= 4096) ? 2 : 0;
+  else if (nt == 3) niw = (pooled_only && blocks >= 16384) ? 3 : ((force || ((a.flags & MG_CONV_UNPOOL) && blocks >= 4096)) ? 2 : 0);
+  else niw = (force || blocks >= 4096) ? 2 : 0;
+  if (pn) niw = nt <= 2 ? (niw ? nt : 0) : 0;  // PixelNorm: all channels of a pixel in one wave
+  const char* e = getenv("MG_WINO_STRIP_NIW");
+  if (e != nullptr && !pn && niw != 0) {
+    const int v = atoi(e);
+    if (v == 1 || (v == 2 && nt >= 2) || (v == 3 && nt == 3)) niw = v;
+  }
+  return niw;
+}
+
 int strip_kind(const WinoArgs& a) {  // the dispatch of wino_epilogue.h, by name
   if (a.flags & MG_CONV_PIXNORM) return SK_PN;
   if (a.flags & MG_CONV_UNPOOL) return SK_UNPOOL;
@@ -589,28 +623,19 @@ int strip_kind(const WinoArgs& a) {  // the dispatch of wino_epilogue.h, by name
 
 }  // namespace
 
-// Whether wino_run (wino3x3.hip) hands this call to the strip kernel.  Shape: whole 16-channel chunk pairs, whole 16-channel out tiles (at
-// most three), whole 16-tile blocks per tile row, whole groups of 8 tile rows, the filter bank within LDS, every plane within 32-bit
-// byte offsets, masked kinds bias-free, PixelNorm without y.  Choice (tools/ab_wino_strip.py, profiles/r05_ab_wino_strip.txt): two
-// out-channel tiles -- 32 channels, both in one wave at two waves per SIMD -- are 8-28 % ahead of wino3x3.hip from ~4 000 tile
-// blocks on; three tiles (192 accumulators, one wave per SIMD) only where the outputs are pooled (1/4 of the stores) and every wave
-// walks many blocks; one tile (16 out-channels: the 32 -> 16 data gradient) is memory-latency-bound in both kernels and stays.
-// MG_WINO_STRIP=0: never; =2: whenever the shape allows (tests, A/B).
+// Whether wino_run (wino3x3.hip) hands this call to the strip kernel.  Shape: whole 16-channel chunk pairs and out tiles, whole 16-tile
+// blocks per tile row, whole groups of 8 tile rows, the filter bank of a workgroup's tiles within LDS, every plane within 32-bit byte
+// offsets, masked kinds bias-free, PixelNorm without y; then strip_plan's choice.  MG_WINO_STRIP=0: never; =2: whenever the shape allows.
 bool mgi_wino_strip_takes(const WinoArgs& a, bool pn) {
   const char* e = getenv("MG_WINO_STRIP");
   if (e != nullptr && atoi(e) == 0) return false;
   const int nt = a.Cout / 16;
-  if ((a.Cin % 16) != 0 || (a.Cout % 16) != 0 || nt > 3 || (a.W % 32) != 0 || ((a.H / 2) % 8) != 0 || (a.H % 2) != 0) return false;
+  if ((a.Cin % 16) != 0 || (a.Cout % 16) != 0 || nt > 10 || (a.W % 32) != 0 || ((a.H / 2) % 8) != 0 || (a.H % 2) != 0) return false;
   if (pn && (nt > 2 || a.y != nullptr)) return false;  // (PixelNorm: all channels of a pixel in one wave, p and rn only)
   if ((a.flags & (MG_CONV_MASK_AUX | MG_CONV_UNPOOL | WF_BLEND_BWD)) && a.bias != nullptr) return false;  // masked kinds: bias-free
-  if ((size_t)(a.Cin / WCC) * nt * 8192 > 160 * 1024) return false;
   if ((long long)a.Cout * a.H * a.W * 16 >= (1ll << 31) || (long long)a.Cin * a.H * a.W * 4 >= (1ll << 31)) return false;
-  if (e != nullptr && atoi(e) > 1) return true;
-  const long long blocks = (long long)a.N * (a.H / 2) * (a.W / 32);
-  if (nt == 2) return blocks >= 4096;
-  const bool pooled_only = (a.flags & MG_CONV_MASK_OUT) || ((a.flags & MG_CONV_MASK_BYTES) && !(a.flags & WF_BLEND));
-  if (nt == 3) return pooled_only && blocks >= 16384;
-  return false;
+  const int niw = strip_plan(a, pn, e != nullptr && atoi(e) > 1);
+  return niw != 0 && (size_t)(a.Cin / WCC) * niw * 8192 <= 160 * 1024;  // the filter bank of a workgroup's tiles fits LDS
 }
 
 int mgi_wino_strip_run(WinoArgs& a, hipStream_t s) {
@@ -628,12 +653,9 @@ int mgi_wino_strip_run(WinoArgs& a, hipStream_t s) {
   // out-channel tiles per wave: all of them (NIW = nt: the input transform is done once) or ONE with the tiles on grid.y (half
   // the registers, twice the waves per SIMD, the input read and transformed once per tile); PixelNorm needs all channels in a wave
   const int kind = strip_kind(a);
-  int niw = nt;
-  {
-    const char* e = getenv("MG_WINO_STRIP_NIW");  // measurement switch
-    if (e != nullptr && atoi(e) == 1 && kind != SK_PN) niw = 1;
-  }
-  dim3 grid(1, nt / niw);
+  const char* e = getenv("MG_WINO_STRIP");
+  const int niw = strip_plan(a, kind == SK_PN, e != nullptr && atoi(e) > 1);
+  dim3 grid(1, mg_cdiv(nt, niw));  // (an odd tile count: the last workgroup row carries one padding tile of zero filters)
   switch (niw) {
     case 1: return launch_strip_kind<1, 8>(a, kind, grid, s);
     case 2: return launch_strip_kind<2, 8>(a, kind, grid, s);

@@ -58,16 +58,24 @@ cases = [(18, 16, 32, 512, "fwd_pool_mask"), (6, 16, 32, 512, "tangent"), (18, 3
          (4, 16, 16, 64, "plain"), (3, 8, 48, 96, "pn"), (5, 24, 32, 64, "unpool")]
 if len(sys.argv) > 1 and sys.argv[1] == "quick":
     cases = cases[:4]
+if len(sys.argv) > 1 and sys.argv[1] == "odd":  # three, five and six out-channel tiles: two per wave + a padding tile, or three per wave
+    cases = [(192, 64, 48, 128, "dgrad_mask"), (18, 32, 48, 256, "fwd_pool_mask"), (18, 32, 48, 256, "plain"), (18, 48, 48, 128, "unpool"),
+             (192, 64, 80, 64, "fwd_pool_mask"), (64, 64, 80, 64, "tangent"), (192, 80, 64, 64, "unpool"), (192, 80, 80, 32, "plain"),
+             (192, 80, 96, 32, "fwd_pool_mask"), (18, 64, 48, 128, "fade_bwd"), (18, 64, 80, 64, "fwd_pool_mask")]
+if len(sys.argv) > 1 and sys.argv[1] == "l5":  # the 64-out-channel layers of level 5 at batch 64 (192 images through the critic)
+    cases = [(192, 48, 64, 128, "fwd_pool_mask"), (64, 48, 64, 128, "tangent"), (192, 64, 48, 128, "dgrad_mask"), (192, 64, 64, 64, "fade_fwd"),
+             (192, 64, 64, 64, "unpool"), (64, 48, 64, 128, "fwd_pool_mask"), (192, 64, 64, 64, "plain"), (192, 64, 80, 64, "fwd_pool_mask"),
+             (192, 80, 64, 64, "unpool")]
 # variants: "0" the staged kernel; "2" strip, all out-channel tiles in a wave; "2n1" strip, one tile per wave (tiles on grid.y)
-VARIANTS = ["0", "2", "2n1"] + [v for v in sys.argv[1:] if v.startswith("2")]
+VARIANTS = ["0", "2"] + [v for v in sys.argv[1:] if v.startswith("2")]
 
 
 def setenv(v):
     os.environ["MG_WINO_STRIP"] = v[0]
     for k in ("MG_WINO_STRIP_NIW", "MG_WINO_STRIP_WGS"):
         os.environ.pop(k, None)
-    if "n1" in v:
-        os.environ["MG_WINO_STRIP_NIW"] = "1"
+    if "n" in v:
+        os.environ["MG_WINO_STRIP_NIW"] = v[v.index("n") + 1]
     if "w" in v:
         os.environ["MG_WINO_STRIP_WGS"] = v[v.index("w") + 1]
 
