@@ -114,8 +114,8 @@ def executed_flops_per_image(level: int, rand_channels: int, batch: int) -> floa
 
 def dominant_kernel_probe(device, batch: int, iters: int = 10):
     """Time the dominant kernel of the step -- the first discriminator conv 48->64 @128x128 + LeakyReLU + fused AvgPool2d over the
-    fused critic step's batch [real|fake|interpolated] = 3*batch images, Winograd F(2x2,3x3) kernel wino3x3_mfma<2,2,4> (173.9
-    algorithmic GFLOP at batch 64) -- with HIP events on the stream it is launched on.  `tflops` is ALGORITHMIC (18*Cin*Cout FLOP
+    fused critic step's batch [real|fake|interpolated] = 3*batch images, Winograd F(2x2,3x3) kernel wino3x3_strip<2,8,ACT_POOL_MOUT>
+    (csrc/wino_strip.hip; rounds 1-4: wino3x3_mfma<2,2,4>) (173.9 algorithmic GFLOP at batch 64) -- with HIP events on the stream it is launched on.  `tflops` is ALGORITHMIC (18*Cin*Cout FLOP
     per output pixel, the direct-convolution count the roofline is defined on); the kernel executes 2.25x fewer multiplies."""
     from musicgan_amd import ops
     g = torch.Generator(device=device).manual_seed(1)
@@ -138,7 +138,7 @@ def dominant_kernel_probe(device, batch: int, iters: int = 10):
     e1.synchronize()
     ms = e0.elapsed_time(e1) / iters
     flop = 2.0 * 9 * 48 * 64 * 128 * 128 * n
-    out = {"name": "wino3x3_mfma<2,2,4> Winograd F(2x2,3x3) conv 48->64@128x128 + lrelu + avgpool + tile mask, 3x batch", "ms": ms,
+    out = {"name": "wino3x3_strip<2,8,ACT_POOL_MOUT> Winograd F(2x2,3x3) conv 48->64@128x128 + lrelu + avgpool + tile mask, 3x batch", "ms": ms,
            "flop": flop, "tflops": flop / ms / 1e9, "executed_tflops": flop / 2.25 / ms / 1e9,
            "algorithmic_bytes": n * (4.0 * 48 * 128 * 128 + 4.0 * 64 * 64 * 64 + 1.0 * 64 * 64 * 64)}
     # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), measured by tools/measure_traffic.sh

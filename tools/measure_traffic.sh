@@ -18,7 +18,7 @@ import csv, glob, json, sys
 R, CASE = sys.argv[1], sys.argv[2]
 T = 1 + 44100 * 600 // 256
 CASES = {
-    "wino3n": ("traffic_dominant_kernel.json", [("wino3x3_mfma", "wino3x3_mfma<2,2,4> lrelu+avgpool+tile mask 48->64@128x128, 192 images (pooled y and mask bytes written)",
+    "wino3n": ("traffic_dominant_kernel.json", [("wino3x3_strip", "wino3x3_strip<2,8,ACT_POOL_MOUT> lrelu+avgpool+tile mask 48->64@128x128, 192 images (pooled y and mask bytes written; two workgroup rows of 32 out-channels each read the input)",
                 192 * (4.0 * 48 * 128 * 128 + 4.0 * 64 * 64 * 64 + 1.0 * 64 * 64 * 64))]),
     "stft": ("traffic_stft_kernel.json", [("stft1024_kernel", "stft1024_kernel, one 10-minute mono 44.1 kHz file (103 360 frames)", 5120.0 * T)]),
     "codec": ("traffic_codec_kernels.json", [("codec_row_pass", "codec_row_pass, 512 x 103 360 bins: 8 B in + 8 B (raw images) out per bin", 16.0 * 512 * T),

@@ -24,7 +24,7 @@ if [ "$2" != "steps-only" ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/dom -- python3 $R/tools/prof_one.py wino3n 300 > /dev/null 2>&1 || exit 1
   cp $R/gpurun_out/dom/*/*kernel_stats.csv $R/gpurun_out/${TAG}_dominant_kernel_wino3n_stats.csv
   rm -rf $R/gpurun_out/dom
-  cd $R && bash tools/pmc_wino.sh wino3n wino3x3_mfma > gpurun_out/${TAG}_pmc_sq_counters_wino3n.txt 2>&1
+  cd $R && bash tools/pmc_wino.sh wino3n wino3x3_strip > gpurun_out/${TAG}_pmc_sq_counters_wino3n.txt 2>&1
   bash tools/measure_traffic.sh wino3n | tail -1
   bash tools/measure_traffic.sh stft | tail -1
   bash tools/measure_traffic.sh codec | tail -1
