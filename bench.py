@@ -112,7 +112,7 @@ def executed_flops_per_image(level: int, rand_channels: int, batch: int) -> floa
     return (d_step + g_step) / n
 
 
-def dominant_kernel_probe(device, batch: int, iters: int = 10):
+def dominant_kernel_probe(device, batch: int, iters: int = 100):
     """Time the dominant kernel of the step -- the first discriminator conv 48->64 @128x128 + LeakyReLU + fused AvgPool2d over the
     fused critic step's batch [real|fake|interpolated] = 3*batch images, Winograd F(2x2,3x3) kernel wino3x3_strip<2,8,ACT_POOL_MOUT>
     (csrc/wino_strip.hip; rounds 1-4: wino3x3_mfma<2,2,4>) (173.9 algorithmic GFLOP at batch 64) -- with HIP events on the stream it is launched on.  `tflops` is ALGORITHMIC (18*Cin*Cout FLOP
@@ -127,7 +127,7 @@ def dominant_kernel_probe(device, batch: int, iters: int = 10):
     q = torch.empty(n, 64, 64, 64, device=device)
     # as engine.disc_forward calls it: pooled result + one sign byte per 2x2 tile (the full-resolution activation is not written)
     fn = lambda: ops.conv3x3(x, None, b, 64, lrelu=True, pool_out=q, wino=up, mask_out=True)
-    for _ in range(2):
+    for _ in range(30):  # (the first launches after host-side work run 10-25 % slow: 989 us max against 783 avg of 300 in the profile)
         fn()
     stream = torch.cuda.current_stream()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
