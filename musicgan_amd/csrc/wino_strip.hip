@@ -66,8 +66,11 @@ __device__ __forceinline__ float sel_bits(int t, float x, float y) {
 // run-time branch the block loop has a control-flow join behind stores whose number the compiler cannot count, and gfx9 has ONE
 // counter for loads and stores -- it then waits `vmcnt(0)` for the next block's prefetched rows, i.e. for the previous block's
 // stores to be acknowledged (measured: every wave 57 % of its time in s_waitcnt).  One straight-line loop per kind instead.
-template <int NIW, int NWAVE, int KIND, bool POOL>
-__global__ void __launch_bounds__(64 * NWAVE, 1) wino3x3_strip(const WinoArgs a) {
+// The body of a workgroup: NIW = out-channel tiles this workgroup computes (accumulators, MFMAs, epilogue), NLDS = tiles per chunk in
+// its LDS filter image (>= NIW: a row whose second tile is padding keeps the two-tile image and computes one), ct0 = its first tile,
+// wg / G = its index among / the number of the workgroups that share its tiles (they walk all tile blocks with stride G).
+template <int NIW, int NLDS, int NWAVE, int KIND, bool POOL>
+__device__ __forceinline__ void strip_body(const WinoArgs& a, const int ct0, const int wg, const int G) {
   constexpr int kind = KIND;
   constexpr int NTHR = 64 * NWAVE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -75,17 +78,16 @@ __global__ void __launch_bounds__(64 * NWAVE, 1) wino3x3_strip(const WinoArgs a)
   const int tid = threadIdx.x;
   const int lane = tid & 63, col = lane & 15, rq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ct0 = blockIdx.y * NIW;
   const int HW = a.H * a.W;
   const int Ht = a.H >> 1, Wt = a.W >> 1;
   const int PP = Ht * Wt;  // one pooled plane
 
   {  // the filter bank of this workgroup's out-channels, once
-    const int n4 = a.nchunk * NIW * 512;  // 16-byte pieces
+    const int n4 = a.nchunk * NLDS * 512;  // 16-byte pieces
     const f32x4* src = reinterpret_cast<const f32x4*>(a.up);
     f32x4* dst = reinterpret_cast<f32x4*>(Us);
     for (int i = tid; i < n4; i += NTHR) {
-      const int ch = i / (NIW * 512), r = i - ch * (NIW * 512);
+      const int ch = i / (NLDS * 512), r = i - ch * (NLDS * 512);
       dst[i] = src[((size_t)ch * a.NT + ct0) * 512 + r];
     }
   }
@@ -100,8 +102,7 @@ __global__ void __launch_bounds__(64 * NWAVE, 1) wino3x3_strip(const WinoArgs a)
   // 4 MB L2 of the XCD: rocprofv3 FETCH_SIZE 2.5x the input instead of 1.7x, 32 -> 16 @512 x 18 images, and 15 % slower.)
   const int groups_y = Ht / NWAVE;
   const int nitems = a.N * groups_y * a.blocks_x;
-  const int G = (int)gridDim.x;
-  const int first = mg_xcd_remap((int)blockIdx.x, G);
+  const int first = mg_xcd_remap(wg, G);  // (row sizes are multiples of 8: workgroup wg of a row sits on XCD wg % 8)
   if (first >= nitems) return;
   const int dbx = G % a.blocks_x, dgy = (G / a.blocks_x) % groups_y, dn = G / (a.blocks_x * groups_y);
   int bx = first % a.blocks_x, gy = (first / a.blocks_x) % groups_y, n0 = first / (a.blocks_x * groups_y);
@@ -190,7 +191,7 @@ __global__ void __launch_bounds__(64 * NWAVE, 1) wino3x3_strip(const WinoArgs a)
   // `first_`: the block's first chunk starts its sums from the zero constant (no 64 x NIW register clears per block)
   auto mfma_chunk = [&](int ch, auto first_) __attribute__((always_inline)) {
     constexpr bool FIRST = decltype(first_)::value;
-    const float* ub = Us + (ch * NIW) * 2048 + lane * 4;
+    const float* ub = Us + (ch * NLDS) * 2048 + lane * 4;
     f32x4 bv[2][NIW];
 #pragma unroll
     for (int ni = 0; ni < NIW; ++ni) bv[0][ni] = *reinterpret_cast<const f32x4*>(ub + ni * 2048);
@@ -362,7 +363,6 @@ __global__ void __launch_bounds__(64 * NWAVE, 1) wino3x3_strip(const WinoArgs a)
         const auto rp = rs(a.p, pooled_n, 4), rm = rs(a.mo, pooled_n, 1);
 #pragma unroll
         for (int ni = 0; ni < NIW; ++ni) {
-          if ((ct0 + ni) * 16 >= a.Cout) continue;  // (a padding tile of the last workgroup row: zero filters, nothing to write)
           f32x4 r4[4];
           xform(ni, r4);
           activate(ni, r4);
@@ -373,7 +373,6 @@ __global__ void __launch_bounds__(64 * NWAVE, 1) wino3x3_strip(const WinoArgs a)
         const auto rp = rs(a.p, pooled_n, 4), rm = rs(a.mi, pooled_n, 1);
 #pragma unroll
         for (int ni = 0; ni < NIW; ++ni) {
-          if ((ct0 + ni) * 16 >= a.Cout) continue;  // (a padding tile of the last workgroup row: zero filters, nothing to write)
           unsigned mb[4];
           load_mask_bytes(rm, mb, ni);
           f32x4 r4[4];
@@ -386,7 +385,6 @@ __global__ void __launch_bounds__(64 * NWAVE, 1) wino3x3_strip(const WinoArgs a)
         const auto ry = rs(a.y, full, 4), rp = rs(a.p, pooled_n, 4);
 #pragma unroll
         for (int ni = 0; ni < NIW; ++ni) {
-          if ((ct0 + ni) * 16 >= a.Cout) continue;  // (a padding tile of the last workgroup row: zero filters, nothing to write)
           f32x4 r4[4];
           xform(ni, r4);
           activate(ni, r4);
@@ -397,7 +395,6 @@ __global__ void __launch_bounds__(64 * NWAVE, 1) wino3x3_strip(const WinoArgs a)
         const auto ry = rs(a.y, full, 4), rx = rs(a.aux, full, 4), rp = rs(a.p, pooled_n, 4);
 #pragma unroll
         for (int ni = 0; ni < NIW; ++ni) {
-          if ((ct0 + ni) * 16 >= a.Cout) continue;  // (a padding tile of the last workgroup row: zero filters, nothing to write)
           f32x4 ax[4];
           load_rows_f(rx, ax, ni);
           f32x4 r4[4];
@@ -421,7 +418,6 @@ __global__ void __launch_bounds__(64 * NWAVE, 1) wino3x3_strip(const WinoArgs a)
         const float qh = 0.25f, ql = 0.25f * slope;
 #pragma unroll
         for (int ni = 0; ni < NIW; ++ni) {
-          if ((ct0 + ni) * 16 >= a.Cout) continue;  // (a padding tile of the last workgroup row: zero filters, nothing to write)
           unsigned mw[4][2];
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4)
@@ -459,7 +455,6 @@ __global__ void __launch_bounds__(64 * NWAVE, 1) wino3x3_strip(const WinoArgs a)
         const float bca = a.coef[0], bcb = a.coef[1];
 #pragma unroll
         for (int ni = 0; ni < NIW; ++ni) {
-          if ((ct0 + ni) * 16 >= a.Cout) continue;  // (a padding tile of the last workgroup row: zero filters, nothing to write)
           f32x4 o4[4];
           load_rows_f(ro, o4, ni);
           unsigned mb[4] = {15u, 15u, 15u, 15u};
@@ -479,7 +474,6 @@ __global__ void __launch_bounds__(64 * NWAVE, 1) wino3x3_strip(const WinoArgs a)
         const float ca = a.coef[0], cb = a.coef[1];
 #pragma unroll
         for (int ni = 0; ni < NIW; ++ni) {
-          if ((ct0 + ni) * 16 >= a.Cout) continue;  // (a padding tile of the last workgroup row: zero filters, nothing to write)
           f32x4 o4[4];
           load_rows_f(ro, o4, ni);
           unsigned mb[4];
@@ -540,6 +534,19 @@ __global__ void __launch_bounds__(64 * NWAVE, 1) wino3x3_strip(const WinoArgs a)
   }
 }
 
+// Workgroup rows: row r owns out-channel tiles r * NIW .. r * NIW + NIW - 1 and walks ALL tile blocks.  The grid is one-dimensional, rows
+// one after the other: a.TBW workgroups per full row, a.TBH for the last row when its second tile is a padding tile (an odd tile
+// count) -- that row runs the ONE-tile body on the two-tile filter image (no MFMAs, no epilogue for the padding tile) and gets fewer
+// workgroups, in proportion to its work.
+template <int NIW, int NWAVE, int KIND, bool POOL>
+__global__ void __launch_bounds__(64 * NWAVE, 1) wino3x3_strip(const WinoArgs a) {
+  const int g_full = a.TBW, g_pad = a.TBH, nrows = a.lgTBW;
+  const int row = ((int)blockIdx.x < (nrows - (g_pad ? 1 : 0)) * g_full) ? (int)blockIdx.x / g_full : nrows - 1;
+  const int wg = (int)blockIdx.x - row * g_full;
+  if (NIW == 2 && g_pad != 0 && row == nrows - 1) strip_body<1, NIW, NWAVE, KIND, POOL>(a, row * NIW, wg, g_pad);
+  else strip_body<NIW, NIW, NWAVE, KIND, POOL>(a, row * NIW, wg, g_full);
+}
+
 template <int NIW, int NWAVE, int KIND, bool POOL>
 int launch_strip(const WinoArgs& a, dim3 grid, hipStream_t s) {
   const size_t lds = (size_t)a.nchunk * NIW * 2048 * sizeof(float);
@@ -555,13 +562,29 @@ int launch_strip(const WinoArgs& a, dim3 grid, hipStream_t s) {
     const char* e = getenv("MG_WINO_STRIP_WGS");  // measurement switch: workgroups per CU
     if (e != nullptr && atoi(e) >= 1) per_cu = atoi(e);
   }
-  int gx = (per_cu * mg_cu_count()) / (int)grid.y;
-  if (gx >= 8) gx &= ~7;  // (workgroups x and x + 8 share an XCD: the tiles' other out-channels, on grid.y, then do too)
+  // rows of workgroups (grid.y of the caller = number of rows) laid out in a 1-D grid; a last row whose second tile is padding does
+  // ~0.7 of a full row's work (half the MFMAs and epilogue, the same input loads and transform; swept 0.6 .. 1.0 on 64->48@128,
+  // 64->80@64, 48->48@128: 0.7) and gets that share of the workgroups
+  const int rows = (int)grid.y, nt = a.Cout / 16;
+  const bool has_pad = NIW == 2 && (nt & 1) != 0 && rows > 1;
+  const int total = per_cu * mg_cu_count();
+  static const double pad_w = getenv("MG_WINO_STRIP_PADW") ? atof(getenv("MG_WINO_STRIP_PADW")) : 0.7;
+  int g_pad = 0, g_full;
+  if (has_pad) {
+    g_pad = (int)(total * pad_w / ((rows - 1) + pad_w)) & ~7;
+    if (g_pad < 8) g_pad = 8;
+    g_full = ((total - g_pad) / (rows - 1)) & ~7;
+  } else {
+    g_full = (total / rows) & ~7;
+  }
+  if (g_full < 8) g_full = 8;
   const int nitems = a.N * (a.blocks_y / NWAVE) * a.blocks_x;
-  if (gx > nitems) gx = nitems;
-  if (gx < 1) gx = 1;
-  grid.x = gx;
-  hipLaunchKernelGGL((wino3x3_strip<NIW, NWAVE, KIND, POOL>), grid, dim3(64 * NWAVE), lds, s, a);
+  if (g_full > nitems) g_full = nitems;  // (small launches: fewer workgroups than CUs; the XCD mapping then is whatever it is)
+  if (g_pad > nitems) g_pad = nitems;
+  WinoArgs b = a;
+  b.TBW = g_full; b.TBH = g_pad; b.lgTBW = rows;
+  grid = dim3((unsigned)((rows - (g_pad ? 1 : 0)) * g_full + g_pad), 1, 1);
+  hipLaunchKernelGGL((wino3x3_strip<NIW, NWAVE, KIND, POOL>), grid, dim3(64 * NWAVE), lds, s, b);
   MG_CHECK_LAUNCH("mg_wino3x3 (strip)");
   return MG_OK;
 }
@@ -586,22 +609,19 @@ int launch_strip_kind(const WinoArgs& a, int kind, dim3 grid, hipStream_t s) {
 }
 
 // Out-channel tiles per wave for a layer of nt tiles, or 0 = leave the call to wino3x3.hip.  Two wherever there are two or more (128
-// accumulators, two waves per SIMD; further tile pairs go to further workgroup rows, grid.y, which read and transform the input
-// again; an odd count ends in a padding tile of zero filters), one for 16 out-channels, three (192 accumulators, one wave per SIMD)
-// for exactly 48 channels with pooled outputs.  The choice follows tools/ab_wino_strip.py (profiles/r05_ab_wino_strip.txt), us per
-// launch against wino3x3.hip:  32 channels 0.72-0.92 from ~4 000 tile blocks on;  64 channels (the dominant launches of level 5:
-// 48->64 @128 x 192 images 929 -> 782) 0.81-0.94 and 80 / 96 channels 0.89-0.97 from ~4 000 blocks on;  48 channels 0.86 with
-// pooled outputs (three tiles per wave) and 0.91 with the un-pooling epilogue, 0.98-1.01 otherwise: not taken;  16 channels (the
-// 32 -> 16 data gradient) 1.03-1.06: not taken.  `force` (MG_WINO_STRIP=2: tests, A/B): whatever the shape allows.
-// MG_WINO_STRIP_NIW (1 / 2 / 3) overrides the tile count per wave (measurements).
+// accumulators, two waves per SIMD; further tile pairs go to further workgroup rows, which read and transform the input again; an odd
+// count ends in a row that computes ONE tile on the two-tile filter image and gets a smaller share of the grid), one for 16
+// out-channels.  The choice follows tools/ab_wino_strip.py (profiles/r05_ab_wino_strip.txt), us per launch against wino3x3.hip:
+// 32 channels 0.72-0.92;  64 channels (the dominant launches of level 5: 48->64 @128 x 192 images 929 -> 782) 0.81-0.94;  48 channels
+// 0.73-0.96 (64->48 @128 x 192, the largest launch of a level-5 step: 1016 -> 903);  80 / 96 channels 0.78-0.97 -- each from ~4 000
+// tile blocks on;  16 channels (the 32 -> 16 data gradient) 1.03-1.06: not taken.  `force` (MG_WINO_STRIP=2: tests, A/B): whatever
+// the shape allows.  MG_WINO_STRIP_NIW (1 / 2 / 3) overrides the tile count per wave (3: the 192-accumulator, one-wave-per-SIMD
+// form for exactly 48 channels; measurements).
 int strip_plan(const WinoArgs& a, bool pn, bool force) {
   const int nt = a.Cout / 16;
   const long long blocks = (long long)a.N * (a.H / 2) * (a.W / 32);
-  const bool pooled_only = (a.flags & MG_CONV_MASK_OUT) || ((a.flags & MG_CONV_MASK_BYTES) && !(a.flags & WF_BLEND));
   int niw = 0;
   if (nt == 1) niw = force ? 1 : 0;
-  else if (nt == 2) niw = (force || blocks >= 4096) ? 2 : 0;
-  else if (nt == 3) niw = (pooled_only && blocks >= 16384) ? 3 : ((force || ((a.flags & MG_CONV_UNPOOL) && blocks >= 4096)) ? 2 : 0);
   else niw = (force || blocks >= 4096) ? 2 : 0;
   if (pn) niw = nt <= 2 ? (niw ? nt : 0) : 0;  // PixelNorm: all channels of a pixel in one wave
   const char* e = getenv("MG_WINO_STRIP_NIW");

@@ -62,6 +62,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "odd":  # three, five and six out-channe
     cases = [(192, 64, 48, 128, "dgrad_mask"), (18, 32, 48, 256, "fwd_pool_mask"), (18, 32, 48, 256, "plain"), (18, 48, 48, 128, "unpool"),
              (192, 64, 80, 64, "fwd_pool_mask"), (64, 64, 80, 64, "tangent"), (192, 80, 64, 64, "unpool"), (192, 80, 80, 32, "plain"),
              (192, 80, 96, 32, "fwd_pool_mask"), (18, 64, 48, 128, "fade_bwd"), (18, 64, 80, 64, "fwd_pool_mask")]
+if len(sys.argv) > 1 and sys.argv[1] == "pad":  # odd tile counts at the sizes where the padded row's share of the grid matters
+    cases = [(192, 64, 48, 128, "dgrad_mask"), (18, 32, 48, 256, "plain"), (18, 48, 48, 128, "unpool"), (192, 64, 80, 64, "fwd_pool_mask"),
+             (18, 64, 48, 128, "fade_bwd"), (64, 64, 48, 128, "dgrad_mask")]
 if len(sys.argv) > 1 and sys.argv[1] == "l5":  # the 64-out-channel layers of level 5 at batch 64 (192 images through the critic)
     cases = [(192, 48, 64, 128, "fwd_pool_mask"), (64, 48, 64, 128, "tangent"), (192, 64, 48, 128, "dgrad_mask"), (192, 64, 64, 64, "fade_fwd"),
              (192, 64, 64, 64, "unpool"), (64, 48, 64, 128, "fwd_pool_mask"), (192, 64, 64, 64, "plain"), (192, 64, 80, 64, "fwd_pool_mask"),
