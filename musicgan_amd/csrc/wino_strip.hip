@@ -177,14 +177,19 @@ __device__ __forceinline__ void strip_body(const WinoArgs& a, const int ct0, con
       UE[1] = rE[ks][1] + rE[ks][2];         UP[1] = rP[ks][1] + rP[ks][2];
       UE[2] = pk_sub(rE[ks][2], rE[ks][1]);  UP[2] = pk_sub(rP[ks][2], rP[ks][1]);
       UE[3] = pk_sub(rE[ks][1], rE[ks][3]);  UP[3] = pk_sub(rP[ks][1], rP[ks][3]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        f32x2 v03, v12;  // (the s_nop: see the hardware rule in the header -- these registers are MFMA sources)
-        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,0]\n\ts_nop 1" : "=v"(v03) : "v"(UE[i]), "v"(UP[i]));  // (e0 - p1, p0 - e1)
-        asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]\n\ts_nop 1" : "=v"(v12) : "v"(UP[i]));             // (p0 + p1, p1 - p0)
-        V[ks][2 * i] = v03;
-        V[ks][2 * i + 1] = v12;
-      }
+      // (v0, v3) and (v1, v2) of the four rows: eight packed adds with swizzle / negate modifiers in ONE statement, and one wait state
+      // behind the last of them (the hardware rule in the header: these registers are MFMA sources)
+      asm("v_pk_add_f32 %0, %8, %12 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,0]\n\t"
+          "v_pk_add_f32 %1, %12, %12 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]\n\t"
+          "v_pk_add_f32 %2, %9, %13 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,0]\n\t"
+          "v_pk_add_f32 %3, %13, %13 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]\n\t"
+          "v_pk_add_f32 %4, %10, %14 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,0]\n\t"
+          "v_pk_add_f32 %5, %14, %14 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]\n\t"
+          "v_pk_add_f32 %6, %11, %15 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,0]\n\t"
+          "v_pk_add_f32 %7, %15, %15 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]\n\t"
+          "s_nop 1"
+          : "=&v"(V[ks][0]), "=&v"(V[ks][1]), "=&v"(V[ks][2]), "=&v"(V[ks][3]), "=&v"(V[ks][4]), "=&v"(V[ks][5]), "=&v"(V[ks][6]), "=&v"(V[ks][7])
+          : "v"(UE[0]), "v"(UE[1]), "v"(UE[2]), "v"(UE[3]), "v"(UP[0]), "v"(UP[1]), "v"(UP[2]), "v"(UP[3]));
     }
   };
 
