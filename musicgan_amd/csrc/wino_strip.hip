@@ -622,12 +622,17 @@ int launch_strip_kind(const WinoArgs& a, int kind, dim3 grid, hipStream_t s) {
 // tile blocks on;  16 channels (the 32 -> 16 data gradient) 1.03-1.06: not taken.  `force` (MG_WINO_STRIP=2: tests, A/B): whatever
 // the shape allows.  MG_WINO_STRIP_NIW (1 / 2 / 3) overrides the tile count per wave (3: the 192-accumulator, one-wave-per-SIMD
 // form for exactly 48 channels; measurements).
+long long strip_min_blocks() {
+  static const long long v = getenv("MG_WINO_STRIP_MIN_BLOCKS") ? atoll(getenv("MG_WINO_STRIP_MIN_BLOCKS")) : 4096;
+  return v;
+}
+
 int strip_plan(const WinoArgs& a, bool pn, bool force) {
   const int nt = a.Cout / 16;
   const long long blocks = (long long)a.N * (a.H / 2) * (a.W / 32);
   int niw = 0;
   if (nt == 1) niw = force ? 1 : 0;
-  else niw = (force || blocks >= 4096) ? 2 : 0;
+  else niw = (force || blocks >= strip_min_blocks()) ? 2 : 0;
   if (pn) niw = nt <= 2 ? (niw ? nt : 0) : 0;  // PixelNorm: all channels of a pixel in one wave
   const char* e = getenv("MG_WINO_STRIP_NIW");
   if (e != nullptr && !pn && niw != 0) {
