@@ -328,7 +328,8 @@ def create_dataset_and_train_records(device, rand_channels: int):
                 "files_per_s_after_setup": n / (wall - stats["setup_s"]),
                 "split_s": {"setup_pinned_ring_and_threads": stats["setup_s"],
                             "waiting_for_the_loader_thread_and_stft_launch": stats["load_stft_s"],
-                            "loader_thread_busy_read_pin_upload": stats["loader_thread_busy_s"],
+                            "loader_threads": stats["loader_threads"],
+                            "loader_busy_thread_s_read_pin_upload": stats["loader_thread_busy_s"],
                             "codec_d2h_submit": stats["codec_copy_submit_s"], "waiting_for_the_writers_at_the_end": stats["drain_s"],
                             "of_which_waiting_for_a_free_pinned_chunk": stats["ring_wait_s"],
                             "writer_threads": stats["writer_threads"], "writer_busy_thread_s": stats["writer_busy_s"]}}

@@ -169,6 +169,7 @@ int mg_conv3x3_wgrad_1x1map(const float* x, const float* gy, float* gw, float* g
                             * Cout<=4 (Cin>4): x is first multiplied by (aux > 0 ? 1 : slope), aux is N,Cin,HW (input side) */
 #define MG_C1_TRANSPOSED 8 /* use w^T: w is [Cin][Cout] in memory (data gradient of the forward conv) */
 #define MG_C1_TANH_BWD_IN 16 /* input is gy*(1-aux_in^2): tanh backward fused on the INPUT side (aux_in: N,Cin,HW) */
+#define MG_C1_ACCUM 32       /* Cin<=4: y += result (two gradient branches joining: generator.py:118-124 backwards) */
 int mg_conv1x1(const float* x, const float* w, const float* bias, const float* aux, float* y, int N, int Cin, int Cout,
                int HW, int flags, float slope, mg_stream_t stream);
 /* gw[Cout][Cin] (+)= sum gy*x, gb (+)= sum gy; if tanh_y != NULL gy is first multiplied by (1 - tanh_y^2).
@@ -177,6 +178,23 @@ int mg_conv1x1(const float* x, const float* w, const float* bias, const float* a
 size_t mg_conv1x1_wgrad_ws_bytes(int N, int Cin, int Cout, int HW);
 int mg_conv1x1_wgrad(const float* x, const float* gy, const float* tanh_y, float* gw, float* gb, void* ws,
                      size_t ws_bytes, int N, int Cin, int Cout, int HW, int accumulate, int bias_n, mg_stream_t stream);
+
+/* The two-channel ends of both networks while a block fades in, one launch each (csrc/fade_ends.hip).
+ * mg_stem_pair [discriminator.py:107-113 forward]: h0 = act(ws x + bs) (N,C0,H,W); xp = AvgPool2d(x) (N,2,H/2,W/2; may be NULL);
+ *   o = act(wo xp + bo) (N,C1,H/2,W/2).  flags: MG_C1_LRELU, or MG_C1_MASK_AUX = bias-free results times the LeakyReLU derivative of
+ *   the activations h0 / o hold, written over them (the penalty's tangent pass).  ws (C0,2), wo (C1,2).  H even, W % 4 == 0.
+ * mg_stem_pair_gx [the same lines, backward to x]: gx = ws^T gs + 0.25 * up2(wo^T go), gs (N,C0,H,W), go (N,C1,H/2,W/2), gx (N,2,H,W).
+ * mg_head_pair [generator.py:118-126]: mp = tanh(wh x + bh) (N,2,H,W), old = tanh(wo xl + bo) (N,2,H/2,W/2), out = a mp + b up2(old);
+ *   (a, b) = coef[0..1] from device memory if coef != NULL, else (ca, cb); mp / old may be NULL (not kept).  wh (2,C), wo (2,Cl).
+ * mg_blend_up_bwd: gx = a g, gy = b * (2x2 block sums of g): the blend's backward (g: (NC,H,W), gy: (NC,H/2,W/2)). */
+int mg_stem_pair(const float* x, const float* ws, const float* bs, const float* wo, const float* bo, float* h0, float* xp, float* o,
+                 int N, int C0, int C1, int H, int W, int flags, float slope, mg_stream_t stream);
+int mg_stem_pair_gx(const float* gs, const float* ws, const float* go, const float* wo, float* gx, int N, int C0, int C1, int H, int W,
+                    mg_stream_t stream);
+int mg_head_pair(const float* x, const float* wh, const float* bh, const float* xl, const float* wo, const float* bo, const float* coef,
+                 float ca, float cb, float* mp, float* old, float* out, int N, int C, int Cl, int H, int W, mg_stream_t stream);
+int mg_blend_up_bwd(const float* g, const float* coef, float ca, float cb, float* gx, float* gy, int NC, int H, int W,
+                    mg_stream_t stream);
 
 /* ------------------------------------------------------------------ element-wise / small ops */
 /* PixelNorm forward [layers.py:11-17]: p = y*rn, rn[n,hw] = 1/sqrt(mean_c y^2 + 1e-8) */
@@ -228,6 +246,9 @@ int mg_scale_per_sample(const float* g, const float* coef, float* out, int N, si
 /* tiny: from sumsq[N] compute penalty = factor*mean((sqrt(ss)-1)^2) and coef[n] = upstream*factor*2*(norm-1)/(N*norm) */
 int mg_gp_finish(const float* sumsq, float* penalty, float* coef, int N, float factor, float upstream,
                  mg_stream_t stream);
+/* mg_gp_finish + mg_scale_per_sample in one launch: out = g * coef[n] with coef as above, penalty (may be NULL) as above */
+int mg_gp_apply(const float* g, const float* sumsq, float* penalty, float* out, int N, size_t chw, float factor, float upstream,
+                mg_stream_t stream);
 /* sum over (n, hw) of a per-channel tensor: out[c] (+)= sum x[n,c,hw] */
 int mg_channel_sum(const float* x, float* out, int N, int C, int HW, int accumulate, mg_stream_t stream);
 

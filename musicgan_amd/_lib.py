@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmusicgan_hip.so")
 MG_CONV_UPS_IN, MG_CONV_LRELU, MG_CONV_MASK_AUX, MG_CONV_PIXNORM, MG_CONV_POOL_OUT = 1, 2, 4, 8, 16
 MG_CONV_MASK_OUT, MG_CONV_MASK_BYTES, MG_CONV_UNPOOL, MG_CONV_UPSUM_OUT = 32, 64, 128, 256
 MG_FADE_FWD, MG_FADE_TANGENT, MG_FADE_BWD = 1, 2, 3
-MG_C1_LRELU, MG_C1_TANH, MG_C1_MASK_AUX, MG_C1_TRANSPOSED, MG_C1_TANH_BWD_IN = 1, 2, 4, 8, 16
+MG_C1_LRELU, MG_C1_TANH, MG_C1_MASK_AUX, MG_C1_TRANSPOSED, MG_C1_TANH_BWD_IN, MG_C1_ACCUM = 1, 2, 4, 8, 16, 32
 
 
 class MusicGanHipError(RuntimeError):
@@ -116,6 +116,11 @@ SIGNATURES = {
     "mg_sumsq_per_sample": (c_int, [_P, _P, c_int, c_size_t, _P]),
     "mg_scale_per_sample": (c_int, [_P, _P, _P, c_int, c_size_t, _P]),
     "mg_gp_finish": (c_int, [_P, _P, _P, c_int, c_float, c_float, _P]),
+    "mg_gp_apply": (c_int, [_P, _P, _P, _P, c_int, c_size_t, c_float, c_float, _P]),
+    "mg_stem_pair": (c_int, [_P] * 8 + [c_int] * 6 + [c_float, _P]),
+    "mg_stem_pair_gx": (c_int, [_P] * 5 + [c_int] * 5 + [_P]),
+    "mg_head_pair": (c_int, [_P] * 7 + [c_float, c_float] + [_P] * 3 + [c_int] * 5 + [_P]),
+    "mg_blend_up_bwd": (c_int, [_P, _P, c_float, c_float, _P, _P, c_int, c_int, c_int, _P]),
     "mg_channel_sum": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "mg_adam_step": (c_int, [_P, c_int, c_float, c_float, c_float, c_float, _P]),
     "mg_group_means": (c_int, [_P, c_int, c_int, _P, _P]),

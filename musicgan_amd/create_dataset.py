@@ -131,31 +131,41 @@ class _Writers:
 
 
 class _Loader:
-    """Reads, page-locks and uploads the wav files one ahead of the loop that transforms them (create_dataset.py:34-38 does
-    `wav_to_stft(path)` in line): a thread maps file k+1, copies its PCM frames AS STORED (int16 stays int16: half of float32's
-    bytes; de-interleaving, scaling and the mono mean happen inside the STFT kernel) into one of two pinned staging buffers and
-    queues the host-to-device copy on its own stream, while the main thread is busy with the device-to-host copies and writers
-    of file k.  Items come out in file order: (path, device PCM tensor (frames, channels) or None, sample rate, ready event)."""
+    """Reads, page-locks and uploads the wav files ahead of the loop that transforms them (create_dataset.py:34-38 does
+    `wav_to_stft(path)` in line): WORKERS threads, worker i taking files i, i + WORKERS, ...; each maps its file, copies the PCM
+    frames AS STORED (int16 stays int16: half of float32's bytes; de-interleaving, scaling and the mono mean happen inside the STFT
+    kernel) through two pinned staging buffers of its own and queues the host-to-device copies on its own stream, while the main
+    thread is busy with the device-to-host copies and writers of earlier files.  (One thread moved a 106 MB float32 file in ~27 ms
+    -- page cache -> pinned memory is a single-core copy -- and was the loop's slowest stage once the writers were fixed, r05.)
+    Items come out in file order: (path, device PCM tensor (frames, channels) or None, sample rate, ready event)."""
 
-    STAGE_BYTES = 32 << 20  # two pinned staging buffers of this size, page-locked once (with the chunk ring, at set-up)
+    STAGE_BYTES = 32 << 20  # two pinned staging buffers of this size per worker, page-locked by the worker while the ring is set up
+    WORKERS = 3
 
-    def __init__(self, paths, device):
-        self.q: "queue.Queue" = queue.Queue(maxsize=2)
+    def __init__(self, paths, device, workers: int = 0):
+        paths = list(paths)
         self.device = device
-        self.busy_s = 0.0
+        self.busy_s = 0.0  # summed over the workers
         self._stop = False
-        self._pins = [th.empty(self.STAGE_BYTES, dtype=th.uint8).pin_memory() for _ in range(2)]
-        self._t = threading.Thread(target=self._run, args=(list(paths),), daemon=True)
-        self._t.start()
+        self._lock = threading.Lock()
+        n = max(1, min(workers or self.WORKERS, len(paths)))
+        self.workers = n
+        self._n_files = len(paths)
+        self._qs = [queue.Queue(maxsize=1) for _ in range(n)]
+        self._threads = [threading.Thread(target=self._run, args=(paths[i::n], self._qs[i]), daemon=True) for i in range(n)]
+        for t in self._threads:
+            t.start()
 
-    def _run(self, paths):
+    def _run(self, paths, out_q):
         import numpy as np
-        stream = th.cuda.Stream(device=self.device)
-        events = [None, None]
-        tdt = {np.dtype(np.int16): th.int16, np.dtype(np.int32): th.int32, np.dtype(np.uint8): th.uint8,
-               np.dtype(np.float32): th.float32}
-        slot = 0
         try:
+            th.cuda.set_device(self.device)
+            pins = [th.empty(self.STAGE_BYTES, dtype=th.uint8).pin_memory() for _ in range(2)]
+            stream = th.cuda.Stream(device=self.device)
+            events = [None, None]
+            tdt = {np.dtype(np.int16): th.int16, np.dtype(np.int32): th.int32, np.dtype(np.uint8): th.uint8,
+                   np.dtype(np.float32): th.float32}
+            slot = 0
             for path in paths:
                 if self._stop:
                     return
@@ -174,7 +184,7 @@ class _Loader:
                         n = min(self.STAGE_BYTES, nbytes - o)
                         if events[slot] is not None:
                             events[slot].synchronize()  # the upload that last read this staging buffer has finished (HOST wait)
-                        host = self._pins[slot][:n]
+                        host = pins[slot][:n]
                         if fh is not None:  # file (page cache) -> pinned memory in one pass, no intermediate array
                             got = fh.readinto(memoryview(host.numpy()))
                             assert got == n, f"short read from {path}"
@@ -194,29 +204,28 @@ class _Loader:
                     ready.record(stream)
                 shape, dt = (pcm.shape[0], pcm.shape[1]), tdt[pcm.dtype]
                 del pcm
-                self.busy_s += time.perf_counter() - t0
-                self.q.put((path, dev.view(dt).view(*shape), sr, ready))
-            self.q.put(None)
+                with self._lock:
+                    self.busy_s += time.perf_counter() - t0
+                out_q.put((path, dev.view(dt).view(*shape), sr, ready))
         except BaseException as e:  # noqa: BLE001  (re-raised by the consumer)
-            self.q.put(e)
+            out_q.put(e)
 
     def __iter__(self):
-        while True:
-            item = self.q.get()
-            if item is None:
-                return
+        for k in range(self._n_files):  # file k comes from worker k % workers
+            item = self._qs[k % self.workers].get()
             if isinstance(item, BaseException):
                 raise item
             yield item
 
     def close(self):
         self._stop = True
-        while self._t.is_alive():  # a producer blocked on a full queue needs room to see the flag
-            try:
-                self.q.get_nowait()
-            except queue.Empty:
-                pass
-            self._t.join(timeout=0.05)
+        for t, q in zip(self._threads, self._qs):
+            while t.is_alive():  # a producer blocked on a full queue needs room to see the flag
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    pass
+                t.join(timeout=0.05)
 
 
 class _Chunk:
@@ -269,8 +278,9 @@ def create_dataset(audio_path: str, dataset_output_dir: str, *, packed: bool = T
             first_idx[f_i] = run
             run += counts[f_i]
     dev = th.device("cuda", th.cuda.current_device())
-    # started first: it reads and uploads file 0 while the chunk ring below is being page-locked
-    loader = _Loader([w_p[f_i] for f_i in mine], dev)
+    # started first: it reads and uploads the first files while the chunk ring below is being page-locked
+    loader = _Loader([w_p[f_i] for f_i in mine], dev, workers=int(os.environ.get("MG_LOADER_THREADS", "0")) or max(1, min(
+        _Loader.WORKERS, host_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))) // 4)))
     # writer threads: one per CPU this process may use (at most 16) -- divided by the ranks sharing the host: 8 ranks x 16 threads
     # on the cores of one node only take turns (the widen + write path is memory-bandwidth-bound)
     cpus = host_cpus()
@@ -389,7 +399,7 @@ def create_dataset(audio_path: str, dataset_output_dir: str, *, packed: bool = T
     if stats is not None:
         wall = time.perf_counter() - t_start
         stats.update({"files": n_files, "samples": len(names), "wall_s": wall, "setup_s": t_setup, "drain_s": t_drain,
-                      "load_stft_s": t_load, "loader_thread_busy_s": t_loader,
+                      "load_stft_s": t_load, "loader_thread_busy_s": t_loader, "loader_threads": loader.workers,
                       "codec_copy_submit_s": t_gpu, "ring_wait_s": t_wait, "writer_threads": n_thr,
                       "writer_busy_s": writers.busy_s, "pt_bytes": len(names) * 2 * (audio.N_FFT // 2) * nb_vec * 8})
 

@@ -3,6 +3,8 @@
 // [generator.py:43-52], their data gradients (weights used transposed) and weight/bias gradients.
 // These are HBM-bound streams (2 <-> 48..160 channels per pixel): one thread owns 4 consecutive pixels (16-byte
 // accesses), channel loops run in registers, weights come through the scalar cache.
+#include <atomic>
+#include <cstdlib>
 #include <type_traits>
 
 #include "mg_common.h"
@@ -97,6 +99,12 @@ __global__ void __launch_bounds__(256) conv1x1_few_in(const C1Args a) {
           if (a.flags & MG_C1_TANH) r = tanhf(r);
           if (has_mask) r *= mg_lrelu_mask(mv[u][v], a.slope);
           acc[v] = r;
+        }
+        if (a.flags & MG_C1_ACCUM) {  // y += result (a second gradient branch joining the first)
+          float prev[V];
+          load_v<V>(a.y + oidx, prev);
+#pragma unroll
+          for (int v = 0; v < V; ++v) acc[v] += prev[v];
         }
         if (V == 4) {
           *reinterpret_cast<f32x4*>(a.y + oidx) = f32x4{acc[0], acc[1], acc[2], acc[3]};
@@ -246,7 +254,34 @@ struct W1Args {
   float* part;            // [gridDim.x][Mtot*(F+1) + F]
   int N, Cm, Cf, HW;
   int bias_n;  // only samples n < bias_n feed the per-channel sums of gy (the bias gradient)
+  // single-launch form (few workgroup columns): the workgroup that finishes LAST sums the partials, in index order
+  unsigned* counter;  // NULL: partials only, conv1x1_wgrad_final follows
+  float *gw, *gb;
+  int gy_is_many, accumulate;
 };
+
+// where output element e of the final sums lives: partial row `by`, slot inside the row, index in gw / gb
+__device__ __forceinline__ void w1_locate(int e, int Cm, int Cf, int gy_is_many, int per_m, int& by, int& slot, int& idx, bool& is_gw) {
+  const int nprod = Cm * Cf;
+  if (e < nprod) {
+    const int m = e / Cf, f = e - m * Cf;
+    by = m / MC;
+    slot = (m - by * MC) * per_m + f;
+    idx = gy_is_many ? m * Cf + f : f * Cm + m;
+    is_gw = true;
+  } else {
+    const int o = e - nprod;
+    idx = o;
+    is_gw = false;
+    if (gy_is_many) {
+      by = o / MC;
+      slot = (o - by * MC) * per_m + (per_m - 1);
+    } else {
+      by = 0;
+      slot = MC * per_m + o;
+    }
+  }
+}
 
 template <int V>
 __global__ void __launch_bounds__(256) conv1x1_wgrad_part(const W1Args a) {
@@ -326,11 +361,47 @@ __global__ void __launch_bounds__(256) conv1x1_wgrad_part(const W1Args a) {
   }
   __syncthreads();
   const int per = MC * (FEW + 1) + FEW;
-  if ((int)threadIdx.x < per) {
-    const float r = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    a.part[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * per + threadIdx.x] = r;
+  float* mine = a.part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * per;
+  if (a.counter == nullptr) {
+    if ((int)threadIdx.x < per) mine[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    return;
   }
+  // Single launch: partials out at device scope, a ticket per workgroup; whoever draws the last ticket reads ALL partials back (device
+  // scope again: the other workgroups ran on other XCDs, behind other L2s) and sums each output over the workgroup columns in
+  // index order -- the same value whichever workgroup happens to be last.  The counter is left at zero for the next launch.
+  if ((int)threadIdx.x < per)
+    __hip_atomic_store(mine + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x],
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __threadfence();
+  __syncthreads();
+  __shared__ int last;
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    last = t == gridDim.x * gridDim.y - 1 ? 1 : 0;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  const int Cout = a.gy_is_many ? a.Cm : a.Cf;
+  const int nout = a.Cm * a.Cf + (a.gb != nullptr ? Cout : 0);
+  const int nx = gridDim.x, ny = gridDim.y;
+  for (int e = threadIdx.x; e < nout; e += blockDim.x) {
+    int by, slot, idx;
+    bool is_gw;
+    w1_locate(e, a.Cm, a.Cf, a.gy_is_many, FEW + 1, by, slot, idx, is_gw);
+    const float* src = a.part + (size_t)by * per + slot;
+    float sum = 0.f;
+#pragma unroll 8
+    for (int bx = 0; bx < nx; ++bx) sum += __hip_atomic_load(src + (size_t)bx * ny * per, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float* dst = is_gw ? a.gw : a.gb;
+    dst[idx] = a.accumulate ? dst[idx] + sum : sum;
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+// tickets of the single-launch form: zero at module load, returned to zero by every launch; consecutive launches take different
+// slots so that two of them running at once on different streams do not share one
+__device__ unsigned g_w1_tickets[64];
 
 // final: gw[o][c], gb[o].  gy_is_many: gy = many tensor (stem: Cout = Cm, Cin = Cf) else gy = few (head: Cout = Cf, Cin = Cm).
 // One wave per output element; lanes stride over the per-block partials and combine with a fixed shuffle tree (deterministic).
@@ -392,6 +463,7 @@ extern "C" int mg_conv1x1(const float* x, const float* w, const float* bias, con
   MG_CHECK_ARG(x && w && y && N > 0 && Cin > 0 && Cout > 0 && HW > 0, "mg_conv1x1: bad arguments");
   MG_CHECK_ARG(Cin <= FEW || Cout <= FEW, "mg_conv1x1: needs Cin<=4 or Cout<=4 (got %d -> %d)", Cin, Cout);
   MG_CHECK_ARG(!(flags & (MG_C1_MASK_AUX | MG_C1_TANH_BWD_IN)) || aux, "mg_conv1x1: aux flag without aux");
+  MG_CHECK_ARG(!(flags & MG_C1_ACCUM) || Cin <= FEW, "mg_conv1x1: MG_C1_ACCUM needs Cin<=4");
   C1Args a;
   a.x = x; a.w = w; a.bias = bias; a.aux = aux; a.y = y;
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.HW = HW;
@@ -453,9 +525,25 @@ extern "C" int mg_conv1x1_wgrad(const float* x, const float* gy, const float* ta
   a.Cf = gy_is_many ? Cin : Cout;
   const int nx = w1_nx(N, HW), ny = mg_cdiv(a.Cm, MC);
   hipStream_t s = (hipStream_t)stream;
+  a.counter = nullptr;
+  a.gw = gw; a.gb = gb; a.gy_is_many = gy_is_many ? 1 : 0; a.accumulate = accumulate;
+  // up to 64 workgroup columns (maps up to ~128x128 at the reference's batch sizes): one launch, the last workgroup sums
+  static const bool single = getenv("MG_C1_WGRAD_SINGLE") == nullptr || atoi(getenv("MG_C1_WGRAD_SINGLE")) != 0;
+  if (single && nx <= 64) {
+    static std::atomic<unsigned> seq{0};
+    static unsigned* bases[MG_MAX_DEVICES] = {};  // (per device: a process may drive several GPUs)
+    unsigned*& base = bases[mg_current_device()];
+    if (base == nullptr && hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_w1_tickets)) != hipSuccess) {
+      base = nullptr;
+      mg_set_error("mg_conv1x1_wgrad: no ticket counters");
+      return MG_ELAUNCH;
+    }
+    a.counter = base + (seq.fetch_add(1) & 63u);
+  }
   if ((HW & 3) == 0) hipLaunchKernelGGL(conv1x1_wgrad_part<4>, dim3(nx, ny), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(conv1x1_wgrad_part<1>, dim3(nx, ny), dim3(256), 0, s, a);
   MG_CHECK_LAUNCH("mg_conv1x1_wgrad");
+  if (a.counter != nullptr) return MG_OK;
   const int total = a.Cm * a.Cf + Cout;
   hipLaunchKernelGGL(conv1x1_wgrad_final, dim3(mg_cdiv(total, 4)), dim3(256), 0, s, a.part, nx, ny, a.Cm, a.Cf,
                      gy_is_many ? 1 : 0, gw, gb, accumulate);

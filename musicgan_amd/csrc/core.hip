@@ -23,5 +23,5 @@ int mg_cu_count() {
   return cus[d];
 }
 
-extern "C" int mg_version(void) { return 105; }  // 105: + mg_pt_write_samples (round 5); 104: + mg_smallnet, mg_conv3x3_small, mg_stft_1024_pcm, mg_stft_generic, mg_pcm_to_mono, mg_crc32_f64 (round 4)
+extern "C" int mg_version(void) { return 106; }  // 106: + mg_stem_pair, mg_stem_pair_gx, mg_head_pair, mg_blend_up_bwd, mg_gp_apply, MG_C1_ACCUM; 105: + mg_pt_write_samples (round 5); 104: + mg_smallnet, mg_conv3x3_small, mg_stft_1024_pcm, mg_stft_generic, mg_pcm_to_mono, mg_crc32_f64 (round 4)
 extern "C" const char* mg_last_error(void) { return g_err; }

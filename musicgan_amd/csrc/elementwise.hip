@@ -486,6 +486,35 @@ __global__ void gp_finish_k(const float* __restrict__ sumsq, float* __restrict__
   if (threadIdx.x == 0 && penalty) penalty[0] = factor * s / (float)N;
 }
 
+// gp_finish_k and scale_per_sample_k in one launch: every thread derives its sample's coefficient from sumsq[n] itself (a square root
+// and a division per 4 elements), workgroup 0 also sums the penalty.
+template <int V>
+__global__ void __launch_bounds__(256) gp_apply_k(const float* __restrict__ g, const float* __restrict__ sumsq,
+                                                  float* __restrict__ penalty, float* __restrict__ out, int N, size_t chwq,
+                                                  float factor, float upstream) {
+  __shared__ float red[16];
+  const size_t total = (size_t)N * chwq;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / chwq);
+    const float nrm = sqrtf(sumsq[n]);
+    const float c = nrm > 0.f ? upstream * factor * 2.f * (nrm - 1.f) / ((float)N * nrm) : 0.f;
+    float a[V];
+    ld<V>(g + i * V, a);
+#pragma unroll
+    for (int v = 0; v < V; ++v) a[v] *= c;
+    st<V>(out + i * V, a);
+  }
+  if (blockIdx.x == 0 && penalty != nullptr) {
+    float s = 0.f;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+      const float d = sqrtf(sumsq[n]) - 1.f;
+      s += d * d;
+    }
+    s = block_sum_1024(s, red);
+    if (threadIdx.x == 0) penalty[0] = factor * s / (float)N;
+  }
+}
+
 // Means of consecutive groups of n critic scores + the Wasserstein loss built from them, one launch (criterion.py:12-18):
 //   out[g] = mean(x[g*n .. g*n+n)),  out[groups] = groups >= 2 ? out[1] - out[0]  (= -(mean D(real) - mean D(fake)))  :  -out[0]
 __global__ void __launch_bounds__(256) group_means_k(const float* __restrict__ x, int groups, int n, float* __restrict__ out) {
@@ -863,6 +892,15 @@ extern "C" int mg_gp_finish(const float* sumsq, float* penalty, float* coef, int
   MG_CHECK_ARG(sumsq && N > 0, "mg_gp_finish: bad arguments");
   EW_LAUNCH(gp_finish_k, 1, 256, sumsq, penalty, coef, N, factor, upstream);
   MG_CHECK_LAUNCH("mg_gp_finish");
+  return MG_OK;
+}
+
+extern "C" int mg_gp_apply(const float* g, const float* sumsq, float* penalty, float* out, int N, size_t chw, float factor,
+                           float upstream, mg_stream_t stream) {
+  MG_CHECK_ARG(g && sumsq && out && N > 0 && chw > 0, "mg_gp_apply: bad arguments");
+  if ((chw & 3) == 0) EW_LAUNCH(gp_apply_k<4>, ew_grid(N * chw / 4), 256, g, sumsq, penalty, out, N, chw / 4, factor, upstream);
+  else EW_LAUNCH(gp_apply_k<1>, ew_grid(N * chw), 256, g, sumsq, penalty, out, N, chw, factor, upstream);
+  MG_CHECK_LAUNCH("mg_gp_apply");
   return MG_OK;
 }
 

@@ -562,7 +562,7 @@ int launch_strip(const WinoArgs& a, dim3 grid, hipStream_t s) {
   // per SIMD -- the waves are independent, occupancy is what hides a block's load latency), never more than there are groups
   int per_cu = 1;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * NWAVE, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-  if (per_cu > 2) per_cu = 2;
+  if (per_cu > 16 / NWAVE) per_cu = 16 / NWAVE;
   {
     const char* e = getenv("MG_WINO_STRIP_WGS");  // measurement switch: workgroups per CU
     if (e != nullptr && atoi(e) >= 1) per_cu = atoi(e);
@@ -687,7 +687,10 @@ int mgi_wino_strip_run(WinoArgs& a, hipStream_t s) {
   const int niw = strip_plan(a, kind == SK_PN, e != nullptr && atoi(e) > 1);
   dim3 grid(1, mg_cdiv(nt, niw));  // (an odd tile count: the last workgroup row carries one padding tile of zero filters)
   switch (niw) {
-    case 1: return launch_strip_kind<1, 8>(a, kind, grid, s);
+    case 1: {
+      const int nw1 = getenv("MG_WINO_STRIP_NW1") ? atoi(getenv("MG_WINO_STRIP_NW1")) : 8;
+      return nw1 == 4 ? launch_strip_kind<1, 4>(a, kind, grid, s) : launch_strip_kind<1, 8>(a, kind, grid, s);
+    }
     case 2: return launch_strip_kind<2, 8>(a, kind, grid, s);
     default: return launch_strip_kind<3, 4>(a, kind, grid, s);
   }

@@ -400,10 +400,15 @@ def gen_forward(W: GenWeights, z: torch.Tensor, alpha: float, cache: PackCache, 
         x_in_last, x = x, p2
     old = None
     if W.old_head is not None:
-        mp = ops.conv1x1(x, W.head[0], W.head[1], 2, tanh=True)
-        old = ops.conv1x1(x_in_last, W.old_head[0], W.old_head[1], 2, tanh=True)
         F = FadeIn.of(alpha)
-        out = ops.blend_up(F.a, mp, F.b, old, out=out, coef=F.dev)
+        if ops.fuse_ends() and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
+            # both heads, the up-sampling of the old one and the blend in one launch
+            out, mp, old = ops.head_pair(x, W.head[0], W.head[1], x_in_last, W.old_head[0], W.old_head[1], F.a, F.b, coef=F.dev,
+                                         save=save, out=out)
+        else:
+            mp = ops.conv1x1(x, W.head[0], W.head[1], 2, tanh=True)
+            old = ops.conv1x1(x_in_last, W.old_head[0], W.old_head[1], 2, tanh=True)
+            out = ops.blend_up(F.a, mp, F.b, old, out=out, coef=F.dev)
     else:
         out = mp = ops.conv1x1(x, W.head[0], W.head[1], 2, tanh=True, out=out)
     ctx = (saved, x, mp, old, alpha) if save else None
@@ -416,7 +421,9 @@ def gen_backward(W: GenWeights, ctx, g_out: torch.Tensor, cache: PackCache, sink
     saved, x_last, mp, old, alpha = ctx
     F = FadeIn.of(alpha)
     g_out = g_out.contiguous()
-    if W.old_head is not None:
+    if W.old_head is not None and ops.fuse_ends() and g_out.shape[2] % 2 == 0 and g_out.shape[3] % 4 == 0:
+        g_mp, g_old = ops.blend_up_bwd(g_out, F.a, F.b, coef=F.dev)
+    elif W.old_head is not None:
         g_mp = ops.axpby(F.a, g_out, coef=F.dev)
         g_old = ops.upsample2x_bwd(g_out)
         g_old = ops.axpby(F.b, g_old, out=g_old, coef=F.dev_b)
@@ -475,8 +482,11 @@ def gen_backward(W: GenWeights, ctx, g_out: torch.Tensor, cache: PackCache, sink
                 gwo, acc = sink.slot(W.old_head[0])
                 gbo, _ = sink.slot(W.old_head[1])
                 ops.conv1x1_wgrad(xin, g_old, gwo, gbo, tanh_y=old, accumulate=acc)
-                extra = ops.conv1x1(g_old, W.old_head[0], None, xin.shape[1], transposed=True, tanh_bwd_in=old)
-                g = ops.axpby(1.0, g, 1.0, extra, out=g)
+                if ops.fuse_ends():  # the old head's branch joins in the conv's epilogue
+                    ops.conv1x1(g_old, W.old_head[0], None, xin.shape[1], transposed=True, tanh_bwd_in=old, out=g, accumulate=True)
+                else:
+                    extra = ops.conv1x1(g_old, W.old_head[0], None, xin.shape[1], transposed=True, tanh_bwd_in=old)
+                    g = ops.axpby(1.0, g, 1.0, extra, out=g)
         elif need_gz:
             gz = cache.conv(gpre1, w1, True, None, ci)
     return gz
@@ -609,10 +619,14 @@ def disc_forward(W: DiscWeights, x: torch.Tensor, alpha: float, cache: PackCache
     x = x.contiguous()
     n = x.shape[0]
     c0 = W.stem[0].shape[0]
-    h0 = ops.conv1x1(x, W.stem[0], W.stem[1], c0, lrelu=True)
+    xp = o = None
+    fused_stem = W.old_stem is not None and ops.stem_pair_supported(x.shape[2], x.shape[3])
+    if fused_stem:  # the new block's stem, the pooled input and the old block's stem on it: one pass over x
+        h0, xp, o = ops.stem_pair(x, W.stem[0], W.stem[1], W.old_stem[0], W.old_stem[1], want_xp=save)
+    else:
+        h0 = ops.conv1x1(x, W.stem[0], W.stem[1], c0, lrelu=True)
     saved = []
     inp = h0
-    xp = o = None
     tail = disc_tail_start(W, x.shape[2], x.shape[3])
     for i, (w1, b1, w2, b2) in enumerate(W.blocks):
         c1 = w1.shape[0]
@@ -632,8 +646,9 @@ def disc_forward(W: DiscWeights, x: torch.Tensor, alpha: float, cache: PackCache
         a1, q1 = cache.conv(inp, w1, False, b1, c1, lrelu=True, pool=True,
                             mask_out=save and _tile_mask_ok(n, w1.shape[1], c1, inp.shape[2], inp.shape[3]))
         if i == 0 and W.old_stem is not None:  # fade-in: the block's output is blended with the old stem's
-            xp = ops.avgpool2_fwd(x)
-            o = ops.conv1x1(xp, W.old_stem[0], W.old_stem[1], c1, lrelu=True)
+            if not fused_stem:
+                xp = ops.avgpool2_fwd(x)
+                o = ops.conv1x1(xp, W.old_stem[0], W.old_stem[1], c1, lrelu=True)
             F = FadeIn.of(alpha)
             c_next = W.blocks[1][0].shape[0] if len(W.blocks) > 1 else 0
             if _fade_fused_ok(n, c1, c_next, q1.shape[2], q1.shape[3]):
@@ -746,7 +761,9 @@ def disc_backward(W: DiscWeights, ctx, g_out: torch.Tensor, cache: PackCache, si
     if keep_h:
         hs["stem"], hs["old"] = gpre_s, gpre_o
     gx = None
-    if need_gx:  # gx_from > 0: only samples gx_from.. are wanted (the fused critic step needs the interpolated third only)
+    if need_gx and W.old_stem is not None and ops.fuse_ends() and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
+        gx = ops.stem_pair_gx(gpre_s[gx_from:], W.stem[0], gpre_o[gx_from:], W.old_stem[0])  # both branches and their sum, one launch
+    elif need_gx:  # gx_from > 0: only samples gx_from.. are wanted (the fused critic step needs the interpolated third only)
         gx = ops.conv1x1(gpre_s[gx_from:], W.stem[0], None, 2, transposed=True)
         if W.old_stem is not None:
             gxp = ops.conv1x1(gpre_o[gx_from:], W.old_stem[0], None, 2, transposed=True)
@@ -826,16 +843,22 @@ def disc_step_fused(W: DiscWeights, x_real: torch.Tensor, x_fake: torch.Tensor, 
     gx, hs = disc_backward(W, ctx, g_out, cache, None, need_gx=True, keep_h=True, gx_from=2 * n)  # input gradient: x~ only
     # penalty value and u_0 = dP/dg_0, written over the interpolated inputs (they are not needed any more)
     ss = ops.sumsq_per_sample(gx)
-    grad_pen, coef = ops.gp_finish(ss, gp_factor, 1.0)
     x, h0, saved, xp, o, flat, _ = ctx
     sl = slice(2 * n, 3 * n)
-    ops.scale_per_sample(gx, coef, out=x[sl])
+    if ops.fuse_ends():
+        grad_pen, _ = ops.gp_apply(gx, ss, gp_factor, 1.0, out=x[sl])
+    else:
+        grad_pen, coef = ops.gp_finish(ss, gp_factor, 1.0)
+        ops.scale_per_sample(gx, coef, out=x[sl])
     # ---- tangent pass, in place over the interpolated slices
     c0 = W.stem[0].shape[0]
-    ops.conv1x1(x[sl], W.stem[0], None, c0, mask_aux=h0[sl], out=h0[sl])
-    if W.old_stem is not None:
-        ops.avgpool2_fwd(x[sl], out=xp[sl])
-        ops.conv1x1(xp[sl], W.old_stem[0], None, W.old_stem[0].shape[0], mask_aux=o[sl], out=o[sl])
+    if W.old_stem is not None and ops.stem_pair_supported(x.shape[2], x.shape[3]):
+        ops.stem_pair(x[sl], W.stem[0], None, W.old_stem[0], None, h0=h0[sl], xp=xp[sl], o=o[sl], masked=True)
+    else:
+        ops.conv1x1(x[sl], W.stem[0], None, c0, mask_aux=h0[sl], out=h0[sl])
+        if W.old_stem is not None:
+            ops.avgpool2_fwd(x[sl], out=xp[sl])
+            ops.conv1x1(xp[sl], W.old_stem[0], None, W.old_stem[0].shape[0], mask_aux=o[sl], out=o[sl])
     nb = len(W.blocks)
     tail = disc_tail_start(W, x.shape[2], x.shape[3])
     for i, (w1, b1, w2, b2) in enumerate(W.blocks):

@@ -529,10 +529,14 @@ def pack_smallnet(w: torch.Tensor, dgrad: bool) -> torch.Tensor:
 
 # ------------------------------------------------------------------ conv 1x1
 def conv1x1(x, w, bias, cout: int, *, lrelu=False, tanh=False, mask_aux=None, transposed=False, tanh_bwd_in=None,
-            out=None):
+            out=None, accumulate=False):
+    """`accumulate` (few input channels only): out += result."""
     _chk(x, w, bias, mask_aux, tanh_bwd_in, out)
     n, cin, h, wd = x.shape
     flags = (MG_C1_LRELU if lrelu else 0) | (MG_C1_TANH if tanh else 0) | (MG_C1_TRANSPOSED if transposed else 0)
+    if accumulate:
+        assert out is not None and cin <= 4
+        flags |= _lib.MG_C1_ACCUM
     aux = None
     if mask_aux is not None:
         flags |= MG_C1_MASK_AUX
@@ -557,6 +561,80 @@ def conv1x1_wgrad(x, gy, gw, gb, *, tanh_y=None, accumulate=False, bias_n: int =
     ws = workspace(nbytes, x.device)
     check(lib.mg_conv1x1_wgrad(_p(x), _p(gy), _p(tanh_y), _p(gw), _p(gb), _p(ws), ws.numel(), n, cin, cout, h * wd,
                                int(accumulate), int(bias_n), _s()), "mg_conv1x1_wgrad")
+
+
+def fuse_ends() -> bool:
+    """The fade-in ends of both networks as single launches (csrc/fade_ends.hip); MG_FUSE_ENDS=0: the separate kernels."""
+    return os.environ.get("MG_FUSE_ENDS", "1") != "0"
+
+
+def stem_pair_supported(h: int, w: int) -> bool:
+    return fuse_ends() and h % 2 == 0 and w % 4 == 0
+
+
+def stem_pair(x, ws, bs, wo, bo, *, lrelu=True, h0=None, xp=None, o=None, masked=False, want_xp=True):
+    """Critic input while a block fades in (discriminator.py:107-113): h0 = act(ws x + bs), xp = AvgPool2d(x), o = act(wo xp + bo).
+    `masked`: the tangent form -- h0 / o hold the forward activations and receive (w x) * lrelu'(activation) in place."""
+    _chk(x, ws, bs, wo, bo, h0, xp, o)
+    n, _, h, w = x.shape
+    c0, c1 = ws.shape[0], wo.shape[0]
+    if masked:
+        assert h0 is not None and o is not None and bs is None and bo is None
+    new = lambda c, hh, ww: torch.empty((n, c, hh, ww), dtype=torch.float32, device=x.device)
+    h0 = new(c0, h, w) if h0 is None else h0
+    o = new(c1, h // 2, w // 2) if o is None else o
+    if xp is None and want_xp:
+        xp = new(2, h // 2, w // 2)
+    flags = MG_C1_MASK_AUX if masked else (MG_C1_LRELU if lrelu else 0)
+    check(_lib.load().mg_stem_pair(_p(x), _p(ws), _p(bs), _p(wo), _p(bo), _p(h0), _p(xp), _p(o), n, c0, c1, h, w, flags, SLOPE, _s()),
+          "mg_stem_pair")
+    return h0, xp, o
+
+
+def stem_pair_gx(gs, ws, go, wo, out=None):
+    """gx = ws^T gs + 0.25 * up2(wo^T go): the data gradient of both input branches back to the critic's input."""
+    _chk(gs, ws, go, wo, out)
+    n, c0, h, w = gs.shape
+    c1 = go.shape[1]
+    assert go.shape[0] == n and go.shape[2] == h // 2 and go.shape[3] == w // 2
+    gx = torch.empty((n, 2, h, w), dtype=torch.float32, device=gs.device) if out is None else out
+    check(_lib.load().mg_stem_pair_gx(_p(gs), _p(ws), _p(go), _p(wo), _p(gx), n, c0, c1, h, w, _s()), "mg_stem_pair_gx")
+    return gx
+
+
+def head_pair(x, wh, bh, xl, wo, bo, a: float, b: float, *, coef=None, save=True, out=None):
+    """Generator output while a block fades in (generator.py:118-126): (out, mp, old) with mp = tanh(wh x + bh), old = tanh(wo xl + bo),
+    out = a mp + b up2(old); `save` False: mp / old are not written (None)."""
+    _chk(x, wh, bh, xl, wo, bo, coef, out)
+    n, c, h, w = x.shape
+    cl = xl.shape[1]
+    assert xl.shape[0] == n and xl.shape[2] == h // 2 and xl.shape[3] == w // 2
+    new = lambda hh, ww: torch.empty((n, 2, hh, ww), dtype=torch.float32, device=x.device)
+    mp, old = (new(h, w), new(h // 2, w // 2)) if save else (None, None)
+    out = new(h, w) if out is None else out
+    check(_lib.load().mg_head_pair(_p(x), _p(wh), _p(bh), _p(xl), _p(wo), _p(bo), _p(coef), float(a), float(b), _p(mp), _p(old), _p(out),
+                                   n, c, cl, h, w, _s()), "mg_head_pair")
+    return out, mp, old
+
+
+def blend_up_bwd(g, a: float, b: float, coef=None):
+    """(a g, b * 2x2 block sums of g): backward of blend_up."""
+    _chk(g, coef)
+    n, c, h, w = g.shape
+    gx = torch.empty_like(g)
+    gy = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=g.device)
+    check(_lib.load().mg_blend_up_bwd(_p(g), _p(coef), float(a), float(b), _p(gx), _p(gy), n * c, h, w, _s()), "mg_blend_up_bwd")
+    return gx, gy
+
+
+def gp_apply(g, sumsq, factor: float, upstream: float = 1.0, out=None):
+    """(penalty, out = g * coef[n]): gp_finish + scale_per_sample in one launch."""
+    _chk(g, sumsq, out)
+    n = g.shape[0]
+    out = torch.empty_like(g) if out is None else out
+    pen = torch.empty((), dtype=torch.float32, device=g.device)
+    check(_lib.load().mg_gp_apply(_p(g), _p(sumsq), _p(pen), _p(out), n, g[0].numel(), float(factor), float(upstream), _s()), "mg_gp_apply")
+    return pen, out
 
 
 # ------------------------------------------------------------------ element-wise

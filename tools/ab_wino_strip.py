@@ -69,16 +69,21 @@ if len(sys.argv) > 1 and sys.argv[1] == "l5":  # the 64-out-channel layers of le
     cases = [(192, 48, 64, 128, "fwd_pool_mask"), (64, 48, 64, 128, "tangent"), (192, 64, 48, 128, "dgrad_mask"), (192, 64, 64, 64, "fade_fwd"),
              (192, 64, 64, 64, "unpool"), (64, 48, 64, 128, "fwd_pool_mask"), (192, 64, 64, 64, "plain"), (192, 64, 80, 64, "fwd_pool_mask"),
              (192, 80, 64, 64, "unpool")]
+if len(sys.argv) > 1 and sys.argv[1] == "nt1":  # 16 out-channels: one tile per wave
+    cases = [(18, 32, 16, 512, "dgrad_mask"), (6, 32, 16, 512, "dgrad_mask"), (18, 16, 16, 512, "plain"), (6, 32, 16, 256, "pn"),
+             (18, 48, 16, 256, "dgrad_mask")]
 # variants: "0" the staged kernel; "2" strip, all out-channel tiles in a wave; "2n1" strip, one tile per wave (tiles on grid.y)
 VARIANTS = ["0", "2"] + [v for v in sys.argv[1:] if v.startswith("2")]
 
 
 def setenv(v):
     os.environ["MG_WINO_STRIP"] = v[0]
-    for k in ("MG_WINO_STRIP_NIW", "MG_WINO_STRIP_WGS"):
+    for k in ("MG_WINO_STRIP_NIW", "MG_WINO_STRIP_WGS", "MG_WINO_STRIP_NW1"):
         os.environ.pop(k, None)
     if "n" in v:
         os.environ["MG_WINO_STRIP_NIW"] = v[v.index("n") + 1]
+    if "q" in v:  # waves per workgroup of the one-tile kernels
+        os.environ["MG_WINO_STRIP_NW1"] = v[v.index("q") + 1]
     if "w" in v:
         os.environ["MG_WINO_STRIP_WGS"] = v[v.index("w") + 1]
 
