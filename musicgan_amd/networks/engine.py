@@ -124,10 +124,10 @@ class PackCache:
         n, cin, h, wd = x.shape
         if kw.get("ups"):
             h, wd = 2 * h, 2 * wd
-        side = int(os.environ.get("MG_SMALLCONV_MAX_SIDE", "8"))
+        side = int(os.environ.get("MG_SMALLCONV_MAX_SIDE", "16"))
         # measured against the direct / Winograd kernels (tools/ab_smallconv.py): ahead up to 192 images at 2x2 / 4x4 (whole images
         # per workgroup), up to 32 images at 8x8 (row bands); beyond that each layer is throughput- not latency-bound
-        cap = int(os.environ.get("MG_SMALLCONV_MAX_PIXELS", "3072" if h * wd <= 16 else "2048"))
+        cap = int(os.environ.get("MG_SMALLCONV_MAX_PIXELS", "3072" if h * wd <= 16 else os.environ.get("MG_SMALLCONV_MAX_PIXELS_BIG", "2048")))
         if h > side or wd > side or n * h * wd > cap:
             return False
         return ops.conv3x3_small_supported(n, cin, cout, h, wd)
