@@ -130,7 +130,7 @@ __device__ __forceinline__ void strip_body(const WinoArgs& a, const int ct0, con
   // (uniform per wave: the first row of tile row 0, the last of tile row Ht - 1, everything of a tile row beyond the image) are read
   // through a descriptor of zero records, the image's left / right edge through an out-of-range lane offset: both return 0.0.
   const int lp = ((2 * rq) * HW + 2 * col) * 4;
-  unsigned vP, vL, vR;
+  unsigned vP, vX;  // own pixel pair; the halo pixel only the first / last lane of a 16-lane row has to fetch (see load_rows)
   int rowoff[4];                     // scalar: (row * W + 32 bx) * 4, row = 2 by - 1 + r
   int rowrec[4];                     // scalar: num_records of the row's descriptor (0 = reads as zero)
   const float* img_base;
@@ -138,8 +138,7 @@ __device__ __forceinline__ void strip_body(const WinoArgs& a, const int ct0, con
     img_base = a.x + (size_t)n0 * a.Cin * HW;
     const int xoff = bx * 128;
     vP = (unsigned)(lp + xoff);
-    vL = (bx == 0 && col == 0) ? 0x80000000u : vP - 4u;
-    vR = (bx == a.blocks_x - 1 && col == 15) ? 0x80000000u : vP + 8u;
+    vX = col == 0 ? (bx == 0 ? 0x80000000u : vP - 4u) : ((col == 15 && bx != a.blocks_x - 1) ? vP + 8u : 0x80000000u);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int Y = 2 * by - 1 + r;
@@ -149,8 +148,13 @@ __device__ __forceinline__ void strip_body(const WinoArgs& a, const int ct0, con
   };
 
   f32x4 acc[16][NIW];
-  f32x2 rP[2][4], rE[2][4];  // own pixel pair; (left, right) halo pixels
-  f32x2 V[2][8];             // [k-step][component pair]: the B operands of this lane
+  // Per row and channel a lane fetches its own pixel pair and -- lanes 0 and 15 of a 16-lane row only, every other lane's offset is
+  // out of range and costs no fetch -- the one halo pixel that belongs to a neighbouring tile BLOCK; the halo pixels inside the block
+  // are the neighbouring lanes' own pixels and come by DPP in the transform (two loads per row and channel instead of three, 8
+  // registers fewer: -2..-6 % per launch, -10 % on the one-tile data gradient, bit-identical).
+  f32x2 rP[2][4];  // [k-step][row]: own pixel pair
+  float rX[2][4];  // the block-edge halo pixel (left for lane 0, right for lane 15 of a row)
+  f32x2 V[2][8];   // [k-step][component pair]: the B operands of this lane
 
   auto load_rows = [&](int ch) __attribute__((always_inline)) {
 #pragma unroll
@@ -160,8 +164,7 @@ __device__ __forceinline__ void strip_body(const WinoArgs& a, const int ct0, con
       for (int ks = 0; ks < 2; ++ks) {
         const int soff = (ch * WCC + ks) * HW * 4 + rowoff[r];
         rP[ks][r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)vP, soff, 0));
-        rE[ks][r][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)vL, soff, 0));
-        rE[ks][r][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)vR, soff, 0));
+        rX[ks][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)vX, soff, 0));
       }
     }
   };
@@ -172,11 +175,19 @@ __device__ __forceinline__ void strip_body(const WinoArgs& a, const int ct0, con
   auto transform_rows = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+      f32x2 rE[4];  // (left, right) halo pixels: lane - 1's right pixel / lane + 1's left pixel; at the ends of a 16-lane row the DPP
+                    // source is invalid and the destination keeps `old` = the fetched block-edge pixel (0.0 at the image edge)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int old = __builtin_bit_cast(int, rX[ks][r]);
+        rE[r][0] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(old, __builtin_bit_cast(int, f2i(rP[ks][r][1])), 0x111, 0xf, 0xf, false));  // row_shr:1
+        rE[r][1] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(old, __builtin_bit_cast(int, f2i(rP[ks][r][0])), 0x101, 0xf, 0xf, false));  // row_shl:1
+      }
       f32x2 UE[4], UP[4];
-      UE[0] = pk_sub(rE[ks][0], rE[ks][2]);  UP[0] = pk_sub(rP[ks][0], rP[ks][2]);
-      UE[1] = rE[ks][1] + rE[ks][2];         UP[1] = rP[ks][1] + rP[ks][2];
-      UE[2] = pk_sub(rE[ks][2], rE[ks][1]);  UP[2] = pk_sub(rP[ks][2], rP[ks][1]);
-      UE[3] = pk_sub(rE[ks][1], rE[ks][3]);  UP[3] = pk_sub(rP[ks][1], rP[ks][3]);
+      UE[0] = pk_sub(rE[0], rE[2]);  UP[0] = pk_sub(rP[ks][0], rP[ks][2]);
+      UE[1] = rE[1] + rE[2];         UP[1] = rP[ks][1] + rP[ks][2];
+      UE[2] = pk_sub(rE[2], rE[1]);  UP[2] = pk_sub(rP[ks][2], rP[ks][1]);
+      UE[3] = pk_sub(rE[1], rE[3]);  UP[3] = pk_sub(rP[ks][1], rP[ks][3]);
       // (v0, v3) and (v1, v2) of the four rows: eight packed adds with swizzle / negate modifiers in ONE statement, and one wait state
       // behind the last of them (the hardware rule in the header: these registers are MFMA sources)
       asm("v_pk_add_f32 %0, %8, %12 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,0]\n\t"
@@ -291,6 +302,10 @@ __device__ __forceinline__ void strip_body(const WinoArgs& a, const int ct0, con
   // the loop body, behind those stores in straight-line code -- there the compiler can wait `vmcnt(number of stores)`.  With that
   // transform at the top of the body the loop header joins "entered from the prologue, no stores behind the loads" with "the back
   // edge, stores behind them" and the wait becomes vmcnt(0): every wave then sits out the write acknowledgements of its own stores.
+  // (Measured and not kept, with the second row set this leaves room for: a chunk's rows requested TWO chunks ahead -- 256 registers with
+  // 2-10 spilled, +5..+12 % on every shape, profiles/r05_ab_wino_strip.txt: what the memory system costs is not an HBM round trip
+  // that one more chunk of MFMAs would cover.)
+  const int nch = a.nchunk;
   block_geometry();
   load_rows(0);
   transform_rows();
@@ -299,7 +314,7 @@ __device__ __forceinline__ void strip_body(const WinoArgs& a, const int ct0, con
     const int ebx = bx, eby = by, en0 = n0;  // this block, for the epilogue
     load_rows(1);
     mfma_chunk(0, T_{});
-    for (int ch = 1; ch + 1 < a.nchunk; ++ch) {
+    for (int ch = 1; ch + 1 < nch; ++ch) {
       transform_rows();
       load_rows(ch + 1);  // in flight during the MFMAs below
       mfma_chunk(ch, F_{});
@@ -310,7 +325,7 @@ __device__ __forceinline__ void strip_body(const WinoArgs& a, const int ct0, con
     advance();
     block_geometry();
     load_rows(0);
-    mfma_chunk(a.nchunk - 1, F_{});
+    mfma_chunk(nch - 1, F_{});
     // the next block's first chunk is transformed BEFORE this block's stores are issued: a wait for loads that have stores behind
     // them is a wait for those stores too (one counter on gfx9; the compiler waits vmcnt(0) whenever both kinds are pending)
     __builtin_amdgcn_sched_barrier(0);
@@ -619,8 +634,8 @@ int launch_strip_kind(const WinoArgs& a, int kind, dim3 grid, hipStream_t s) {
 // out-channels.  The choice follows tools/ab_wino_strip.py (profiles/r05_ab_wino_strip.txt), us per launch against wino3x3.hip:
 // 32 channels 0.72-0.92;  64 channels (the dominant launches of level 5: 48->64 @128 x 192 images 929 -> 782) 0.81-0.94;  48 channels
 // 0.73-0.96 (64->48 @128 x 192, the largest launch of a level-5 step: 1016 -> 903);  80 / 96 channels 0.78-0.97 -- each from ~4 000
-// tile blocks on;  16 channels (the 32 -> 16 data gradient) 1.03-1.06: not taken.  `force` (MG_WINO_STRIP=2: tests, A/B): whatever
-// the shape allows.  MG_WINO_STRIP_NIW (1 / 2 / 3) overrides the tile count per wave (3: the 192-accumulator, one-wave-per-SIMD
+// tile blocks on;  16 channels (one tile per wave: the 32 -> 16 data gradient of level 7) 0.81-0.91 since the in-block halo pixels come
+// by DPP (1.01-1.06 before).  `force` (MG_WINO_STRIP=2: tests, A/B): whatever the shape allows.  MG_WINO_STRIP_NIW (1 / 2 / 3) overrides the tile count per wave (3: the 192-accumulator, one-wave-per-SIMD
 // form for exactly 48 channels; measurements).
 long long strip_min_blocks() {
   static const long long v = getenv("MG_WINO_STRIP_MIN_BLOCKS") ? atoll(getenv("MG_WINO_STRIP_MIN_BLOCKS")) : 4096;
@@ -631,8 +646,7 @@ int strip_plan(const WinoArgs& a, bool pn, bool force) {
   const int nt = a.Cout / 16;
   const long long blocks = (long long)a.N * (a.H / 2) * (a.W / 32);
   int niw = 0;
-  if (nt == 1) niw = force ? 1 : 0;
-  else niw = (force || blocks >= strip_min_blocks()) ? 2 : 0;
+  niw = (force || blocks >= strip_min_blocks()) ? (nt == 1 ? 1 : 2) : 0;
   if (pn) niw = nt <= 2 ? (niw ? nt : 0) : 0;  // PixelNorm: all channels of a pixel in one wave
   const char* e = getenv("MG_WINO_STRIP_NIW");
   if (e != nullptr && !pn && niw != 0) {
