@@ -633,12 +633,12 @@ int launch_strip_kind(const WinoArgs& a, int kind, dim3 grid, hipStream_t s) {
 // count ends in a row that computes ONE tile on the two-tile filter image and gets a smaller share of the grid), one for 16
 // out-channels.  The choice follows tools/ab_wino_strip.py (profiles/r05_ab_wino_strip.txt), us per launch against wino3x3.hip:
 // 32 channels 0.72-0.92;  64 channels (the dominant launches of level 5: 48->64 @128 x 192 images 929 -> 782) 0.81-0.94;  48 channels
-// 0.73-0.96 (64->48 @128 x 192, the largest launch of a level-5 step: 1016 -> 903);  80 / 96 channels 0.78-0.97 -- each from ~4 000
-// tile blocks on;  16 channels (one tile per wave: the 32 -> 16 data gradient of level 7) 0.81-0.91 since the in-block halo pixels come
+// 0.73-0.96 (64->48 @128 x 192, the largest launch of a level-5 step: 1016 -> 903);  80 / 96 channels 0.78-0.97 -- each from ~2 000
+// tile blocks on (whole steps: 4096 -> 2048 is -0.3 % at level 5, -0.5 % at level 4, nothing at levels 3 / 6 / 7; 1536 is +1.3 % at level 6);  16 channels (one tile per wave: the 32 -> 16 data gradient of level 7) 0.81-0.91 since the in-block halo pixels come
 // by DPP (1.01-1.06 before).  `force` (MG_WINO_STRIP=2: tests, A/B): whatever the shape allows.  MG_WINO_STRIP_NIW (1 / 2 / 3) overrides the tile count per wave (3: the 192-accumulator, one-wave-per-SIMD
 // form for exactly 48 channels; measurements).
 long long strip_min_blocks() {
-  static const long long v = getenv("MG_WINO_STRIP_MIN_BLOCKS") ? atoll(getenv("MG_WINO_STRIP_MIN_BLOCKS")) : 4096;
+  static const long long v = getenv("MG_WINO_STRIP_MIN_BLOCKS") ? atoll(getenv("MG_WINO_STRIP_MIN_BLOCKS")) : 2048;
   return v;
 }
 
