@@ -53,7 +53,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // (TY, TX) is then the 3x3 low-res neighbourhood with the centre row / column doubled -- one dword per row and lane.
 // The body takes its block coordinates as arguments: `split` (slab index, blockIdx.x of a single-layer launch) and `yblk`
 // (channel block pair, blockIdx.y) -- a grouped launch (wino_wgrad_group_mfma below) derives them from a table instead.
-template <int CT, int OT, bool UPS>
+// FAST: chunks of 8 x 1 x 1 tiles on maps whose width is a multiple of 16 (every layer from 16x16 maps up): which rows and halo pixels
+// of a chunk exist is then the same for all its lanes, so a lane's byte offset is fixed for the kernel (+ one add of the chunk's
+// column), rows travel in the scalar offset, and a row / chunk outside the tensor is read through a descriptor of zero records --
+// the general form spends ~45 of its ~115 vector instructions per chunk and wave on per-lane predicates and offsets.
+template <int CT, int OT, bool UPS, bool FAST = false>
 __device__ __forceinline__ void ww_body(const WwArgs& a, const int split, const int yblk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -81,6 +85,10 @@ __device__ __forceinline__ void ww_body(const WwArgs& a, const int split, const 
 
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gy), 0, (int)a.gy_bytes, 0x00020000);
+  // FAST: lane parts of the byte offsets (channel plane + own pixel pair inside the chunk's 16 pixels); out of range = no such channel
+  const unsigned fxP = xch ? (unsigned)(((c0 + chs) * HWx + (UPS ? t : 2 * t)) * 4) : 0x80000000u;
+  const unsigned fyP = ych ? (unsigned)(((o0 + chs) * HW + 2 * t) * 4) : 0x80000000u;
+  const int fdelta = t == 0 ? -4 : (UPS ? 4 : 8);  // halo pixel of an edge lane relative to its own pair
 
   f32x4 acc[2][CT][OT];
 #pragma unroll
@@ -109,6 +117,46 @@ __device__ __forceinline__ void ww_body(const WwArgs& a, const int split, const 
   }
   auto load_chunk = [&]() {  // the slab's next chunk (all-zero once past its end)
     const int blk = nq < a.per ? split * a.per + nq : a.nblk;
+    if constexpr (FAST) {
+      // scalar: the chunk is tile row `by` of image `bn`, tiles 8 bx .. 8 bx + 7
+      const bool ok = blk < a.nblk;
+      const unsigned vP = fxP + (unsigned)((UPS ? 8 : 16) * bx * 4);
+      const bool ev = t == 0 ? bx > 0 : bx < a.blocks_x - 1;
+      const unsigned vE = (xch && (t == 0 || t == 7) && ev) ? vP + (unsigned)fdelta : 0x80000000u;
+      constexpr int NR = UPS ? 3 : 4;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const bool rv = ok && (r == 0 ? by > 0 : (r == NR - 1 ? by < Ht - 1 : true));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, rv ? (int)a.x_bytes : 0, 0x00020000);
+        const int so = UPS ? ((bn * a.Cin) * HWx + (by - 1 + r) * Wt) * 4 : ((bn * a.Cin) * HWx + (2 * by - 1 + r) * a.W) * 4;
+        if constexpr (UPS) {
+          const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)vP, so, 0));
+          const float ve = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)vE, so, 0));
+          const int rr = r == 0 ? 0 : (r == 1 ? 1 : 3);
+          rP[rr] = f32x2{v, v};
+          rE[rr] = ve;
+          if (r == 1) { rP[2] = f32x2{v, v}; rE[2] = ve; }
+        } else {
+          rP[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)vP, so, 0));
+          rE[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)vE, so, 0));
+        }
+      }
+      const __amdgpu_buffer_rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gy), 0, ok ? (int)a.gy_bytes : 0, 0x00020000);
+      const unsigned vY = fyP + (unsigned)(16 * bx * 4);
+      const int sy = ((bn * a.Cout) * HW + (2 * by) * a.W) * 4;
+      rG[0] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ys, (int)vY, sy, 0));
+      rG[1] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ys, (int)vY, sy + a.W * 4, 0));
+      bnext = bn < a.bias_n;
+      ++nq;
+      ++bx;
+      const int wx = bx == a.blocks_x ? 1 : 0;
+      bx = wx ? 0 : bx;
+      by += wx;
+      const int wy = by == a.blocks_y ? 1 : 0;
+      by = wy ? 0 : by;
+      bn += wy;
+      return;
+    }
     const int n = bn * a.TBN + nl, TY = by * a.TBH + tyl, TX = bx * a.TBW + txl;
     const bool ok = (blk < a.nblk) && (n < a.N) && (TY < Ht) && (TX < Wt);
     const int ux = UPS ? (bn * a.TBN * a.Cin) * HWx + (by * a.TBH) * Wt + bx * a.TBW
@@ -310,9 +358,9 @@ __device__ __forceinline__ void ww_body(const WwArgs& a, const int split, const 
   if (cb == 0 && t == 0 && chs < OT * 16 && o0 + chs < a.CoutP) a.slab_b[(size_t)split * a.CoutP + o0 + chs] = bsum;
 }
 
-template <int CT, int OT, bool UPS>
+template <int CT, int OT, bool UPS, bool FAST>
 __global__ void __launch_bounds__(512) wino_wgrad_mfma(const WwArgs a) {
-  ww_body<CT, OT, UPS>(a, blockIdx.x, blockIdx.y);
+  ww_body<CT, OT, UPS, FAST>(a, blockIdx.x, blockIdx.y);
 }
 
 // ---- several layers in ONE launch.  At small batch / on small maps a layer's weight gradient is a 10-30 us launch of a few dozen
@@ -354,7 +402,7 @@ __global__ void __launch_bounds__(512) wino_wgrad_group_mfma(const WwGroup g) {
 // whose per-chunk work (8 tiles x a few dozen channels) is far below an HBM round trip -- see the comments inside.
 // UPS: x is (N, Cin, H/2, W/2) and the convolution input is its nearest x2 up-sampling (generator.py:24-25): the 4x4 patch of tile
 // (TY, TX) is then the 3x3 low-res neighbourhood with the centre row / column doubled -- one dword per row and lane.
-template <int CT, int OT, bool UPS>
+template <int CT, int OT, bool UPS, bool FAST>
 __global__ void __launch_bounds__(512, 4) wino_wgrad_narrow_mfma(const WwArgs a) {
   static_assert(CT + OT <= 4, "the narrow form: at most four channel tiles in all");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -395,6 +443,10 @@ __global__ void __launch_bounds__(512, 4) wino_wgrad_narrow_mfma(const WwArgs a)
 
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gy), 0, (int)a.gy_bytes, 0x00020000);
+  // FAST (see ww_body): lane parts of the byte offsets, fixed for the kernel
+  const unsigned fxP = xch ? (unsigned)(((c0 + xs) * HWx + (UPS ? t : 2 * t)) * 4) : 0x80000000u;
+  const unsigned fyP = ych ? (unsigned)(((o0 + ys) * HW + 2 * t) * 4) : 0x80000000u;
+  const int fdelta = t == 0 ? -4 : (UPS ? 4 : 8);
 
   f32x4 acc[2][CT][OT];
 #pragma unroll
@@ -433,6 +485,49 @@ __global__ void __launch_bounds__(512, 4) wino_wgrad_narrow_mfma(const WwArgs a)
     constexpr int ROLE = decltype(role_)::value;  // bit 0: this wave stages x slots, bit 1: gy slots
     auto& rP = rr.rP; auto& rG = rr.rG; auto& rE = rr.rE; bool& bnext = rr.bnext;
     const int blk = nq < a.per ? split * a.per + nq : a.nblk;
+    if constexpr (FAST) {
+      const bool ok = blk < a.nblk;
+      if constexpr ((ROLE & 1) != 0) {
+        const unsigned vP = fxP + (unsigned)((UPS ? 8 : 16) * bx * 4);
+        const bool ev = t == 0 ? bx > 0 : bx < a.blocks_x - 1;
+        const unsigned vE = (xch && (t == 0 || t == 7) && ev) ? vP + (unsigned)fdelta : 0x80000000u;
+        constexpr int NR = UPS ? 3 : 4;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const bool rv = ok && (r == 0 ? by > 0 : (r == NR - 1 ? by < Ht - 1 : true));
+          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, rv ? (int)a.x_bytes : 0, 0x00020000);
+          const int so = UPS ? ((bn * a.Cin) * HWx + (by - 1 + r) * Wt) * 4 : ((bn * a.Cin) * HWx + (2 * by - 1 + r) * a.W) * 4;
+          if constexpr (UPS) {
+            const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)vP, so, 0));
+            const float ve = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)vE, so, 0));
+            const int r4 = r == 0 ? 0 : (r == 1 ? 1 : 3);
+            rP[r4] = f32x2{v, v};
+            rE[r4] = ve;
+            if (r == 1) { rP[2] = f32x2{v, v}; rE[2] = ve; }
+          } else {
+            rP[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)vP, so, 0));
+            rE[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)vE, so, 0));
+          }
+        }
+      }
+      if constexpr ((ROLE & 2) != 0) {
+        const __amdgpu_buffer_rsrc_t ysr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gy), 0, ok ? (int)a.gy_bytes : 0, 0x00020000);
+        const unsigned vY = fyP + (unsigned)(16 * bx * 4);
+        const int sy = ((bn * a.Cout) * HW + (2 * by) * a.W) * 4;
+        rG[0] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ysr, (int)vY, sy, 0));
+        rG[1] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ysr, (int)vY, sy + a.W * 4, 0));
+        bnext = bn < a.bias_n;
+      }
+      ++nq;
+      ++bx;
+      const int wx = bx == a.blocks_x ? 1 : 0;
+      bx = wx ? 0 : bx;
+      by += wx;
+      const int wy = by == a.blocks_y ? 1 : 0;
+      by = wy ? 0 : by;
+      bn += wy;
+      return;
+    }
     const int n = bn * a.TBN + nl, TY = by * a.TBH + tyl, TX = bx * a.TBW + txl;
     const bool ok = (blk < a.nblk) && (n < a.N) && (TY < Ht) && (TX < Wt);
     const int ux = UPS ? (bn * a.TBN * a.Cin) * HWx + (by * a.TBH) * Wt + bx * a.TBW
@@ -791,49 +886,60 @@ void plan_ww(int N, int Cin, int Cout, int H, int W, WwPlan& pl) {
   pl.ws_floats = (size_t)pl.nsplit * (9 * (size_t)a.CinP * a.CoutP + a.CoutP);
 }
 
-template <int CT, int OT, bool UPS>
+template <int CT, int OT, bool UPS, bool FAST>
 int launch_ww(const WwArgs& a, dim3 grid, hipStream_t s) {
   constexpr size_t lds = (size_t)2 * (CT + OT <= 4 ? IMG : STAGE) * sizeof(float);
   static MgPerDevice once;  // the LDS limit is a per-device function attribute
   if constexpr (CT + OT <= 4) {
     if (mg_first_use_on_device(once)) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_wgrad_narrow_mfma<CT, OT, UPS>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_wgrad_narrow_mfma<CT, OT, UPS, FAST>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    hipLaunchKernelGGL((wino_wgrad_narrow_mfma<CT, OT, UPS>), grid, dim3(512), lds, s, a);
+    hipLaunchKernelGGL((wino_wgrad_narrow_mfma<CT, OT, UPS, FAST>), grid, dim3(512), lds, s, a);
   } else {
     if (mg_first_use_on_device(once)) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_wgrad_mfma<CT, OT, UPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_wgrad_mfma<CT, OT, UPS, FAST>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024);
     }
-    hipLaunchKernelGGL((wino_wgrad_mfma<CT, OT, UPS>), grid, dim3(512), lds, s, a);
+    hipLaunchKernelGGL((wino_wgrad_mfma<CT, OT, UPS, FAST>), grid, dim3(512), lds, s, a);
   }
   MG_CHECK_LAUNCH("mg_wino3x3_wgrad");
   return MG_OK;
 }
 
-template <bool UPS>
-int dispatch_ww(int CT, int OT, const WwArgs& a, dim3 grid, hipStream_t s) {
+// the scalar-addressed form (ww_body FAST): chunks of 8 x 1 x 1 tiles, whole chunks per tile row; MG_WGRAD_FAST=0: never
+bool ww_fast(const WwArgs& a) {
+  static const bool on = getenv("MG_WGRAD_FAST") == nullptr || atoi(getenv("MG_WGRAD_FAST")) != 0;
+  return on && a.TBW == 8 && a.TBH == 1 && a.TBN == 1 && (a.W % 16) == 0;
+}
+
+template <bool UPS, bool FAST>
+int dispatch_ww_f(int CT, int OT, const WwArgs& a, dim3 grid, hipStream_t s) {
   switch (CT * 10 + OT) {
-    case 11: return launch_ww<1, 1, UPS>(a, grid, s);
-    case 12: return launch_ww<1, 2, UPS>(a, grid, s);
-    case 13: return launch_ww<1, 3, UPS>(a, grid, s);
-    case 14: return launch_ww<1, 4, UPS>(a, grid, s);
-    case 21: return launch_ww<2, 1, UPS>(a, grid, s);
-    case 22: return launch_ww<2, 2, UPS>(a, grid, s);
-    case 23: return launch_ww<2, 3, UPS>(a, grid, s);
-    case 24: return launch_ww<2, 4, UPS>(a, grid, s);
-    case 31: return launch_ww<3, 1, UPS>(a, grid, s);
-    case 32: return launch_ww<3, 2, UPS>(a, grid, s);
-    case 33: return launch_ww<3, 3, UPS>(a, grid, s);
-    case 34: return launch_ww<3, 4, UPS>(a, grid, s);
-    case 41: return launch_ww<4, 1, UPS>(a, grid, s);
-    case 42: return launch_ww<4, 2, UPS>(a, grid, s);
-    case 43: return launch_ww<4, 3, UPS>(a, grid, s);
-    case 44: return launch_ww<4, 4, UPS>(a, grid, s);
+    case 11: return launch_ww<1, 1, UPS, FAST>(a, grid, s);
+    case 12: return launch_ww<1, 2, UPS, FAST>(a, grid, s);
+    case 13: return launch_ww<1, 3, UPS, FAST>(a, grid, s);
+    case 14: return launch_ww<1, 4, UPS, FAST>(a, grid, s);
+    case 21: return launch_ww<2, 1, UPS, FAST>(a, grid, s);
+    case 22: return launch_ww<2, 2, UPS, FAST>(a, grid, s);
+    case 23: return launch_ww<2, 3, UPS, FAST>(a, grid, s);
+    case 24: return launch_ww<2, 4, UPS, FAST>(a, grid, s);
+    case 31: return launch_ww<3, 1, UPS, FAST>(a, grid, s);
+    case 32: return launch_ww<3, 2, UPS, FAST>(a, grid, s);
+    case 33: return launch_ww<3, 3, UPS, FAST>(a, grid, s);
+    case 34: return launch_ww<3, 4, UPS, FAST>(a, grid, s);
+    case 41: return launch_ww<4, 1, UPS, FAST>(a, grid, s);
+    case 42: return launch_ww<4, 2, UPS, FAST>(a, grid, s);
+    case 43: return launch_ww<4, 3, UPS, FAST>(a, grid, s);
+    case 44: return launch_ww<4, 4, UPS, FAST>(a, grid, s);
   }
   mg_set_error("mg_wino3x3_wgrad: internal tile error (CT=%d, OT=%d)", CT, OT);
   return MG_EINVAL;
+}
+
+template <bool UPS>
+int dispatch_ww(int CT, int OT, const WwArgs& a, dim3 grid, hipStream_t s) {
+  return ww_fast(a) ? dispatch_ww_f<UPS, true>(CT, OT, a, grid, s) : dispatch_ww_f<UPS, false>(CT, OT, a, grid, s);
 }
 
 int launch_ww_group(const WwGroup& g, hipStream_t s) {
