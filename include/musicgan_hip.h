@@ -76,6 +76,9 @@ int mg_upconv3x3(const float* x, const float* wp, const float* bias, float* y, f
  * as mg_conv3x3; PIXNORM needs Cout <= 64.  up from mg_wino3x3_pack (dgrad = 1: filters of the data-gradient convolution). */
 size_t mg_wino3x3_packed_floats(int Cin, int Cout);
 int mg_wino3x3_pack(const float* w, float* up, int Co, int Ci, int dgrad, mg_stream_t stream);
+/* whether MG_CONV_MASK_AUX | MG_CONV_MASK_BYTES WITHOUT MG_CONV_POOL_OUT (y = result x lrelu'(tile-mask bytes), full resolution) is
+ * available for this shape: an epilogue of the wave-per-tile-block kernel (csrc/wino_strip.hip) only */
+int mg_wino3x3_mask_bytes_y_supported(int N, int Cin, int Cout, int H, int W);
 int mg_wino3x3(const float* x, const float* up, const float* bias, const float* aux, float* y, float* p, float* rn, int N,
                int Cin, int Cout, int H, int W, int flags, float slope, mg_stream_t stream);
 
@@ -183,12 +186,14 @@ int mg_conv1x1_wgrad(const float* x, const float* gy, const float* tanh_y, float
  * mg_stem_pair [discriminator.py:107-113 forward]: h0 = act(ws x + bs) (N,C0,H,W); xp = AvgPool2d(x) (N,2,H/2,W/2; may be NULL);
  *   o = act(wo xp + bo) (N,C1,H/2,W/2).  flags: MG_C1_LRELU, or MG_C1_MASK_AUX = bias-free results times the LeakyReLU derivative of
  *   the activations h0 / o hold, written over them (the penalty's tangent pass).  ws (C0,2), wo (C1,2).  H even, W % 4 == 0.
+ *   h0_mask (optional, forward form): the tile mask of h0 in mg_wino3x3's format (N,C0,H/2,W/2 uint8, bit 2i+j <-> h0[2Y+i][2X+j] > 0),
+ *   what the data-gradient conv in front of the stem reads instead of h0 itself (MG_CONV_MASK_AUX | MG_CONV_MASK_BYTES).
  * mg_stem_pair_gx [the same lines, backward to x]: gx = ws^T gs + 0.25 * up2(wo^T go), gs (N,C0,H,W), go (N,C1,H/2,W/2), gx (N,2,H,W).
  * mg_head_pair [generator.py:118-126]: mp = tanh(wh x + bh) (N,2,H,W), old = tanh(wo xl + bo) (N,2,H/2,W/2), out = a mp + b up2(old);
  *   (a, b) = coef[0..1] from device memory if coef != NULL, else (ca, cb); mp / old may be NULL (not kept).  wh (2,C), wo (2,Cl).
  * mg_blend_up_bwd: gx = a g, gy = b * (2x2 block sums of g): the blend's backward (g: (NC,H,W), gy: (NC,H/2,W/2)). */
 int mg_stem_pair(const float* x, const float* ws, const float* bs, const float* wo, const float* bo, float* h0, float* xp, float* o,
-                 int N, int C0, int C1, int H, int W, int flags, float slope, mg_stream_t stream);
+                 unsigned char* h0_mask, int N, int C0, int C1, int H, int W, int flags, float slope, mg_stream_t stream);
 int mg_stem_pair_gx(const float* gs, const float* ws, const float* go, const float* wo, float* gx, int N, int C0, int C1, int H, int W,
                     mg_stream_t stream);
 int mg_head_pair(const float* x, const float* wh, const float* bh, const float* xl, const float* wo, const float* bo, const float* coef,

@@ -117,7 +117,8 @@ SIGNATURES = {
     "mg_scale_per_sample": (c_int, [_P, _P, _P, c_int, c_size_t, _P]),
     "mg_gp_finish": (c_int, [_P, _P, _P, c_int, c_float, c_float, _P]),
     "mg_gp_apply": (c_int, [_P, _P, _P, _P, c_int, c_size_t, c_float, c_float, _P]),
-    "mg_stem_pair": (c_int, [_P] * 8 + [c_int] * 6 + [c_float, _P]),
+    "mg_wino3x3_mask_bytes_y_supported": (c_int, [c_int] * 5),
+    "mg_stem_pair": (c_int, [_P] * 9 + [c_int] * 6 + [c_float, _P]),
     "mg_stem_pair_gx": (c_int, [_P] * 5 + [c_int] * 5 + [_P]),
     "mg_head_pair": (c_int, [_P] * 7 + [c_float, c_float] + [_P] * 3 + [c_int] * 5 + [_P]),
     "mg_blend_up_bwd": (c_int, [_P, _P, c_float, c_float, _P, _P, c_int, c_int, c_int, _P]),

@@ -19,6 +19,7 @@ struct StemArgs {
   const float* x;
   const float *ws, *bs, *wo, *bo;
   float *h0, *xp, *o;
+  unsigned char* hm;  // optional: tile mask of h0, one byte per 2x2 tile and channel (bit 2i+j <-> h0[2Y+i][2X+j] > 0; wino3x3.hip's format)
   int N, C0, C1, H, W;
   int flags;
   float slope;
@@ -74,6 +75,7 @@ __global__ void __launch_bounds__(256) stem_pair_k(const StemArgs a) {
         for (int u = 0; u < OB; ++u) {
           if (ob + u >= hi) break;
           float* dst = a.h0 + ((size_t)n * a.C0 + ob + u) * HW + off;
+          unsigned bits = 0;  // byte 0: the patch's left tile, byte 1: its right tile
 #pragma unroll
           for (int rr = 0; rr < 2; ++rr) {
             f32x4 v;
@@ -83,9 +85,11 @@ __global__ void __launch_bounds__(256) stem_pair_k(const StemArgs a) {
               if (lrelu) t = mg_lrelu(t, a.slope);
               if (masked) t *= mg_lrelu_mask(m[u][rr][e], a.slope);
               v[e] = t;
+              bits |= mg_pos_bit(t) << (8 * (e >> 1) + 2 * rr + (e & 1));
             }
             *reinterpret_cast<f32x4*>(dst + rr * a.W) = v;
           }
+          if (a.hm != nullptr) *reinterpret_cast<unsigned short*>(a.hm + ((size_t)n * a.C0 + ob + u) * PP + offp) = (unsigned short)bits;
         }
       }
     }
@@ -276,13 +280,15 @@ int grid_for(size_t items, int per_block, int cap) {
 }  // namespace
 
 extern "C" int mg_stem_pair(const float* x, const float* ws, const float* bs, const float* wo, const float* bo, float* h0, float* xp,
-                            float* o, int N, int C0, int C1, int H, int W, int flags, float slope, mg_stream_t stream) {
+                            float* o, unsigned char* h0_mask, int N, int C0, int C1, int H, int W, int flags, float slope,
+                            mg_stream_t stream) {
   MG_CHECK_ARG(x && ws && wo && h0 && o && N > 0 && C0 > 0 && C1 > 0 && H > 0 && W > 0, "mg_stem_pair: bad arguments");
   MG_CHECK_ARG((H % 2) == 0 && (W % 4) == 0, "mg_stem_pair: needs H %% 2 == 0 and W %% 4 == 0 (got %dx%d)", H, W);
   MG_CHECK_ARG(!(flags & ~(MG_C1_LRELU | MG_C1_MASK_AUX)), "mg_stem_pair: flags other than MG_C1_LRELU | MG_C1_MASK_AUX");
   MG_CHECK_ARG(!((flags & MG_C1_MASK_AUX) && (bs || bo)), "mg_stem_pair: the masked (tangent) form is bias-free");
   StemArgs a;
-  a.x = x; a.ws = ws; a.bs = bs; a.wo = wo; a.bo = bo; a.h0 = h0; a.xp = xp; a.o = o;
+  MG_CHECK_ARG(!(h0_mask && (flags & MG_C1_MASK_AUX)), "mg_stem_pair: the tile mask is an output of the forward form");
+  a.x = x; a.ws = ws; a.bs = bs; a.wo = wo; a.bo = bo; a.h0 = h0; a.xp = xp; a.o = o; a.hm = h0_mask;
   a.N = N; a.C0 = C0; a.C1 = C1; a.H = H; a.W = W; a.flags = flags; a.slope = slope;
   const size_t px = (size_t)N * H * W;
   const int cmax = C0 > C1 ? C0 : C1;

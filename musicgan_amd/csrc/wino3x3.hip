@@ -318,8 +318,8 @@ extern "C" int mg_wino3x3(const float* x, const float* up, const float* bias, co
   MG_CHECK_ARG(pn || y || mask_bytes, "mg_wino3x3: y is NULL");
   MG_CHECK_ARG(!mask_out || ((flags & MG_CONV_POOL_OUT) && (flags & MG_CONV_LRELU) && !(flags & MG_CONV_MASK_AUX) && !unpool),
                "mg_wino3x3: MASK_OUT needs POOL_OUT and LRELU");
-  MG_CHECK_ARG(!mask_bytes || ((flags & MG_CONV_MASK_AUX) && (flags & MG_CONV_POOL_OUT) && !unpool),
-               "mg_wino3x3: MASK_BYTES needs MASK_AUX and POOL_OUT (the pooled result is the only output)");
+  MG_CHECK_ARG(!mask_bytes || ((flags & MG_CONV_MASK_AUX) && ((flags & MG_CONV_POOL_OUT) || y) && !unpool),
+               "mg_wino3x3: MASK_BYTES needs MASK_AUX and an output (POOL_OUT: the pooled result only; else y)");
   MG_CHECK_ARG(!unpool || (aux && y && !(flags & ~MG_CONV_UNPOOL) && !bias), "mg_wino3x3: UNPOOL takes aux and y and no other flag");
   MG_CHECK_ARG(!(flags & MG_CONV_POOL_OUT) || (!pn && p), "mg_wino3x3: POOL_OUT needs p and no PIXNORM");
   MG_CHECK_ARG(!((flags & MG_CONV_MASK_AUX) && (flags & (MG_CONV_LRELU | MG_CONV_PIXNORM))),
@@ -339,6 +339,14 @@ extern "C" int mg_wino3x3(const float* x, const float* up, const float* bias, co
   return wino_run(a, pn, (hipStream_t)stream);
 }
 
+extern "C" int mg_wino3x3_mask_bytes_y_supported(int N, int Cin, int Cout, int H, int W) {
+  if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (H % 2) || (W % 2)) return 0;
+  WinoArgs a = {};
+  a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+  a.flags = MG_CONV_MASK_AUX | MG_CONV_MASK_BYTES;
+  return mgi_wino_strip_takes(a, false) ? 1 : 0;
+}
+
 namespace {
 int wino_run(WinoArgs& a, bool pn, hipStream_t s) {
   const int N = a.N, Cin = a.Cin, Cout = a.Cout, H = a.H, W = a.W;
@@ -348,6 +356,9 @@ int wino_run(WinoArgs& a, bool pn, hipStream_t s) {
   const int Ht = H / 2, Wt = W / 2;
   // few channels on a large map: one wave per tile block, operands built in registers, filters resident in LDS (wino_strip.hip)
   if (mgi_wino_strip_takes(a, pn)) return mgi_wino_strip_run(a, s);
+  // (tile-mask bytes applied to a full-resolution result: an epilogue of the strip kernel only -- mg_wino3x3_mask_bytes_y_supported)
+  MG_CHECK_ARG(!(a.flags & MG_CONV_MASK_BYTES) || (a.flags & (MG_CONV_POOL_OUT | WF_BLEND)),
+               "mg_wino3x3: MASK_BYTES without POOL_OUT needs a shape the strip kernel takes (N=%d %d->%d @%dx%d)", N, Cin, Cout, H, W);
 
   // out-channel tiles per workgroup (wave groups x tiles per wave): 4 = 2x2, 3 = 3x1, 2 = 2x1 -- least padding wins
   int cfg = 4, best = mg_cdiv(nt, 4) * 4;

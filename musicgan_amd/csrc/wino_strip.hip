@@ -50,6 +50,7 @@ enum StripKind {
   SK_BLEND_TAN,      // fade-in tangent: x mask bytes, blend -> y
   SK_BLEND_BWD,      // fade-in backward: two masked, scaled copies -> y, p
   SK_PN,             // bias + LeakyReLU + PixelNorm -> p, rn (+ y)
+  SK_MB_Y,           // x tile-mask bytes -> y (a data gradient times the LeakyReLU derivative of the layer below, kept as bytes)
 };
 
 // (by value on purpose: __builtin_bit_cast applied to an ext-vector ELEMENT lvalue, e.g. bit_cast(unsigned, v4[g]), reads element 0
@@ -512,6 +513,17 @@ __device__ __forceinline__ void strip_body(const WinoArgs& a, const int ct0, con
           store_rows(ry, ra, ni);
           store_rows(rp, rb, ni);
         }
+      } else if constexpr (kind == SK_MB_Y) {
+        const auto ry = rs(a.y, full, 4), rm = rs(a.mi, pooled_n, 1);
+#pragma unroll
+        for (int ni = 0; ni < NIW; ++ni) {
+          unsigned mb[4];
+          load_mask_bytes(rm, mb, ni);
+          f32x4 r4[4];
+          xform(ni, r4);
+          apply_mask_bytes(r4, mb);
+          store_rows(ry, r4, ni);
+        }
       } else {  // SK_PN: all channels of a pixel are in this wave (NIW tiles x 4 row groups x 4)
         const auto rp = rs(a.p, full, 4);  // (y is not written: mgi_wino_strip_takes)
         f32x4 o[NIW][4];
@@ -621,6 +633,7 @@ int launch_strip_kind(const WinoArgs& a, int kind, dim3 grid, hipStream_t s) {
     case SK_BLEND_FWD: return launch_strip<NIW, NWAVE, SK_BLEND_FWD, false>(a, grid, s);
     case SK_BLEND_TAN: return launch_strip<NIW, NWAVE, SK_BLEND_TAN, false>(a, grid, s);
     case SK_BLEND_BWD: return launch_strip<NIW, NWAVE, SK_BLEND_BWD, false>(a, grid, s);
+    case SK_MB_Y: return launch_strip<NIW, NWAVE, SK_MB_Y, false>(a, grid, s);
     default:
       if constexpr (NIW <= 2) return launch_strip<NIW, NWAVE, SK_PN, false>(a, grid, s);
       mg_set_error("mg_wino3x3 (strip): PixelNorm with three out-channel tiles");
@@ -661,7 +674,7 @@ int strip_kind(const WinoArgs& a) {  // the dispatch of wino_epilogue.h, by name
   if (a.flags & MG_CONV_UNPOOL) return SK_UNPOOL;
   if (a.flags & WF_BLEND_BWD) return SK_BLEND_BWD;
   if (a.flags & WF_BLEND) return (a.flags & MG_CONV_MASK_BYTES) ? SK_BLEND_TAN : SK_BLEND_FWD;
-  if (a.flags & MG_CONV_MASK_AUX) return (a.flags & MG_CONV_MASK_BYTES) ? SK_MB_POOL : SK_MASKF;
+  if (a.flags & MG_CONV_MASK_AUX) return (a.flags & MG_CONV_MASK_BYTES) ? ((a.flags & MG_CONV_POOL_OUT) ? SK_MB_POOL : SK_MB_Y) : SK_MASKF;
   return (a.flags & MG_CONV_MASK_OUT) ? SK_ACT_POOL_MOUT : SK_ACT;
 }
 

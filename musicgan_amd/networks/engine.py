@@ -621,8 +621,17 @@ def disc_forward(W: DiscWeights, x: torch.Tensor, alpha: float, cache: PackCache
     c0 = W.stem[0].shape[0]
     xp = o = None
     fused_stem = W.old_stem is not None and ops.stem_pair_supported(x.shape[2], x.shape[3])
+    h0m = None
     if fused_stem:  # the new block's stem, the pooled input and the old block's stem on it: one pass over x
-        h0, xp, o = ops.stem_pair(x, W.stem[0], W.stem[1], W.old_stem[0], W.old_stem[1], want_xp=save)
+        # of h0 the data-gradient conv in front of the stem only needs the sign: where that conv is the Winograd kernel the stem also
+        # leaves one byte per 2x2 tile and channel, 1/16 of the bytes the fp32 mask costs that launch (the largest of a D / G backward)
+        c1_0 = W.blocks[0][0].shape[0]
+        if save and os.environ.get("MG_TILEMASK", "1") != "0" and os.environ.get("MG_STEM_TILEMASK", "1") != "0" and \
+                ops.wino3x3_supported(n, c0, x.shape[2], x.shape[3], cin=c1_0) and \
+                ops.wino3x3_mask_bytes_y_supported(n, c1_0, c0, x.shape[2], x.shape[3]):
+            h0, xp, o, h0m = ops.stem_pair(x, W.stem[0], W.stem[1], W.old_stem[0], W.old_stem[1], want_xp=save, want_mask=True)
+        else:
+            h0, xp, o = ops.stem_pair(x, W.stem[0], W.stem[1], W.old_stem[0], W.old_stem[1], want_xp=save)
     else:
         h0 = ops.conv1x1(x, W.stem[0], W.stem[1], c0, lrelu=True)
     saved = []
@@ -639,7 +648,7 @@ def disc_forward(W: DiscWeights, x: torch.Tensor, alpha: float, cache: PackCache
                 saved.append((inp, a1, q1, rest[0][0]))
                 saved.extend(rest[1:])
             flat = rest[-1][3].reshape(n, -1) if save else None
-            return out, ((x, h0, saved, xp, o, flat, alpha) if save else None)
+            return out, ((x, h0, saved, xp, o, flat, alpha, h0m) if save else None)
         # AvgPool2d fused in the epilogue.  Of the full-resolution activation the backward passes only need the sign, so on the
         # large maps (Winograd kernel, for every batch slice that will come back with the mask) it is kept as one byte per
         # 2x2 tile and a1 is that uint8 tile mask (N,c1,H/2,W/2) instead of the fp32 tensor.
@@ -666,7 +675,7 @@ def disc_forward(W: DiscWeights, x: torch.Tensor, alpha: float, cache: PackCache
         f"discriminator input must be square with side 2**(9-curr_layer); final map is {tuple(inp.shape)}"
     flat = inp.reshape(n, -1)
     out = ops.linear1_fwd(flat, W.clf[0], W.clf[1])
-    ctx = (x, h0, saved, xp, o, flat, alpha) if save else None
+    ctx = (x, h0, saved, xp, o, flat, alpha, h0m) if save else None
     return out, ctx
 
 
@@ -674,7 +683,7 @@ def disc_backward(W: DiscWeights, ctx, g_out: torch.Tensor, cache: PackCache, si
                   need_gx: bool, keep_h: bool = False, gx_from: int = 0):
     """Back-propagate g_out (N,1).  sink=None skips all parameter gradients (first-order pass of the penalty).
     keep_h returns the masked per-layer gradients h_l needed by disc_gp_param_grads()."""
-    x, h0, saved, xp, o, flat, alpha = ctx
+    x, h0, saved, xp, o, flat, alpha, h0m = ctx
     F = FadeIn.of(alpha)
     g_out = g_out.contiguous()
     n = x.shape[0]
@@ -749,7 +758,7 @@ def disc_backward(W: DiscWeights, ctx, g_out: torch.Tensor, cache: PackCache, si
             else:
                 gpre2 = cache.conv(gpre1, w1, True, None, cin, mask_aux=a2_prev)
         else:
-            gpre_s = cache.conv(gpre1, w1, True, None, cin, mask_aux=h0)
+            gpre_s = cache.conv(gpre1, w1, True, None, cin, mask_aux=h0m if h0m is not None else h0)
     if sink is not None:
         gws, acc = sink.slot(W.stem[0])
         gbs, _ = sink.slot(W.stem[1])
@@ -775,7 +784,7 @@ def disc_gp_param_grads(W: DiscWeights, ctx, hs, u0: torch.Tensor, cache: PackCa
                         g_out: Optional[torch.Tensor] = None, want_t: bool = False):
     """Second-order pass of the gradient penalty: tangent-forward u_l = mask_l * L_l u_{l-1} and dP/dW_l = wgrad(u_{l-1}, h_l).
     Biases receive no gradient from the penalty."""
-    x, h0, saved, xp, o, flat, alpha = ctx
+    x, h0, saved, xp, o, flat, alpha, _ = ctx
     n = x.shape[0]
     c0 = W.stem[0].shape[0]
     gws, acc = sink.slot(W.stem[0])
@@ -843,7 +852,7 @@ def disc_step_fused(W: DiscWeights, x_real: torch.Tensor, x_fake: torch.Tensor, 
     gx, hs = disc_backward(W, ctx, g_out, cache, None, need_gx=True, keep_h=True, gx_from=2 * n)  # input gradient: x~ only
     # penalty value and u_0 = dP/dg_0, written over the interpolated inputs (they are not needed any more)
     ss = ops.sumsq_per_sample(gx)
-    x, h0, saved, xp, o, flat, _ = ctx
+    x, h0, saved, xp, o, flat, _, _ = ctx
     sl = slice(2 * n, 3 * n)
     if ops.fuse_ends():
         grad_pen, _ = ops.gp_apply(gx, ss, gp_factor, 1.0, out=x[sl])

@@ -112,6 +112,11 @@ def wino3x3_supported(n: int, cout: int, h: int, w: int, *, ups=False, pixnorm=F
     return n * h * w >= int(os.environ.get("MG_WINO_MIN_PIXELS", "4096"))
 
 
+def wino3x3_mask_bytes_y_supported(n: int, cin: int, cout: int, h: int, w: int) -> bool:
+    """conv3x3(..., mask_aux=<uint8 tile mask>) without pool: the strip kernel's epilogue, for the shapes it takes."""
+    return bool(_lib.load().mg_wino3x3_mask_bytes_y_supported(n, cin, cout, h, w))
+
+
 def _chk_tilemask(m, shape):
     if not m.is_cuda or m.dtype != torch.uint8 or not m.is_contiguous() or tuple(m.shape) != tuple(shape):
         raise _lib.MusicGanHipError(f"tile mask must be a contiguous uint8 GPU tensor of shape {tuple(shape)}, got "
@@ -126,7 +131,8 @@ def conv3x3(x, wp, bias, cout: int, *, ups=False, lrelu=False, mask_aux=None, pi
     written by the same lane); `pool_out` (optional) receives the pooled tensor.
     Tile masks (Winograd kernel only; one uint8 per 2x2 tile and channel, bit 2i+j <-> y[2Y+i, 2X+j] > 0):
     `mask_out` with pool + lrelu returns (tile mask, pooled) -- the full-resolution y is never written;
-    a uint8 `mask_aux` (with pool) is such a mask of this conv's own output: returns (None, pooled);
+    a uint8 `mask_aux` is such a mask of this conv's own output: with pool it returns (None, pooled), without pool the masked
+    result y itself (a data gradient times the LeakyReLU derivative of the layer below);
     `unpool_mask` (N,cout,H,W uint8, nothing else): returns the (N,cout,2H,2W) tensor 0.25 * up2(conv) * lrelu'(mask) --
     AvgPool2d backward + LeakyReLU backward of the layer below, fused on the data-gradient conv that feeds them."""
     if unpool_mask is not None or mask_out or (mask_aux is not None and mask_aux.dtype == torch.uint8):
@@ -176,7 +182,13 @@ def _conv3x3_tilemask(x, bias, cout, *, lrelu, mask_aux, pool, pool_out, wino, m
                              SLOPE, _s()), "mg_wino3x3")
         return y
     if not pool:
-        raise _lib.MusicGanHipError("tile masks go with the fused AvgPool2d epilogue")
+        if mask_aux is None or mask_out or lrelu or bias is not None:
+            raise _lib.MusicGanHipError("without the fused AvgPool2d a tile mask is an input only (bias-free, no lrelu)")
+        _chk_tilemask(mask_aux, (n, cout, h // 2, w // 2))
+        y = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+        check(lib.mg_wino3x3(_p(x), _p(wino), None, _p(mask_aux), _p(y), None, None, n, cin, cout, h, w,
+                             MG_CONV_MASK_AUX | _lib.MG_CONV_MASK_BYTES, SLOPE, _s()), "mg_wino3x3")
+        return y
     p = pool_out if pool_out is not None else torch.empty((n, cout, h // 2, w // 2), dtype=torch.float32, device=x.device)
     if mask_out:
         if not lrelu or mask_aux is not None:
@@ -572,7 +584,7 @@ def stem_pair_supported(h: int, w: int) -> bool:
     return fuse_ends() and h % 2 == 0 and w % 4 == 0
 
 
-def stem_pair(x, ws, bs, wo, bo, *, lrelu=True, h0=None, xp=None, o=None, masked=False, want_xp=True):
+def stem_pair(x, ws, bs, wo, bo, *, lrelu=True, h0=None, xp=None, o=None, masked=False, want_xp=True, want_mask=False):
     """Critic input while a block fades in (discriminator.py:107-113): h0 = act(ws x + bs), xp = AvgPool2d(x), o = act(wo xp + bo).
     `masked`: the tangent form -- h0 / o hold the forward activations and receive (w x) * lrelu'(activation) in place."""
     _chk(x, ws, bs, wo, bo, h0, xp, o)
@@ -586,9 +598,10 @@ def stem_pair(x, ws, bs, wo, bo, *, lrelu=True, h0=None, xp=None, o=None, masked
     if xp is None and want_xp:
         xp = new(2, h // 2, w // 2)
     flags = MG_C1_MASK_AUX if masked else (MG_C1_LRELU if lrelu else 0)
-    check(_lib.load().mg_stem_pair(_p(x), _p(ws), _p(bs), _p(wo), _p(bo), _p(h0), _p(xp), _p(o), n, c0, c1, h, w, flags, SLOPE, _s()),
-          "mg_stem_pair")
-    return h0, xp, o
+    hm = torch.empty((n, c0, h // 2, w // 2), dtype=torch.uint8, device=x.device) if (want_mask and not masked) else None
+    check(_lib.load().mg_stem_pair(_p(x), _p(ws), _p(bs), _p(wo), _p(bo), _p(h0), _p(xp), _p(o), _p(hm), n, c0, c1, h, w, flags, SLOPE,
+                                   _s()), "mg_stem_pair")
+    return (h0, xp, o, hm) if want_mask else (h0, xp, o)
 
 
 def stem_pair_gx(gs, ws, go, wo, out=None):

@@ -40,6 +40,10 @@ def test_stem_pair_forward_and_tangent(shape):
     # the separate kernels give the same values (one fused multiply-add chain per output either way)
     h0_s = ops.conv1x1(to(x), to(ws), to(bs), c0, lrelu=True)
     assert torch.equal(h0, h0_s)
+    # the optional tile mask of h0: one byte per 2x2 tile, bit 2i+j <-> h0[2Y+i][2X+j] > 0 (mg_wino3x3's format)
+    h0_m, _, _, hm = ops.stem_pair(to(x), to(ws), to(bs), to(wo), to(bo), want_mask=True)
+    b = (h0_m > 0).reshape(n, c0, h // 2, 2, w // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, c0, h // 2, w // 2, 4).to(torch.uint8)
+    assert torch.equal(h0_m, h0) and torch.equal(hm, b[..., 0] + 2 * b[..., 1] + 4 * b[..., 2] + 8 * b[..., 3])
     # tangent form: (w u) * lrelu'(activation), over the activations
     u = torch.randn(n, 2, h, w, generator=g)
     ref_t = F.conv2d(u.double(), ws.double()) * torch.where(ref_h0 > 0, 1.0, SLOPE)

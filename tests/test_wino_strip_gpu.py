@@ -40,6 +40,10 @@ def _all_kinds(ops, x, wt, b, gy, act_out, act_up, other, coef):
     out["tangent_fp32_in_place"] = ops.conv3x3(x, None, None, co, mask_aux=buf, out=buf, pool=True, wino=up)
     out["dgrad_mask"] = (ops.conv3x3(gy, None, None, ci, mask_aux=x, wino=upd),)
     out["dgrad_unpool"] = (ops.conv3x3(gy, None, None, ci, wino=upd, unpool_mask=_tile_mask(act_up)),)
+    # the LeakyReLU mask as tile bytes on a full-resolution result: a strip-kernel epilogue; the staged kernel takes the fp32 mask
+    n_, _, h_, w_ = gy.shape
+    bytes_ok = ops.wino3x3_mask_bytes_y_supported(n_, co, ci, h_, w_)
+    out["dgrad_mask_bytes"] = (ops.conv3x3(gy, None, None, ci, mask_aux=_tile_mask(x) if bytes_ok else x, wino=upd),)
     out["fade_fwd"] = ops.conv3x3_fade(x, up, b, co, _lib.MG_FADE_FWD, other, coef)
     out["fade_tangent"] = (ops.conv3x3_fade(x, up, None, co, _lib.MG_FADE_TANGENT, other, coef, mask_in=m_out),)
     out["fade_bwd"] = ops.conv3x3_fade(gy, upd, None, ci, _lib.MG_FADE_BWD, x, coef, mask_in=_tile_mask(x))
@@ -121,3 +125,6 @@ def test_strip_kernel_against_fp64_at_level_6_7_shapes(shape, monkeypatch):
     refd = F.conv_transpose2d(gy.double(), wt.double(), padding=1) * torch.where(x > 0, 1.0, 0.2).double()
     gx = ops.conv3x3(gy.to(DEV), None, None, ci, mask_aux=x.to(DEV), wino=ops.pack_wino3x3(wt.to(DEV), dgrad=True))
     assert float((gx.double().cpu() - refd).abs().max()) <= 2e-6 * float(refd.abs().max())
+    # the same with the mask as one byte per 2x2 tile (what the critic keeps of its stem's output): the same bits
+    gxb = ops.conv3x3(gy.to(DEV), None, None, ci, mask_aux=_tile_mask(x.to(DEV)), wino=ops.pack_wino3x3(wt.to(DEV), dgrad=True))
+    assert torch.equal(gx, gxb)
