@@ -909,7 +909,8 @@ int launch_ww(const WwArgs& a, dim3 grid, hipStream_t s) {
 
 // the scalar-addressed form (ww_body FAST): chunks of 8 x 1 x 1 tiles, whole chunks per tile row; MG_WGRAD_FAST=0: never
 bool ww_fast(const WwArgs& a) {
-  static const bool on = getenv("MG_WGRAD_FAST") == nullptr || atoi(getenv("MG_WGRAD_FAST")) != 0;
+  const char* e = getenv("MG_WGRAD_FAST");  // (read per call: tests and A/B runs switch it inside one process)
+  const bool on = e == nullptr || atoi(e) != 0;
   return on && a.TBW == 8 && a.TBH == 1 && a.TBN == 1 && (a.W % 16) == 0;
 }
 

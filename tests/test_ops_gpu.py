@@ -545,6 +545,26 @@ def test_wino_wgrad_matches_autograd(shape, monkeypatch):
     report("wino vs direct wgrad", gw2, gwd.double(), 3e-6)
 
 
+@pytest.mark.parametrize("case", [(3, 16, 32, 64, 64, False, 2), (2, 48, 64, 32, 48, False, 0), (5, 96, 80, 16, 16, False, 3),
+                                  (2, 32, 16, 64, 32, True, 0), (3, 64, 48, 32, 32, True, 1), (1, 112, 96, 16, 32, False, 0)])
+def test_wino_wgrad_scalar_addressed_loads_equal_the_general_form(case, monkeypatch):
+    """(N, Cin, Cout, H, W, ups, bias_n): on maps at least 16 wide the weight-gradient kernels address their loads per chunk instead of
+    per lane (wino_wgrad.hip, FAST); the loads fetch the same values, so every sum has the same bits as with MG_WGRAD_FAST=0."""
+    ops = _ops()
+    monkeypatch.setenv("MG_WINO_WGRAD_MIN_PIXELS", "1")
+    n, ci, co, h, w, ups, bias_n = case
+    g = torch.Generator(device=DEV).manual_seed(17)
+    x = torch.randn(n, ci, h // 2 if ups else h, w // 2 if ups else w, device=DEV, generator=g)
+    gy = torch.randn(n, co, h, w, device=DEV, generator=g)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MG_WGRAD_FAST", mode)
+        gw, gb = torch.empty(co, ci, 3, 3, device=DEV), torch.empty(co, device=DEV)
+        ops.conv3x3_wgrad(x, gy, gw, gb, ups=ups, bias_n=bias_n)
+        res[mode] = (gw, gb)
+    assert torch.equal(res["0"][0], res["1"][0]) and torch.equal(res["0"][1], res["1"][1])
+
+
 def test_blend_lrelu_bwd_equals_the_four_kernels_it_replaces():
     ops = _ops()
     g = torch.Generator().manual_seed(41)
