@@ -107,9 +107,11 @@ def test_conv1x1_accumulate():
 
 
 @pytest.mark.parametrize("case", [(24, 2, 48, 32, 32, 16), (8, 160, 2, 8, 8, 0), (6, 2, 16, 64, 64, 4), (3, 80, 2, 16, 16, 0)])
-def test_conv1x1_wgrad_single_launch(case):
-    """(N, Cin, Cout, H, W, bias_n): up to 64 workgroup columns take the single-launch form (the last workgroup sums the partials);
-    the same launch twenty times gives the same bits (the ticket counter returns to zero, the order of the sums is fixed)."""
+def test_conv1x1_wgrad_single_launch(case, monkeypatch):
+    """(N, Cin, Cout, H, W, bias_n): the opt-in single-launch form (MG_C1_WGRAD_SINGLE=1, up to 64 workgroup columns: the last workgroup
+    sums the partials); the same launch twenty times gives the same bits (the ticket counter returns to zero, the order of the sums is
+    fixed)."""
+    monkeypatch.setenv("MG_C1_WGRAD_SINGLE", "1")
     ops = _ops()
     n, cin, cout, h, w, bias_n = case
     g = torch.Generator().manual_seed(8)
