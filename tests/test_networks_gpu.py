@@ -283,7 +283,7 @@ def _oracle_full_step(level, batch):
     return _ORACLE_CACHE[key]
 
 
-@pytest.mark.parametrize("level,batch", [(5, 2), (4, 32), (6, 1), (7, 1), (5, 16)])
+@pytest.mark.parametrize("level,batch", [(5, 2), (4, 32), (6, 1), (7, 1), (5, 16), (3, 8), (6, 6)])
 def test_full_size_step_against_fp64_oracle(level, batch, conv_mode):
     """BASELINE.json's shapes against the ORACLE (not against another HIP path): the headline level 5 (2x128x128; batch 2 -- the
     critic then runs on 6 images, every kernel on the tiling it uses at batch 64 -- and batch 16: 48 images through the critic),
