@@ -34,7 +34,7 @@ def gen_conv_form(n: int, cin: int, cout: int, h: int, wd: int, ups: bool) -> st
     ho, wo = (2 * h, 2 * wd) if ups else (h, wd)
     if n * ho * wo < int(os.environ.get("MG_PN_FUSE_MIN_PIXELS", "16384")):
         return "conv+pixnorm"
-    if ups and n * h * wd < int(os.environ.get("MG_UPCONV_MIN_LOWRES_PIXELS", "32768")) and \
+    if ups and n * h * wd < int(os.environ.get("MG_UPCONV_MIN_LOWRES_PIXELS", "16384")) and \
             ops.wino3x3_supported(n, cout, ho, wo, cin=cin):
         return "upsample+wino+pixnorm"
     if not ups and cout > 64 and os.environ.get("MG_PN_WIDE_UNFUSED", "1") == "1" and \
