@@ -714,10 +714,8 @@ int mgi_wino_strip_run(WinoArgs& a, hipStream_t s) {
   const int niw = strip_plan(a, kind == SK_PN, e != nullptr && atoi(e) > 1);
   dim3 grid(1, mg_cdiv(nt, niw));  // (an odd tile count: the last workgroup row carries one padding tile of zero filters)
   switch (niw) {
-    case 1: {
-      const int nw1 = getenv("MG_WINO_STRIP_NW1") ? atoi(getenv("MG_WINO_STRIP_NW1")) : 8;
-      return nw1 == 4 ? launch_strip_kind<1, 4>(a, kind, grid, s) : launch_strip_kind<1, 8>(a, kind, grid, s);
-    }
+    case 1: return launch_strip_kind<1, 8>(a, kind, grid, s);  // (four-wave workgroups, i.e. up to four waves per SIMD: no effect,
+                                                               //  profiles/r05_ab_wino_strip_nt1_occupancy.txt)
     case 2: return launch_strip_kind<2, 8>(a, kind, grid, s);
     default: return launch_strip_kind<3, 4>(a, kind, grid, s);
   }

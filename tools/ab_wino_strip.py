@@ -78,12 +78,10 @@ VARIANTS = ["0", "2"] + [v for v in sys.argv[1:] if v.startswith("2")]
 
 def setenv(v):
     os.environ["MG_WINO_STRIP"] = v[0]
-    for k in ("MG_WINO_STRIP_NIW", "MG_WINO_STRIP_WGS", "MG_WINO_STRIP_NW1"):
+    for k in ("MG_WINO_STRIP_NIW", "MG_WINO_STRIP_WGS"):
         os.environ.pop(k, None)
     if "n" in v:
         os.environ["MG_WINO_STRIP_NIW"] = v[v.index("n") + 1]
-    if "q" in v:  # waves per workgroup of the one-tile kernels
-        os.environ["MG_WINO_STRIP_NW1"] = v[v.index("q") + 1]
     if "w" in v:
         os.environ["MG_WINO_STRIP_WGS"] = v[v.index("w") + 1]
 
