@@ -710,9 +710,10 @@ def main():
             # (l4: long enough to be past the transient that follows the level-5 run -- measured straight after it, the first 30
             # level-4 steps take 5.3 ms, a run on its own, 50 or 3 000 steps, 4.58)
             line["l4_bs32"] = level_record(device, args.rand_channels, 4, 32, 100, 60, "BASELINE.json configs[1]")
-            line["l6_bs6"] = level_record(device, args.rand_channels, 6, 6, 40, 10, "the reference's batch, train.py:43")
-            line["l7_bs6"] = level_record(device, args.rand_channels, 7, 6, 30, 10, "the reference's batch, train.py:43")
-            line["l7_bs16"] = level_record(device, args.rand_channels, 7, 16, 20, 6, "final level, larger batch")
+            # (levels 6-7 likewise: 30 steps straight after the previous record read 7.26 ms where a 160-step run on the same box gives 7.16)
+            line["l6_bs6"] = level_record(device, args.rand_channels, 6, 6, 100, 40, "the reference's batch, train.py:43")
+            line["l7_bs6"] = level_record(device, args.rand_channels, 7, 6, 80, 40, "the reference's batch, train.py:43")
+            line["l7_bs16"] = level_record(device, args.rand_channels, 7, 16, 40, 20, "final level, larger batch")
             line["l3_bs8"] = level_record(device, args.rand_channels, 3, 8, 100, 30, "BASELINE.json configs[0], on the GPU")
             line["stft"] = stft_record(device, cpu=False)
             line.update(create_dataset_and_train_records(device, args.rand_channels))
