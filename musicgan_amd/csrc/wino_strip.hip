@@ -1,6 +1,6 @@
-// Winograd F(2x2,3x3) convolution for the FEW-CHANNEL layers on large maps (16 .. 48 channels at 128x128 .. 512x512: where the
-// reference trains, batch 6 at levels 6-7 -- /root/reference/music_gan/networks/generator.py:67-76, discriminator.py:60-70,
-// train.py:43,101-109).  Same arithmetic and the same packed filters as wino3x3.hip, bit for bit the same results; what differs
+// Winograd F(2x2,3x3) convolution with one wave per tile block.  Written for the FEW-CHANNEL layers on large maps (16 .. 48 channels at
+// 128x128 .. 512x512: where the reference trains, batch 6 at levels 6-7 -- /root/reference/music_gan/networks/generator.py:67-76,
+// discriminator.py:60-70, train.py:43,101-109), it now carries every layer of 16 .. 160 out-channels from 2 048 tile blocks on.  Same arithmetic and the same packed filters as wino3x3.hip, bit for bit the same results; what differs
 // is who builds the operands and what the vector unit has to do besides.  On gfx950 an fp32 MFMA and a vector instruction
 // cost the SAME issue slots (157.3 TFLOP/s is also the v_pk_fma_f32 peak, and the two add up: profiles/r01_hw_valu_under_mfma.txt),
 // so a layer with 2-6 channel chunks per tile block is bound by its vector instructions: wino3x3.hip spends 8.8-10 of them per MFMA
@@ -8,12 +8,13 @@
 //   * the whole transformed filter bank of the workgroup's out-channels sits in LDS for the workgroup's lifetime (one copy at
 //     start, 8 KB per 8-channel chunk and 16 out-channels; persistent workgroups, one per CU);
 //   * ONE WAVE owns a tile block -- 16 horizontally adjacent tiles x all input channels x NIW x 16 out-channels -- and there is
-//     no barrier after the start: lane (rq, col) loads the 4x4 patch of tile `col` for channel 8 ch + 2 rq + ks straight from
-//     global memory (own pixel pair per row as one 8-byte load, 128 contiguous bytes per 16 lanes; the halo columns as two 4-byte
-//     loads whose offsets are out of range where the image ends, so that the hardware bounds check returns the zero padding),
-//     transforms it IN REGISTERS with 16 packed adds, and the 16 components are exactly the B operand of
-//     v_mfma_f32_16x16x4_f32 for k-index rq -- the activations never touch LDS, no lane exchanges, no selects;
-//   * shapes are restricted to what those layers have (W a multiple of 32, Cout of 16, Cin of 8), so a tile block is valid or not
+//     no barrier after the start: lane (rq, col) holds the 4x4 patch of tile `col` for channel 8 ch + 2 rq + ks -- its own pixel pair
+//     per row straight from global memory (one 8-byte load, 128 contiguous bytes per 16 lanes), the two halo columns from the
+//     neighbouring lanes' pairs by DPP; only lanes 0 and 15 of a 16-lane row fetch the one halo pixel that belongs to the next tile
+//     block (a 4-byte load whose offset is out of range for every other lane and where the image ends: the hardware bounds check
+//     returns the zero padding without an access) -- transforms it IN REGISTERS with 16 packed adds, and the 16 components are
+//     exactly the B operand of v_mfma_f32_16x16x4_f32 for k-index rq: the activations never touch LDS, no selects;
+//   * shapes are restricted to what those layers have (W a multiple of 32, Cout and Cin of 16), so a tile block is valid or not
 //     as a whole (one scalar branch) and every global access is a buffer access: 32-bit lane offset computed once per block +
 //     scalar offset per plane / row;
 //   * each epilogue kind is written for its own outputs: packed output transform, LeakyReLU mask bits by integer clamps of the
