@@ -738,6 +738,424 @@ __global__ void __launch_bounds__(512, 4) wino_wgrad_narrow_mfma(const WwArgs a)
   if (cb == 0 && t == 0 && ys >= 0 && ys < OT * 16 && o0 + ys < a.CoutP) a.slab_b[(size_t)split * a.CoutP + o0 + ys] = bsum;
 }
 
+// ---- row-staged form (round 6): the operands are transformed IN REGISTERS, in MFMA operand layout, from RAW rows that the memory
+// system writes straight into LDS (LDS-DMA, `buffer_load_dwordx4 ... lds`).
+// The two kernels above transform on the way INTO LDS: a thread owns a (tile, channel) item, computes all 16 Winograd components of it
+// and scatters them over eight component-pair images (64 B per item and operand), so a stage holds only 8 tiles, every 8 tiles cost a
+// workgroup barrier, and the per-item work (halo exchange by DPP + selects, 16 packed adds, 8 LDS writes, the loads' address
+// arithmetic) is 1.6 vector + 1.7 scalar instructions per MFMA on the widest block shape and 3.7 + 4.2 on the narrow ones
+// (profiles/r06_pmc_w20n_base.txt, r06_pmc_ww16_base.txt: 64 % of the wave cycles waiting).  Here
+//   * a stage is 16 horizontally adjacent tiles (one k-step = 4 tiles, 4 k-steps) of all channels of the block as RAW pixels:
+//     x rows 2by-1 .. 2by+2, pixels -1 .. 34 of the stage (nine 16-byte pieces per row), gy rows 2by, 2by+1 (eight pieces) -- 8 bytes
+//     per item and row instead of 64: half the barriers in 45 % of the LDS.  The stage image is a sequence of 16-byte pieces and wave
+//     w copies pieces 64 (w + 8 m) .. + 63 with ONE LDS-DMA instruction per m (5-7 per wave and stage): no staging registers, no LDS
+//     store instructions (`ds_write_b128` moves 79 B per clock: measured, the register-staged version of this kernel spent 12 % of
+//     its time in them and another 13 % around the loads), lane offsets fixed for the kernel, the stage in a scalar offset.  Pieces of
+//     rows above / below the image, of channels beyond the tensor and the padding pieces have an out-of-range offset: the bounds
+//     check writes ZEROS for them, per dword (tools/hwtests/lds_dma_oob.hip), which is also what clips the last row's pixels behind the
+//     tensor's end.  Pixel -1 of a row's first stage and pixel 32 of its last one are fetched (they exist: the neighbouring row's) and
+//     overwritten with zeros by the wave that copied them; x[-1] itself, before the tensor, is never touched (the first stage's first
+//     piece is patched from pixel 0 on);
+//   * an x row is stored from pixel -1 on, so the 4-pixel patch row of tile T (pixels 2T-1 .. 2T+2) starts at an even word:
+//     [e0, p0 | p1, e1]; wave w owns component pair w as before -- row i = w / 2 of the component matrix, columns (0, 3) for even and
+//     (1, 2) for odd w -- and lane (rq, col) reads, for tile 4 ks + rq and channel 16 i + col, exactly the TWO patch rows its component
+//     row needs (B^T d: d0 - d2, d1 + d2, d2 - d1, d1 - d3): two packed adds for the row step, and the column step is ONE packed add of
+//     the two halves -- (u0 - u2, u1 - u3) = (v0, v3) for even waves, (u1 + u2, u2 - u1) = (v1, v2) for odd ones -- whose result IS the
+//     A operand pair; the gy side is 0-2 packed adds per out-channel tile (A t A^T: row i is t0, t0 + t1, t0 - t1 or t1; the signs of
+//     the components that carry a minus are applied once, to the accumulators, after the tile loop);
+//   * nothing else in the loop: no DPP, no selects, no per-lane address arithmetic (LDS offsets are immediates);
+//   * every operand read is a `ds_read_b64` (two 32-lane groups, bank = word mod 64, 256 B per clock): lane (rq, col) reads words
+//     col * stride + 2 rq + {0, 1}, so channel strides of 4 x odd modulo 64 (148, 68 words) give the 16 channels x 2 tiles of a group
+//     64 different banks.  The reads are inline assembly: hipcc merges adjacent 8-byte LDS reads into `ds_read2_b64`, which this LDS
+//     serves at HALF the rate with banks modulo 32 (MI355X_MICROARCH.md, LDS).  Measured on the way (profiles/r06_wgrad_rows_steps.txt,
+//     48 x 64 @128 x 192 images, chunk-staged kernel 914 us): strides of 16 modulo 64 with 4-byte halo reads 1 306 us
+//     (SQ_LDS_BANK_CONFLICT 84 % of the LDS cycles); 16-byte patch rows as ds_read2_b64 on strides of 24 / 8: 1 075 us (72 %).
+// Each wave runs ONE of eight specialisations of the tile loop (component row x parity), chosen once; all of them execute the
+// same barriers.  Accumulator layout, G^T M G slab pass and reduce kernel are those of wino_wgrad_mfma.
+constexpr int RW_RS = 36;              // words per staged x row: pixel p (-1 .. 34) at word p + 1 = 9 pieces
+constexpr int RW_CSX = 4 * RW_RS + 4;  // words per x channel (4 rows + one padding piece = 37 pieces); 148 = 4 * 5 mod 64
+constexpr int RW_CSY = 68;             // words per gy channel: 2 rows x 32 pixels + one padding piece = 17 pieces (= 4 mod 64)
+
+template <int CT, int OT>
+struct RwGeom {
+  static constexpr int XI = (16 * CT * 37 + 63) / 64;  // LDS-DMA instructions (64 pieces each) of the x part, of the gy part
+  static constexpr int YI = (16 * OT * 17 + 63) / 64;
+  static constexpr int NI = XI + YI;
+  static constexpr int NM = (NI + 7) / 8;  // per wave
+  static constexpr int YB = XI * 256;      // words
+  static constexpr int STG = NI * 256;
+  static constexpr size_t lds_bytes() {
+    const size_t stages = (size_t)2 * STG * sizeof(float), slab = (size_t)16 * 32 * 64 * sizeof(float);
+    return stages > slab ? stages : slab;
+  }
+};
+
+template <class F, int... Is>
+__device__ __forceinline__ void rw_static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void rw_static_for(F&& f) {
+  rw_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+// 8 bytes of LDS at byte address `addr` + OFF.  NOT tracked by hipcc's s_waitcnt insertion: rw_lds_wait() before the first use.
+template <int OFF>
+__device__ __forceinline__ f32x2 rw_lds64(unsigned addr) {
+  f32x2 v;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+__device__ __forceinline__ void rw_lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void rw_tie(f32x2& v) { asm volatile("" : "+v"(v)); }  // orders the uses of v behind the wait
+typedef __attribute__((address_space(3))) void* rw_lds_ptr;
+
+template <int CT, int OT>
+__global__ void __launch_bounds__(512) wino_wgrad_rows_mfma(const WwArgs a) {
+  using GEO = RwGeom<CT, OT>;
+  constexpr int YB = GEO::YB, STG = GEO::STG, XI = GEO::XI, NI = GEO::NI, NM = GEO::NM;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = component pair
+  const int col = lane & 15, rq = lane >> 4;
+  const int split = blockIdx.x;
+  const int cb = blockIdx.y / a.nob, ob = blockIdx.y % a.nob;
+  const int c0 = cb * CT * 16, o0 = ob * OT * 16;
+  const int HW = a.H * a.W;
+  const int Ht = a.H >> 1;
+  constexpr unsigned INV = 0x80000000u;
+
+  // ---- loader: slot m of this wave is LDS-DMA instruction k = wave + 8 m of a stage, this lane's piece P = 64 k + lane.
+  // x part (k < XI): P = 37 ch + 9 r + seg -- pixels 4 seg - 1 .. 4 seg + 2 of patch row r of channel ch (P mod 37 = 36: padding);
+  // gy part: P - 64 XI = 17 ch + 8 r + seg.  x is addressed relative to x - (W + 4) floats, so that row -1 and pixel -1 have
+  // non-negative offsets.  voff[m]: byte offset of the piece inside a stage, INV = write zeros.  cls: per slot, bit 4m: the piece is
+  // patch row 0 (outside the image in the top tile row), 4m+1: patch row 3 (bottom), 4m+2: its first word is pixel -1, 4m+3: its
+  // second word is pixel 32.
+  unsigned voff[NM];
+  unsigned cls = 0;
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    const int k = wave + 8 * m;
+    const int P = 64 * k + lane;
+    unsigned v = INV;
+    if (k < XI) {
+      const int ch = P / 37, rem = P - 37 * ch, r = rem / 9, sg = rem - 9 * r;
+      if (ch < 16 * CT && rem < 36 && c0 + ch < a.Cin) {
+        v = (unsigned)((ch * HW + r * a.W + 4 * sg + 3) * 4);
+        cls |= (unsigned)(r == 0) << (4 * m) | (unsigned)(r == 3) << (4 * m + 1) | (unsigned)(sg == 0) << (4 * m + 2) | (unsigned)(sg == 8) << (4 * m + 3);
+      }
+    } else if (k < NI) {
+      const int Q = P - 64 * XI;
+      const int ch = Q / 17, rem = Q - 17 * ch, r = rem >> 3, sg = rem & 7;
+      if (ch < 16 * OT && rem < 16 && o0 + ch < a.Cout) v = (unsigned)((ch * HW + r * a.W + 4 * sg) * 4);
+    }
+    voff[m] = v;
+  }
+  const unsigned xshift = (unsigned)(a.W + 4) * 4u;
+  const char* xbase = reinterpret_cast<const char*>(a.x) - xshift;
+  // the piece that begins at x[-1]: channel 0, patch row 1, piece 0 of the tensor's first stage = lane 9 of wave 0's slot 0
+  const bool own_first = split == 0 && c0 == 0 && wave == 0;
+
+  bool zl = false, zr = false;  // the stage copied last begins / ends at the image's left / right edge
+  int nq = 0, bx, by, bn;
+  {
+    const int b0 = split * a.per;
+    bx = b0 % a.blocks_x;
+    const int t2 = b0 / a.blocks_x;
+    by = t2 % a.blocks_y;
+    bn = t2 / a.blocks_y;
+  }
+  // the slab's next stage -> LDS at word offset so (asynchronous: rw_landed() before the barrier that precedes its first read)
+  auto issue_stage = [&](int so) __attribute__((always_inline)) {
+    const bool ok = nq < a.per && split * a.per + nq < a.nblk;
+    const bool top = by == 0, bot = by == Ht - 1;
+    const __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xbase), 0, ok ? (int)(a.x_bytes + xshift) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gy), 0, ok ? (int)a.gy_bytes : 0, 0x00020000);
+    int sx = ((bn * a.Cin + c0) * HW + 2 * by * a.W + 32 * bx) * 4;
+    int sy = ((bn * a.Cout + o0) * HW + 2 * by * a.W + 32 * bx) * 4;
+    if (a.TBN & 16) { sx = (c0 * HW + (2 + (split & 31) * 2) * a.W) * 4; sy = (o0 * HW + (2 + (split & 31) * 2) * a.W) * 4; }  // (rows >= 1: inside the tensor)
+    const bool patch = own_first && nq == 0;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+      const int k = wave + 8 * m;
+      if (k < NI) {  // (wave-uniform)
+        float* dst = smem + so + 256 * k;
+        if (k < XI) {
+          unsigned v = voff[m];
+          if (top || bot || patch) {  // (wave-uniform; the common stage takes the offsets as they are)
+            const bool kill = (top && ((cls >> (4 * m)) & 1u)) || (bot && ((cls >> (4 * m + 1)) & 1u)) || (patch && m == 0 && lane == 9);
+            v = kill ? INV : v;
+          }
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xs, (rw_lds_ptr)dst, 16, (int)v, sx, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(ys, (rw_lds_ptr)dst, 16, (int)voff[m], sy, 0, 0);
+        }
+      }
+    }
+    zl = bx == 0;
+    zr = bx == a.blocks_x - 1;
+    ++nq;
+    ++bx;
+    const int wx = bx == a.blocks_x ? 1 : 0;
+    bx = wx ? 0 : bx;
+    by += wx;
+    const int wy = by == a.blocks_y ? 1 : 0;
+    by = wy ? 0 : by;
+    bn += wy;
+  };
+  // the stage at word offset so has landed (this wave's pieces): zero the pixels beside the image that this wave copied
+  auto landed = [&](int so) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (zl || zr) {  // (wave-uniform)
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        const int k = wave + 8 * m;
+        if (k < XI) {
+          float* pc = smem + so + 256 * k + 4 * lane;
+          if (zl && ((cls >> (4 * m + 2)) & 1u)) pc[0] = 0.f;
+          if (zr && ((cls >> (4 * m + 3)) & 1u)) pc[1] = 0.f;
+        }
+      }
+    }
+  };
+
+  f32x4 acc[2][CT][OT];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+      for (int j = 0; j < OT; ++j) acc[p][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[OT];
+#pragma unroll
+  for (int j = 0; j < OT; ++j) bsum[j] = 0.f;
+
+  // LDS byte addresses of this lane's operand reads (the low 32 bits of a shared-aperture address are the LDS offset)
+  const unsigned xrd_a = (unsigned)reinterpret_cast<size_t>(smem + col * RW_CSX + 2 * rq);       // + 16 i CSX + row RS + 8 ks: [e0, p0 | p1, e1] of tile 4 ks + rq
+  const unsigned yrd_a = (unsigned)reinterpret_cast<size_t>(smem + YB + col * RW_CSY + 2 * rq);  // + 16 j CSY + row 32 + 8 ks: (t.0, t.1)
+
+  auto tile_loop = [&](auto i_, auto odd_) __attribute__((always_inline)) {
+    constexpr int I = decltype(i_)::value;
+    constexpr bool ODD = decltype(odd_)::value;
+    constexpr int RA = I == 0 ? 0 : (I == 2 ? 2 : 1), RB = I == 0 ? 2 : (I == 1 ? 2 : (I == 2 ? 1 : 3));  // u = d[RA] +- d[RB]
+    constexpr bool PLUS = I == 1;
+    constexpr bool Y0 = I != 3, Y1 = I != 0;  // which gy rows the component row needs
+    struct Raw {
+      f32x2 al[CT], ah[CT], bl[CT], bh[CT], t0[OT], t1[OT];  // rows RA / RB as (e0, p0) | (p1, e1); gy rows
+    };
+    auto read_raw = [&](Raw& r, unsigned xa, unsigned ya, auto ks_) __attribute__((always_inline)) {
+      constexpr int KS = decltype(ks_)::value;
+      rw_static_for<CT>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int o = (16 * i * RW_CSX + 8 * KS) * 4;
+        r.al[i] = rw_lds64<o + RA * RW_RS * 4>(xa);
+        r.ah[i] = rw_lds64<o + RA * RW_RS * 4 + 8>(xa);
+        r.bl[i] = rw_lds64<o + RB * RW_RS * 4>(xa);
+        r.bh[i] = rw_lds64<o + RB * RW_RS * 4 + 8>(xa);
+      });
+      rw_static_for<OT>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int o = (16 * j * RW_CSY + 8 * KS) * 4;
+        if constexpr (Y0) r.t0[j] = rw_lds64<o>(ya);
+        if constexpr (Y1) r.t1[j] = rw_lds64<o + 128>(ya);
+      });
+    };
+    auto wait_raw = [&](Raw& r) __attribute__((always_inline)) {
+      rw_lds_wait();
+#pragma unroll
+      for (int i = 0; i < CT; ++i) { rw_tie(r.al[i]); rw_tie(r.ah[i]); rw_tie(r.bl[i]); rw_tie(r.bh[i]); }
+#pragma unroll
+      for (int j = 0; j < OT; ++j) {
+        if constexpr (Y0) rw_tie(r.t0[j]);
+        if constexpr (Y1) rw_tie(r.t1[j]);
+      }
+    };
+    // raw rows -> MFMA operands: av[i] = the wave's two x components of channel tile i, bv[j] = its two gy components (unsigned)
+    auto transform = [&](const Raw& r, f32x2 (&av)[CT], f32x2 (&bv)[OT], bool bias_on) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < CT; ++i) {
+        const f32x2 ul = PLUS ? r.al[i] + r.bl[i] : pk_sub(r.al[i], r.bl[i]);  // (u0, u1)
+        const f32x2 uh = PLUS ? r.ah[i] + r.bh[i] : pk_sub(r.ah[i], r.bh[i]);  // (u2, u3)
+        if constexpr (!ODD) asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(av[i]) : "v"(ul), "v"(uh));  // (u0 - u2, u1 - u3)
+        else asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[1,0]" : "=v"(av[i]) : "v"(ul), "v"(uh));  // (u1 + u2, u2 - u1)
+      }
+#pragma unroll
+      for (int j = 0; j < OT; ++j) {
+        f32x2 rr;
+        if constexpr (I == 0) rr = r.t0[j];
+        else if constexpr (I == 1) rr = r.t0[j] + r.t1[j];
+        else if constexpr (I == 2) rr = pk_sub(r.t0[j], r.t1[j]);
+        else rr = r.t1[j];
+        if constexpr (I == 1 && !ODD) {
+          if (bias_on) bsum[j] += rr[0] + rr[1];  // t00 + t10 + t01 + t11: the bias gradient rides in wave 2
+        }
+        if constexpr (!ODD) bv[j] = rr;
+        else asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(bv[j]) : "v"(rr));  // (r0 + r1, r0 - r1)
+      }
+    };
+    // (gfx950: registers written by vector instructions inside inline assembly and read as MFMA sources right behind them need wait
+    // states hipcc only inserts for instructions it schedules itself -- wino_strip.hip; the fence names them)
+    auto fence = [&](f32x2 (&av)[CT], f32x2 (&bv)[OT]) __attribute__((always_inline)) {
+      if constexpr (CT == 1) asm volatile("s_nop 1" : "+v"(av[0]));
+      if constexpr (CT == 2) asm volatile("s_nop 1" : "+v"(av[0]), "+v"(av[1]));
+      if constexpr (CT == 3) asm volatile("s_nop 1" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]));
+      if constexpr (CT == 4) asm volatile("s_nop 1" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]));
+      if constexpr (OT == 1) asm volatile("" : "+v"(bv[0]));
+      if constexpr (OT == 2) asm volatile("" : "+v"(bv[0]), "+v"(bv[1]));
+      if constexpr (OT == 3) asm volatile("" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]));
+      if constexpr (OT == 4) asm volatile("" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]));
+    };
+    auto mma = [&](const f32x2 (&av)[CT], const f32x2 (&bv)[OT]) __attribute__((always_inline)) {
+      if (a.TBN & 32) __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+          for (int j = 0; j < OT; ++j) acc[p][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][p], bv[j][p], acc[p][i][j], 0, 0, 0);
+      if (a.TBN & 32) __builtin_amdgcn_s_setprio(0);
+    };
+
+    // pipeline over stages: iteration q requests stage q + 1 into the other buffer, computes stage q from buffer q & 1, waits for
+    // its own pieces of stage q + 1 and meets the other waves at the barrier
+    issue_stage(0);
+    landed(0);
+    if (own_first && lane == 9) {  // x[0 .. 2] of the tensor's first row (the piece itself was zero-filled: it begins at x[-1])
+      smem[RW_RS + 1] = a.x[0];
+      smem[RW_RS + 2] = a.x[1];
+      smem[RW_RS + 3] = a.x[2];
+    }
+    __syncthreads();
+    // the image of the stage being computed (bias gradient: images below bias_n count)
+    const int per_img = a.blocks_x * a.blocks_y;
+    int img = (split * a.per) / per_img, img_left = per_img - (split * a.per) % per_img;
+    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
+    for (int q = 0; q < a.per; ++q) {
+      const int so = (q & 1) * STG, sn = STG - so;
+      const unsigned xa = xrd_a + (unsigned)so * 4u, ya = yrd_a + (unsigned)so * 4u;
+      Raw r0, r1;
+      f32x2 av[CT], bv[OT];
+      // (the scheduling fences keep hipcc from sinking a k-step's MFMAs below the wait for the NEXT k-step's operand reads -- the
+      // reads are opaque to it -- which exposed an LDS round trip per k-step: 859 -> see profiles/r06_wgrad_rows_steps.txt)
+      read_raw(r0, xa, ya, K0{});
+      if (!(a.TBN & 2)) issue_stage(sn);
+      const bool bias_on = img < a.bias_n;
+      wait_raw(r0);
+      transform(r0, av, bv, bias_on);
+      read_raw(r1, xa, ya, K1{});
+      fence(av, bv);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(av, bv);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_raw(r1);
+      transform(r1, av, bv, bias_on);
+      read_raw(r0, xa, ya, K2{});
+      fence(av, bv);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(av, bv);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_raw(r0);
+      transform(r0, av, bv, bias_on);
+      read_raw(r1, xa, ya, K3{});
+      fence(av, bv);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(av, bv);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_raw(r1);
+      transform(r1, av, bv, bias_on);
+      fence(av, bv);
+      mma(av, bv);
+      if (--img_left == 0) { img_left = per_img; ++img; }
+      if (!(a.TBN & 10)) landed(sn);
+      if (!(a.TBN & 4)) __syncthreads();
+    }
+    // signs of the gy components computed unsigned: (i, 3) for i < 3, (3, 0), (3, 1), (3, 2)
+    constexpr float S0 = I == 3 ? -1.f : 1.f;                                // p = 0: column 0 (even) / 1 (odd)
+    constexpr float S1 = ODD ? (I == 3 ? -1.f : 1.f) : (I == 3 ? 1.f : -1.f);  // p = 1: column 3 (even) / 2 (odd)
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+      for (int j = 0; j < OT; ++j) {
+        if constexpr (S0 < 0.f) acc[0][i][j] = -acc[0][i][j];
+        if constexpr (S1 < 0.f) acc[1][i][j] = -acc[1][i][j];
+      }
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+  switch (wave) {
+    case 0: tile_loop(I0{}, std::false_type{}); break;
+    case 1: tile_loop(I0{}, std::true_type{}); break;
+    case 2: tile_loop(I1{}, std::false_type{}); break;
+    case 3: tile_loop(I1{}, std::true_type{}); break;
+    case 4: tile_loop(I2{}, std::false_type{}); break;
+    case 5: tile_loop(I2{}, std::true_type{}); break;
+    case 6: tile_loop(I3{}, std::false_type{}); break;
+    default: tile_loop(I3{}, std::true_type{}); break;
+  }
+
+  // slab of this split: G^T M G per (c, o) -- wino_wgrad_mfma's pass, the same accumulator layout
+  float* G = smem;  // [slot 16][cc 32][o 64]
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = 2 * h + ii;
+        if (i < CT) {
+#pragma unroll
+          for (int j = 0; j < OT; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              G[((2 * wave + p) * 32 + ii * 16 + rq * 4 + g) * 64 + ((j ^ rq) * 16 + col)] = acc[p][i][j][g];
+        }
+      }
+    __syncthreads();
+    constexpr int SL[4] = {0, 2, 3, 1};
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const int cc = (tid >> 6) + 8 * k4;
+      const int ol = tid & 63;
+      const int i = 2 * h + (cc >> 4);
+      const int c = c0 + i * 16 + (cc & 15), o = o0 + ol;
+      if (i < CT && ol < OT * 16 && c < a.CinP && o < a.CoutP) {
+        const int osw = ((ol >> 4) ^ ((cc >> 2) & 3)) * 16 + (ol & 15);
+        float M[4][4];
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+          for (int nu = 0; nu < 4; ++nu) M[xi][nu] = G[((4 * xi + SL[nu]) * 32 + cc) * 64 + osw];
+        float hh[3][4];
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+          hh[0][nu] = M[0][nu] + 0.5f * (M[1][nu] + M[2][nu]);
+          hh[1][nu] = 0.5f * (M[1][nu] - M[2][nu]);
+          hh[2][nu] = 0.5f * (M[1][nu] + M[2][nu]) + M[3][nu];
+        }
+        float* sl = a.slab + (size_t)split * 9 * a.CinP * a.CoutP + (size_t)c * a.CoutP + o;
+        const size_t plane = (size_t)a.CinP * a.CoutP;
+#pragma unroll
+        for (int aa = 0; aa < 3; ++aa) {
+          sl[(size_t)(aa * 3 + 0) * plane] = hh[aa][0] + 0.5f * (hh[aa][1] + hh[aa][2]);
+          sl[(size_t)(aa * 3 + 1) * plane] = 0.5f * (hh[aa][1] - hh[aa][2]);
+          sl[(size_t)(aa * 3 + 2) * plane] = 0.5f * (hh[aa][1] + hh[aa][2]) + hh[aa][3];
+        }
+      }
+    }
+  }
+  // bias gradient: wave 2 holds, per out-channel tile, lane (rq, col) = its tiles' sums of channel 16 j + col
+  if (wave == 2 && cb == 0) {
+#pragma unroll
+    for (int j = 0; j < OT; ++j) {
+      float v = bsum[j];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (rq == 0 && o0 + 16 * j + col < a.CoutP) a.slab_b[(size_t)split * a.CoutP + o0 + 16 * j + col] = v;
+    }
+  }
+}
+
 // Sum the split-K slabs (already transformed to the 9 taps by the partial kernel) in a fixed order.  Block = EL consecutive (c, o)
 // pairs x KL split-lanes, EL * KL = 512 (a thread sums every KL-th split of the 9 taps, four slabs of loads in flight: this is a
 // pure latency problem), LDS-combined as a fixed tree => deterministic.  KL = 8 normally; 32 for the layers with few filter
@@ -852,6 +1270,7 @@ struct WwPlan {
   WwArgs a;
   int CT, OT, ncb, nsplit;
   size_t ws_floats;
+  bool rows = false;  // the row-staged kernel (wino_wgrad_rows_mfma) and its stage geometry
 };
 
 int blocks_of(int tiles) {  // channel tiles -> blocks of <= 4 tiles, balanced
@@ -905,6 +1324,69 @@ int launch_ww(const WwArgs& a, dim3 grid, hipStream_t s) {
   }
   MG_CHECK_LAUNCH("mg_wino3x3_wgrad");
   return MG_OK;
+}
+
+// ---- the row-staged form: stages of 16 x 1 x 1 tiles.  MG_WGRAD_ROWS=0: never; 2: also the narrow block shapes (measurements)
+bool ww_rows_takes(const WwPlan& pl, bool ups) {
+  const char* e = getenv("MG_WGRAD_ROWS");  // (read per call: tests and A/B runs switch it inside one process)
+  const int mode = e == nullptr ? 1 : atoi(e);
+  if (mode == 0 || ups || (pl.a.W % 32) != 0 || (pl.a.H % 2) != 0) return false;
+  return mode >= 2 || pl.CT + pl.OT > 4;
+}
+
+void plan_rows(WwPlan& pl) {
+  WwArgs& a = pl.a;
+  a.TBW = 16; a.TBH = 1; a.TBN = 1; a.lgTBW = 4; a.lgTBH = 0;
+  {
+    const char* e = getenv("MG_WGRAD_ROWS_ABLATE");  // measurement switch (wrong results): 2 = no staging, 4 = no barriers, 8 = staging never waited for, 16 = every stage re-reads the slab's first one
+    if (e != nullptr) a.TBN |= atoi(e) & 62;
+  }
+  a.blocks_x = a.W / 32; a.blocks_y = a.H / 2; a.blocks_n = a.N;
+  a.nblk = a.blocks_x * a.blocks_y * a.blocks_n;
+  const int ny = pl.ncb * a.nob;
+  int ns = mg_cu_count() / ny > 0 ? mg_cu_count() / ny : 1;  // one 8-wave workgroup per CU
+  if (ns > a.nblk) ns = a.nblk;
+  a.per = mg_cdiv(a.nblk, ns);
+  pl.nsplit = mg_cdiv(a.nblk, a.per);
+  pl.ws_floats = (size_t)pl.nsplit * (9 * (size_t)a.CinP * a.CoutP + a.CoutP);
+  a.slab_b = a.slab + (size_t)pl.nsplit * 9 * a.CinP * a.CoutP;
+  pl.rows = true;
+}
+
+template <int CT, int OT>
+int launch_rows(const WwArgs& a, dim3 grid, hipStream_t s) {
+  constexpr size_t lds = RwGeom<CT, OT>::lds_bytes();
+  static MgPerDevice once;
+  if (mg_first_use_on_device(once)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_wgrad_rows_mfma<CT, OT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+  }
+  hipLaunchKernelGGL((wino_wgrad_rows_mfma<CT, OT>), grid, dim3(512), lds, s, a);
+  MG_CHECK_LAUNCH("mg_wino3x3_wgrad (rows)");
+  return MG_OK;
+}
+
+int dispatch_rows(int CT, int OT, const WwArgs& a, dim3 grid, hipStream_t s) {
+  switch (CT * 10 + OT) {
+    case 11: return launch_rows<1, 1>(a, grid, s);
+    case 12: return launch_rows<1, 2>(a, grid, s);
+    case 13: return launch_rows<1, 3>(a, grid, s);
+    case 14: return launch_rows<1, 4>(a, grid, s);
+    case 21: return launch_rows<2, 1>(a, grid, s);
+    case 22: return launch_rows<2, 2>(a, grid, s);
+    case 23: return launch_rows<2, 3>(a, grid, s);
+    case 24: return launch_rows<2, 4>(a, grid, s);
+    case 31: return launch_rows<3, 1>(a, grid, s);
+    case 32: return launch_rows<3, 2>(a, grid, s);
+    case 33: return launch_rows<3, 3>(a, grid, s);
+    case 34: return launch_rows<3, 4>(a, grid, s);
+    case 41: return launch_rows<4, 1>(a, grid, s);
+    case 42: return launch_rows<4, 2>(a, grid, s);
+    case 43: return launch_rows<4, 3>(a, grid, s);
+    case 44: return launch_rows<4, 4>(a, grid, s);
+  }
+  mg_set_error("mg_wino3x3_wgrad: internal tile error (CT=%d, OT=%d)", CT, OT);
+  return MG_EINVAL;
 }
 
 // the scalar-addressed form (ww_body FAST): chunks of 8 x 1 x 1 tiles, whole chunks per tile row; MG_WGRAD_FAST=0: never
@@ -989,6 +1471,7 @@ void fill_job(const WwPlan& pl, float* gw, float* gb, int accumulate, mg_wgrad_j
 
 int launch_single_ww(const WwPlan& pl, bool ups, hipStream_t s) {
   dim3 grid(pl.nsplit, pl.ncb * pl.a.nob);
+  if (pl.rows) return dispatch_rows(pl.CT, pl.OT, pl.a, grid, s);
   return ups ? dispatch_ww<true>(pl.CT, pl.OT, pl.a, grid, s) : dispatch_ww<false>(pl.CT, pl.OT, pl.a, grid, s);
 }
 
@@ -1007,6 +1490,7 @@ extern "C" int mg_wino3x3_wgrad_partial(const float* x, const float* gy, float* 
   WwPlan pl;
   int rc = prepare_ww(x, gy, gw, ws, ws_bytes, N, Cin, Cout, H, W, flags, bias_n, pl);
   if (rc != MG_OK) return rc;
+  if (ww_rows_takes(pl, (flags & MG_CONV_UPS_IN) != 0)) plan_rows(pl);  // (never more splits than the chunk plan the workspace is sized for)
   rc = launch_single_ww(pl, (flags & MG_CONV_UPS_IN) != 0, (hipStream_t)stream);
   if (rc != MG_OK) return rc;
   fill_job(pl, gw, gb, accumulate, job);
@@ -1027,6 +1511,7 @@ extern "C" int mg_wino3x3_wgrad_partial_multi(const mg_wgrad_desc_t* d, int n, i
     const long long work = (long long)pl[i].a.nblk * pl[i].ncb * pl[i].a.nob;  // chunks x channel blocks
     const bool small = group_max_chunks > 0 && ww_groupable(pl[i].CT, pl[i].OT) && work <= (long long)group_max_chunks * n_cu;
     key[i] = small ? (pl[i].CT * 10 + pl[i].OT) * 2 + ((d[i].flags & MG_CONV_UPS_IN) ? 1 : 0) : 0;
+    if (!small && ww_rows_takes(pl[i], (d[i].flags & MG_CONV_UPS_IN) != 0)) plan_rows(pl[i]);
   }
   for (;;) {
     int idx[WW_GROUP], m = 0;

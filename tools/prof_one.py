@@ -17,6 +17,9 @@ elif case == "d20":    # conv 48->64 @128 + lrelu
 elif case == "w20":    # wgrad 48->64 @128
     x = R(N, 48, 128, 128); gy = R(N, 64, 128, 128); gw = torch.empty(64, 48, 3, 3, device=dev); gb = torch.empty(64, device=dev)
     fn = lambda: ops.conv3x3_wgrad(x, gy, gw, gb)
+elif case == "w20n":   # the weight gradient of the step's dominant layer as the critic update runs it: 48 x 64 @128 over 3N = 192 images
+    x = R(3 * N, 48, 128, 128); gy = R(3 * N, 64, 128, 128); gw = torch.empty(64, 48, 3, 3, device=dev); gb = torch.empty(64, device=dev)
+    fn = lambda: ops.conv3x3_wgrad(x, gy, gw, gb)
 elif case == "w54":
     x = R(N, 64, 64, 64); gy = R(N, 48, 128, 128); gw = torch.empty(48, 64, 3, 3, device=dev); gb = torch.empty(48, device=dev)
     fn = lambda: ops.conv3x3_wgrad(x, gy, gw, gb, ups=True)
