@@ -864,33 +864,24 @@ __global__ void __launch_bounds__(512) wino_wgrad_rows_mfma(const WwArgs a) {
     by = t2 % a.blocks_y;
     bn = t2 / a.blocks_y;
   }
-  // the slab's next stage -> LDS at word offset so (asynchronous: rw_landed() before the barrier that precedes its first read)
-  auto issue_stage = [&](int so) __attribute__((always_inline)) {
+  // the slab's next stage -> LDS at word offset so (asynchronous: landed() before the barrier that precedes its first read).  The
+  // stage's 5-7 copy instructions per wave are issued a few at a time (issue_begin, issue_slots<LO, HI>, ...): all 45-54 of a
+  // workgroup in one burst right behind the barrier fill the CU's memory pipeline, and every wave sits at its last copy instruction
+  // instead of issuing MFMAs (measured: the burst cost 13 % of the kernel's cycles).
+  __amdgpu_buffer_rsrc_t st_xs, st_ys;
+  int st_sx = 0, st_sy = 0, st_so = 0;
+  bool st_top = false, st_bot = false, st_patch = false;
+  auto issue_begin = [&](int so) __attribute__((always_inline)) {
     const bool ok = nq < a.per && split * a.per + nq < a.nblk;
-    const bool top = by == 0, bot = by == Ht - 1;
-    const __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xbase), 0, ok ? (int)(a.x_bytes + xshift) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gy), 0, ok ? (int)a.gy_bytes : 0, 0x00020000);
-    int sx = ((bn * a.Cin + c0) * HW + 2 * by * a.W + 32 * bx) * 4;
-    int sy = ((bn * a.Cout + o0) * HW + 2 * by * a.W + 32 * bx) * 4;
-    if (a.TBN & 16) { sx = (c0 * HW + (2 + (split & 31) * 2) * a.W) * 4; sy = (o0 * HW + (2 + (split & 31) * 2) * a.W) * 4; }  // (rows >= 1: inside the tensor)
-    const bool patch = own_first && nq == 0;
-#pragma unroll
-    for (int m = 0; m < NM; ++m) {
-      const int k = wave + 8 * m;
-      if (k < NI) {  // (wave-uniform)
-        float* dst = smem + so + 256 * k;
-        if (k < XI) {
-          unsigned v = voff[m];
-          if (top || bot || patch) {  // (wave-uniform; the common stage takes the offsets as they are)
-            const bool kill = (top && ((cls >> (4 * m)) & 1u)) || (bot && ((cls >> (4 * m + 1)) & 1u)) || (patch && m == 0 && lane == 9);
-            v = kill ? INV : v;
-          }
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(xs, (rw_lds_ptr)dst, 16, (int)v, sx, 0, 0);
-        } else {
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(ys, (rw_lds_ptr)dst, 16, (int)voff[m], sy, 0, 0);
-        }
-      }
-    }
+    st_top = by == 0;
+    st_bot = by == Ht - 1;
+    st_xs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xbase), 0, ok ? (int)(a.x_bytes + xshift) : 0, 0x00020000);
+    st_ys = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gy), 0, ok ? (int)a.gy_bytes : 0, 0x00020000);
+    st_sx = ((bn * a.Cin + c0) * HW + 2 * by * a.W + 32 * bx) * 4;
+    st_sy = ((bn * a.Cout + o0) * HW + 2 * by * a.W + 32 * bx) * 4;
+    if (a.TBN & 16) { st_sx = (c0 * HW + (2 + (split & 31) * 2) * a.W) * 4; st_sy = (o0 * HW + (2 + (split & 31) * 2) * a.W) * 4; }  // (rows >= 1: inside the tensor)
+    st_patch = own_first && nq == 0;
+    st_so = so;
     zl = bx == 0;
     zr = bx == a.blocks_x - 1;
     ++nq;
@@ -901,6 +892,32 @@ __global__ void __launch_bounds__(512) wino_wgrad_rows_mfma(const WwArgs a) {
     const int wy = by == a.blocks_y ? 1 : 0;
     by = wy ? 0 : by;
     bn += wy;
+  };
+  auto issue_slots = [&](auto lo_, auto hi_) __attribute__((always_inline)) {
+    constexpr int LO = decltype(lo_)::value, HI = decltype(hi_)::value < NM ? decltype(hi_)::value : NM;
+#pragma unroll
+    for (int m = LO; m < HI; ++m) {
+      const int k = wave + 8 * m;
+      if (k < NI) {  // (wave-uniform)
+        float* dst = smem + st_so + 256 * k;
+        if (k < XI) {
+          unsigned v = voff[m];
+          if (st_top || st_bot || st_patch) {  // (wave-uniform; the common stage takes the offsets as they are)
+            const bool kill = (st_top && ((cls >> (4 * m)) & 1u)) || (st_bot && ((cls >> (4 * m + 1)) & 1u)) || (st_patch && m == 0 && lane == 9);
+            v = kill ? INV : v;
+          }
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(st_xs, (rw_lds_ptr)dst, 16, (int)v, st_sx, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(st_ys, (rw_lds_ptr)dst, 16, (int)voff[m], st_sy, 0, 0);
+        }
+      }
+    }
+  };
+  using M0_ = std::integral_constant<int, 0>; using M2_ = std::integral_constant<int, 2>; using M4_ = std::integral_constant<int, 4>;
+  using M6_ = std::integral_constant<int, 6>; using M8_ = std::integral_constant<int, 8>;
+  auto issue_stage = [&](int so) __attribute__((always_inline)) {
+    issue_begin(so);
+    issue_slots(M0_{}, M8_{});
   };
   // the stage at word offset so has landed (this wave's pieces): zero the pixels beside the image that this wave copied
   auto landed = [&](int so) __attribute__((always_inline)) {
@@ -942,7 +959,10 @@ __global__ void __launch_bounds__(512) wino_wgrad_rows_mfma(const WwArgs a) {
     struct Raw {
       f32x2 al[CT], ah[CT], bl[CT], bh[CT], t0[OT], t1[OT];  // rows RA / RB as (e0, p0) | (p1, e1); gy rows
     };
-    auto read_raw = [&](Raw& r, unsigned xa, unsigned ya, auto ks_) __attribute__((always_inline)) {
+    struct Ops {
+      f32x2 av[CT], bv[OT];  // the wave's two x components per in-channel tile / two gy components (unsigned) per out-channel tile
+    };
+    auto read_x = [&](Raw& r, unsigned xa, auto ks_) __attribute__((always_inline)) {
       constexpr int KS = decltype(ks_)::value;
       rw_static_for<CT>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
@@ -952,6 +972,9 @@ __global__ void __launch_bounds__(512) wino_wgrad_rows_mfma(const WwArgs a) {
         r.bl[i] = rw_lds64<o + RB * RW_RS * 4>(xa);
         r.bh[i] = rw_lds64<o + RB * RW_RS * 4 + 8>(xa);
       });
+    };
+    auto read_y = [&](Raw& r, unsigned ya, auto ks_) __attribute__((always_inline)) {
+      constexpr int KS = decltype(ks_)::value;
       rw_static_for<OT>([&](auto jc) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
         constexpr int o = (16 * j * RW_CSY + 8 * KS) * 4;
@@ -969,15 +992,17 @@ __global__ void __launch_bounds__(512) wino_wgrad_rows_mfma(const WwArgs a) {
         if constexpr (Y1) rw_tie(r.t1[j]);
       }
     };
-    // raw rows -> MFMA operands: av[i] = the wave's two x components of channel tile i, bv[j] = its two gy components (unsigned)
-    auto transform = [&](const Raw& r, f32x2 (&av)[CT], f32x2 (&bv)[OT], bool bias_on) __attribute__((always_inline)) {
+    // raw rows -> MFMA operands
+    auto transform_x = [&](const Raw& r, Ops& o) __attribute__((always_inline)) {
 #pragma unroll
       for (int i = 0; i < CT; ++i) {
         const f32x2 ul = PLUS ? r.al[i] + r.bl[i] : pk_sub(r.al[i], r.bl[i]);  // (u0, u1)
         const f32x2 uh = PLUS ? r.ah[i] + r.bh[i] : pk_sub(r.ah[i], r.bh[i]);  // (u2, u3)
-        if constexpr (!ODD) asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(av[i]) : "v"(ul), "v"(uh));  // (u0 - u2, u1 - u3)
-        else asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[1,0]" : "=v"(av[i]) : "v"(ul), "v"(uh));  // (u1 + u2, u2 - u1)
+        if constexpr (!ODD) asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(o.av[i]) : "v"(ul), "v"(uh));  // (u0 - u2, u1 - u3)
+        else asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[1,0]" : "=v"(o.av[i]) : "v"(ul), "v"(uh));  // (u1 + u2, u2 - u1)
       }
+    };
+    auto transform_y = [&](const Raw& r, Ops& o, bool bias_on) __attribute__((always_inline)) {
 #pragma unroll
       for (int j = 0; j < OT; ++j) {
         f32x2 rr;
@@ -988,35 +1013,72 @@ __global__ void __launch_bounds__(512) wino_wgrad_rows_mfma(const WwArgs a) {
         if constexpr (I == 1 && !ODD) {
           if (bias_on) bsum[j] += rr[0] + rr[1];  // t00 + t10 + t01 + t11: the bias gradient rides in wave 2
         }
-        if constexpr (!ODD) bv[j] = rr;
-        else asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(bv[j]) : "v"(rr));  // (r0 + r1, r0 - r1)
+        if constexpr (!ODD) o.bv[j] = rr;
+        else asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(o.bv[j]) : "v"(rr));  // (r0 + r1, r0 - r1)
       }
     };
     // (gfx950: registers written by vector instructions inside inline assembly and read as MFMA sources right behind them need wait
     // states hipcc only inserts for instructions it schedules itself -- wino_strip.hip; the fence names them)
-    auto fence = [&](f32x2 (&av)[CT], f32x2 (&bv)[OT]) __attribute__((always_inline)) {
-      if constexpr (CT == 1) asm volatile("s_nop 1" : "+v"(av[0]));
-      if constexpr (CT == 2) asm volatile("s_nop 1" : "+v"(av[0]), "+v"(av[1]));
-      if constexpr (CT == 3) asm volatile("s_nop 1" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]));
-      if constexpr (CT == 4) asm volatile("s_nop 1" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]));
-      if constexpr (OT == 1) asm volatile("" : "+v"(bv[0]));
-      if constexpr (OT == 2) asm volatile("" : "+v"(bv[0]), "+v"(bv[1]));
-      if constexpr (OT == 3) asm volatile("" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]));
-      if constexpr (OT == 4) asm volatile("" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]));
+    auto fence = [&](Ops& o) __attribute__((always_inline)) {
+      if constexpr (CT == 1) asm volatile("s_nop 1" : "+v"(o.av[0]));
+      if constexpr (CT == 2) asm volatile("s_nop 1" : "+v"(o.av[0]), "+v"(o.av[1]));
+      if constexpr (CT == 3) asm volatile("s_nop 1" : "+v"(o.av[0]), "+v"(o.av[1]), "+v"(o.av[2]));
+      if constexpr (CT == 4) asm volatile("s_nop 1" : "+v"(o.av[0]), "+v"(o.av[1]), "+v"(o.av[2]), "+v"(o.av[3]));
+      if constexpr (OT == 1) asm volatile("" : "+v"(o.bv[0]));
+      if constexpr (OT == 2) asm volatile("" : "+v"(o.bv[0]), "+v"(o.bv[1]));
+      if constexpr (OT == 3) asm volatile("" : "+v"(o.bv[0]), "+v"(o.bv[1]), "+v"(o.bv[2]));
+      if constexpr (OT == 4) asm volatile("" : "+v"(o.bv[0]), "+v"(o.bv[1]), "+v"(o.bv[2]), "+v"(o.bv[3]));
     };
-    auto mma = [&](const f32x2 (&av)[CT], const f32x2 (&bv)[OT]) __attribute__((always_inline)) {
-      if (a.TBN & 32) __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-      for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int i = 0; i < CT; ++i)
-#pragma unroll
-          for (int j = 0; j < OT; ++j) acc[p][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][p], bv[j][p], acc[p][i][j], 0, 0, 0);
-      if (a.TBN & 32) __builtin_amdgcn_s_setprio(0);
+    // MFMAs LO .. HI - 1 of a k-step, n = (p CT + i) OT + j
+    constexpr int NMF = 2 * CT * OT;
+    auto mma = [&](const Ops& o, auto lo_, auto hi_) __attribute__((always_inline)) {
+      constexpr int LO = decltype(lo_)::value, HI = decltype(hi_)::value;
+      rw_static_for<HI - LO>([&](auto nc) __attribute__((always_inline)) {
+        constexpr int n = LO + decltype(nc)::value;
+        constexpr int p = n / (CT * OT), i = (n / OT) % CT, j = n % OT;
+        acc[p][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.av[i][p], o.bv[j][p], acc[p][i][j], 0, 0, 0);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // One k-step.  Its MFMAs carry, in their shadow, the operand reads and the transform of the NEXT k-step (vector and LDS
+    // instructions issued right behind an MFMA of the same wave cost 2-4 cycles each instead of 8.5, tools/hwtests/
+    // valu_latency_under_mfma.hip; in a phase of their own both waves of a SIMD sit in it at the same time and the matrix pipe idles:
+    // measured, 24 % of the kernel).  The LAST k-step of a stage also carries the stage change: wait for the own pieces of the next
+    // stage, barrier, request the stage after it into the buffer just left -- all between its first MFMAs and the reads.
+    constexpr int C1 = NMF / 4, C2 = (3 * NMF) / 8, C3 = NMF / 2, C4 = (3 * NMF) / 4, C5 = (7 * NMF) / 8;
+    using N0_ = std::integral_constant<int, 0>; using N1_ = std::integral_constant<int, C1>; using N2_ = std::integral_constant<int, C2>;
+    using N3_ = std::integral_constant<int, C3>; using N4_ = std::integral_constant<int, C4>; using N5_ = std::integral_constant<int, C5>;
+    using N6_ = std::integral_constant<int, NMF>;
+    auto step = [&](const Ops& cur, Ops& nxt, Raw& r, unsigned xa, unsigned ya, auto nks_, bool bias_on, auto&& between) __attribute__((always_inline)) {
+      mma(cur, N0_{}, N1_{});
+      between();
+      __builtin_amdgcn_sched_barrier(0);
+      mma(cur, N1_{}, N2_{});
+      read_x(r, xa, nks_);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(cur, N2_{}, N3_{});
+      read_y(r, ya, nks_);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(cur, N3_{}, N4_{});
+      wait_raw(r);
+      transform_x(r, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(cur, N4_{}, N5_{});
+      transform_y(r, nxt, bias_on);
+      fence(nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(cur, N5_{}, N6_{});
     };
 
-    // pipeline over stages: iteration q requests stage q + 1 into the other buffer, computes stage q from buffer q & 1, waits for
-    // its own pieces of stage q + 1 and meets the other waves at the barrier
+    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
+    // the image of a stage (bias gradient: images below bias_n count)
+    const int per_img = a.blocks_x * a.blocks_y;
+    int img = (split * a.per) / per_img, img_left = per_img - (split * a.per) % per_img;
+    const bool staging = !(a.TBN & 2);
+    Raw r;
+    Ops o0, o1;
+    // prologue: stage 0 in buffer 0, stage 1 on its way into buffer 1, the operands of stage 0's first k-step
     issue_stage(0);
     landed(0);
     if (own_first && lane == 9) {  // x[0 .. 2] of the tensor's first row (the piece itself was zero-filled: it begins at x[-1])
@@ -1025,49 +1087,32 @@ __global__ void __launch_bounds__(512) wino_wgrad_rows_mfma(const WwArgs a) {
       smem[RW_RS + 3] = a.x[2];
     }
     __syncthreads();
-    // the image of the stage being computed (bias gradient: images below bias_n count)
-    const int per_img = a.blocks_x * a.blocks_y;
-    int img = (split * a.per) / per_img, img_left = per_img - (split * a.per) % per_img;
-    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
-    using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
+    if (a.per > 1 && staging) issue_stage(STG);
+    read_x(r, xrd_a, K0{});
+    read_y(r, yrd_a, K0{});
+    wait_raw(r);
+    transform_x(r, o0);
+    transform_y(r, o0, img < a.bias_n);
+    fence(o0);
+    __builtin_amdgcn_sched_barrier(0);
     for (int q = 0; q < a.per; ++q) {
       const int so = (q & 1) * STG, sn = STG - so;
       const unsigned xa = xrd_a + (unsigned)so * 4u, ya = yrd_a + (unsigned)so * 4u;
-      Raw r0, r1;
-      f32x2 av[CT], bv[OT];
-      // (the scheduling fences keep hipcc from sinking a k-step's MFMAs below the wait for the NEXT k-step's operand reads -- the
-      // reads are opaque to it -- which exposed an LDS round trip per k-step: 859 -> see profiles/r06_wgrad_rows_steps.txt)
-      read_raw(r0, xa, ya, K0{});
-      if (!(a.TBN & 2)) issue_stage(sn);
+      const unsigned xn = xrd_a + (unsigned)sn * 4u, yn = yrd_a + (unsigned)sn * 4u;
       const bool bias_on = img < a.bias_n;
-      wait_raw(r0);
-      transform(r0, av, bv, bias_on);
-      read_raw(r1, xa, ya, K1{});
-      fence(av, bv);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(av, bv);
-      __builtin_amdgcn_sched_barrier(0);
-      wait_raw(r1);
-      transform(r1, av, bv, bias_on);
-      read_raw(r0, xa, ya, K2{});
-      fence(av, bv);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(av, bv);
-      __builtin_amdgcn_sched_barrier(0);
-      wait_raw(r0);
-      transform(r0, av, bv, bias_on);
-      read_raw(r1, xa, ya, K3{});
-      fence(av, bv);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(av, bv);
-      __builtin_amdgcn_sched_barrier(0);
-      wait_raw(r1);
-      transform(r1, av, bv, bias_on);
-      fence(av, bv);
-      mma(av, bv);
+      const bool dma = staging && q > 0 && q + 1 < a.per;  // stage q + 1 is being copied: its slots 2 .. go out under k-steps 0 .. 2
+      step(o0, o1, r, xa, ya, K1{}, bias_on, [&]() __attribute__((always_inline)) { if (dma) issue_slots(M2_{}, M4_{}); });
+      step(o1, o0, r, xa, ya, K2{}, bias_on, [&]() __attribute__((always_inline)) { if (dma) issue_slots(M4_{}, M6_{}); });
+      step(o0, o1, r, xa, ya, K3{}, bias_on, [&]() __attribute__((always_inline)) { if (dma) issue_slots(M6_{}, M8_{}); });
       if (--img_left == 0) { img_left = per_img; ++img; }
-      if (!(a.TBN & 10)) landed(sn);
-      if (!(a.TBN & 4)) __syncthreads();
+      step(o1, o0, r, xn, yn, K0{}, q + 1 < a.per && img < a.bias_n, [&]() __attribute__((always_inline)) {  // (behind the last stage: stale LDS, unused)
+        if (staging && !(a.TBN & 8)) landed(sn);  // stage q + 1: this wave's pieces are in LDS (and its edge pixels zeroed)
+        if (!(a.TBN & 4)) __syncthreads();       // ... everybody's; and nobody reads buffer `so` any more
+        if (staging && q + 2 < a.per) {          // stage q + 2: its first copy instructions
+          issue_begin(so);
+          issue_slots(M0_{}, M2_{});
+        }
+      });
     }
     // signs of the gy components computed unsigned: (i, 3) for i < 3, (3, 0), (3, 1), (3, 2)
     constexpr float S0 = I == 3 ? -1.f : 1.f;                                // p = 0: column 0 (even) / 1 (odd)
@@ -1331,7 +1376,7 @@ bool ww_rows_takes(const WwPlan& pl, bool ups) {
   const char* e = getenv("MG_WGRAD_ROWS");  // (read per call: tests and A/B runs switch it inside one process)
   const int mode = e == nullptr ? 1 : atoi(e);
   if (mode == 0 || ups || (pl.a.W % 32) != 0 || (pl.a.H % 2) != 0) return false;
-  return mode >= 2 || pl.CT + pl.OT > 4;
+  return mode >= 2 || pl.CT * pl.OT >= 4;  // (blocks of one channel tile on either side: 2 MFMAs per wave and k-step -- the chunk-staged narrow form is as fast or faster, profiles/r06_wgrad_rows_steps.txt)
 }
 
 void plan_rows(WwPlan& pl) {
