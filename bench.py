@@ -149,7 +149,7 @@ def dominant_kernel_probe(device, batch: int, iters: int = 100):
     return out
 
 
-def time_step(level: int, batch: int, rand_channels: int, device, steps: int, warmup: int, seed: int = 1234):
+def time_step(level: int, batch: int, rand_channels: int, device, steps: int, warmup: int, seed: int = 1234, alpha: float = 0.5):
     """ms per D+G step of a fresh single-GPU stepper at (level, batch), HIP events on the launch stream, nothing skipped."""
     from musicgan_amd.optim import FusedAdam
     from musicgan_amd.train_step import ProGANStepper
@@ -162,8 +162,8 @@ def time_step(level: int, batch: int, rand_channels: int, device, steps: int, wa
     x_real = torch.rand(batch, 2, side, side, device=device, generator=rng) * 2 - 1
 
     def one():
-        stepper.d_step(x_real, 0.5)
-        stepper.g_step(batch, 0.5, device)
+        stepper.d_step(x_real, alpha)
+        stepper.g_step(batch, alpha, device)
 
     for _ in range(warmup):
         one()
@@ -199,15 +199,15 @@ def step_traffic(level: int, batch: int):
     return rec if rec.get("batch") == batch else None
 
 
-def level_record(device, rand_channels: int, level: int, batch: int, steps: int, warmup: int, what: str):
+def level_record(device, rand_channels: int, level: int, batch: int, steps: int, warmup: int, what: str, alpha: float = 0.5):
     """One more (level, batch) with the headline's step and accounting: BASELINE.json configs[0..1] and the levels a real run of
     the reference lives at -- it trains at batch 6 (train.py:43) and spends 65 % of its scheduled FLOPs at level 6 and everything
     after 1.4 M samples at level 7 (train.py:101-109)."""
-    ms = time_step(level, batch, rand_channels, device, steps=steps, warmup=warmup)
+    ms = time_step(level, batch, rand_channels, device, steps=steps, warmup=warmup, alpha=alpha)
     ips = batch / ms * 1e3
     side = LEVEL_SIDE[level]
     fpi, xfpi = flops_per_image(level, rand_channels), executed_flops_per_image(level, rand_channels, batch)
-    return {"workload": f"ProGAN level {level} WGAN-GP D+G step, 2x{side}x{side}, batch {batch}, alpha 0.5 ({what})",
+    return {"workload": f"ProGAN level {level} WGAN-GP D+G step, 2x{side}x{side}, batch {batch}, alpha {alpha:g} ({what})",
             "value": ips, "unit": "images/s", "ms_per_step": ms, "steps": steps, "warmup": warmup,
             "roofline": step_roofline(fpi, xfpi, ips)}
 
@@ -433,13 +433,60 @@ def host_io_probe(device, scratch_dir: str, threads: int, samples_per_thread: in
             for i in range(batches * 8):
                 os.remove(os.path.join(scratch_dir, f"probe_{t}_{i}.pt"))
             os.remove(os.path.join(scratch_dir, f"probe_side_{t}.bin"))
+    # The bound itself must not be the product's own call: the two things a sample costs the host whatever the code around them --
+    # (i) plain `write` of 8 MiB into a new file + `pwrite` of 4 MiB into a per-thread file, from a zero buffer (page cache, inode
+    # and directory work of this file system), (ii) a float32 -> float64 widening of 2 x 512 x 512 values (numpy, one pass) -- each
+    # on `threads` threads at once.
+    import numpy as np
+    zeros8, zeros4 = bytes(8 << 20), bytes(4 << 20)
+    src32 = [np.random.default_rng(t).random(row_floats, dtype=np.float32) for t in range(threads)]
+    n_ind = max(8, samples_per_thread // 2)
+
+    def raw_writer(tid, busy):
+        side = os.open(os.path.join(scratch_dir, f"probe_rawside_{tid}.bin"), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        t0 = time.perf_counter()
+        for i in range(n_ind):
+            fd = os.open(os.path.join(scratch_dir, f"probe_raw_{tid}_{i}.bin"), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+            os.write(fd, zeros8)
+            os.close(fd)
+            os.pwrite(side, zeros4, i * len(zeros4))
+        busy[tid] = time.perf_counter() - t0
+        os.close(side)
+
+    def widener(tid, busy):
+        dst = np.empty(row_floats, dtype=np.float64)
+        t0 = time.perf_counter()
+        for i in range(n_ind):
+            np.copyto(dst, src32[tid], casting="safe")
+        busy[tid] = time.perf_counter() - t0
+
+    indep = {}
+    for what, fn in (("raw_write", raw_writer), ("widen", widener)):
+        busy = [0.0] * threads
+        ths = [threading.Thread(target=fn, args=(t, busy)) for t in range(threads)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        wall = time.perf_counter() - t0
+        indep[what] = wall / n_ind  # seconds per sample and thread, all threads busy
+        out[f"{what}_ms_per_sample_{threads}_threads"] = 1e3 * wall / n_ind
+    for t in range(threads):
+        for i in range(n_ind):
+            os.remove(os.path.join(scratch_dir, f"probe_raw_{t}_{i}.bin"))
+        os.remove(os.path.join(scratch_dir, f"probe_rawside_{t}.bin"))
     d2h = max(out["d2h_GB_per_s_1_stream"], out["d2h_GB_per_s_2_streams"])
     per_file_d2h = 201 * 2 * 512 * 512 * 4 / (d2h * 1e9)
     per_file_write = 201 / out[f"writer_path_samples_per_s_{threads}_thread{'s' if threads > 1 else ''}"]
-    out.update({"threads": threads, "bound_s_per_file_d2h": per_file_d2h, "bound_s_per_file_writer_path": per_file_write,
-                "bound_files_per_s": 1.0 / max(per_file_d2h, per_file_write),
-                "basis": "per 10-minute file: 421 MB over the measured pinned D2H rate; 201 samples over the measured rate of the writer "
-                         "path (widen to float64 + writev 8 MiB .pt + pwrite 4 MiB side-car row) on the writer threads; the larger one"})
+    per_file_indep = 201 * (indep["raw_write"] + indep["widen"]) / threads
+    out.update({"threads": threads, "bound_s_per_file_d2h": per_file_d2h, "bound_s_per_file_host_write_and_widen": per_file_indep,
+                "product_writer_path_s_per_file": per_file_write,
+                "bound_files_per_s": 1.0 / max(per_file_d2h, per_file_indep),
+                "basis": "per 10-minute file: 421 MB over the measured pinned D2H rate; 201 samples x (plain write of 8 MiB to a new file + "
+                         "pwrite of 4 MiB + one numpy float32 -> float64 pass), zero / random buffers, on the writer threads' count of "
+                         "threads at once, in the record's scratch directory; the larger one.  `product_writer_path_*`: the loop's own "
+                         "native call (mg_pt_write_samples) on the same threads, for comparison -- not part of the bound"})
     return out
 
 
@@ -506,19 +553,16 @@ def cpu_baseline(level: int, rand_channels: int, batch: int, iters: int):
 
 
 def launch_ranks(n: int, argv) -> int:
-    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1 --master-port <free> bench.py argv` as
+    """`python -m torch.distributed.run --standalone --local-addr 127.0.0.1 --nnodes=1 --nproc-per-node n bench.py argv` as
     a child process with inherited stdout / stderr; returns its exit code.  MG_BENCH_LAUNCHER (a command line) replaces
     `python -m torch.distributed.run` -- the CPU test suite puts a recording stub there."""
     import shlex
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     launcher = os.environ.get("MG_BENCH_LAUNCHER")
     head = shlex.split(launcher) if launcher else [sys.executable, "-m", "torch.distributed.run"]
-    cmd = head + ["--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                  os.path.abspath(__file__)] + list(argv)
+    # --standalone: the launcher binds its own rendezvous port on 127.0.0.1 (a port picked here by bind-and-close could be taken by
+    # another bench run on the node before the launcher opens it)
+    cmd = head + ["--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={n}", os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: RCCL between processes needs it on this image)
     return subprocess.run(cmd, env=env).returncode
@@ -532,6 +576,8 @@ def main():
     ap.add_argument("--level", type=int, default=5, choices=[3, 4, 5, 6, 7])
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--rand-channels", type=int, default=32)
+    ap.add_argument("--alpha", type=float, default=0.5,
+                    help="fade-in coefficient of the timed step (SURVEY 8(d): 0.5 and 1.0; utils.py:62-68 holds 1.0 once a block has faded in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the other levels' records, the STFT / codec / create_dataset records and the train-loop record")
@@ -540,6 +586,10 @@ def main():
                     help="skip the 5 critic : 1 generator `secondary` record (profiling runs: the trace then holds D+G steps only)")
     args = ap.parse_args()
 
+    if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # dmabuf IPC (RCCL between processes needs it on this image): in THIS process, before the first HIP call -- a launcher that
+        # starts `torch.distributed.run ... bench.py --gpus N` itself never passes through launch_ranks()
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start one rank per GPU ourselves -- as a CHILD process and before this
         # process has touched the GPU (an exec, or a fork after HIP initialisation, takes the node down on this pool) -- and pass
@@ -549,7 +599,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU path)")
+        raise SystemExit("bench.py needs an MI355X (no CPU path)" +
+                         (f" [rank {rank} of {world}, HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}]" if world > 1 else ""))
     # Rehearsal of the N > 1 code on a one-GPU box (tests/test_dp_gpu.py): MG_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
     # takes gloo, because RCCL refuses two ranks on one device.  The driver's launches never set it.
     share_gpu = os.environ.get("MG_BENCH_SHARE_GPU") == "1"
@@ -574,7 +625,7 @@ def main():
     optim_gen = FusedAdam(gen.parameters(), lr=1e-3, betas=(0.0, 0.9))
     optim_disc = FusedAdam(disc.parameters(), lr=1e-3, betas=(0.0, 0.9))
     side = LEVEL_SIDE[args.level]
-    alpha = 0.5
+    alpha = args.alpha
     data_rng = torch.Generator(device=device).manual_seed(1234 + rank)
     # latents and the penalty's epsilon: fresh per update from this seeded generator, drawn by the stepper as
     # train.py:143-149 / discriminator.py:166 do -- straight into the replayed graph's input buffers
@@ -683,7 +734,7 @@ def main():
             "ranks_seen": ranks_seen, "ms_per_step_fastest_rank": rank_ms[0], "ms_per_step_slowest_rank": rank_ms[1],
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"ProGAN level {args.level} WGAN-GP D+G step, 2x{side}x{side}, "
-                                   f"batch {args.batch}/GPU, rand_channels {args.rand_channels}, alpha 0.5 (fade-in live), "
+                                   f"batch {args.batch}/GPU, rand_channels {args.rand_channels}, alpha {args.alpha:g} (fade-in branch live), "
                                    f"Adam(1e-3,(0,0.9)) on both nets, random-init weights",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}"},
             "roofline": {**step_roofline(fpi, xfpi, images_per_s / world),
@@ -715,14 +766,18 @@ def main():
             line["l7_bs6"] = level_record(device, args.rand_channels, 7, 6, 80, 40, "the reference's batch, train.py:43")
             line["l7_bs16"] = level_record(device, args.rand_channels, 7, 16, 40, 20, "final level, larger batch")
             line["l3_bs8"] = level_record(device, args.rand_channels, 3, 8, 100, 30, "BASELINE.json configs[0], on the GPU")
+            # SURVEY 8(d)'s second synthetic-input configuration: alpha = 1.0 (utils.py:62-68: where a stage sits once its block has
+            # faded in; the fade-in branch still executes, generator.py:122-124 -- alpha is device data of the same captured graphs)
+            line["alpha_1"] = level_record(device, args.rand_channels, 5, 64, 50, 20, "the headline configuration at alpha = 1.0", alpha=1.0)
             line["stft"] = stft_record(device, cpu=False)
             line.update(create_dataset_and_train_records(device, args.rand_channels))
         if world == 1 and not args.no_cpu_baseline:
-            # 1 warm-up + 1 timed step each (~20 s at level 5): a bounded sample, and the driver's GPU-load sampler still sees the GPU
-            line["cpu_baseline"] = cpu_baseline(args.level, args.rand_channels, args.cpu_batch, iters=1)
+            # bounded samples (~25 s in all): 1 warm-up + 1 timed step at level 5 (~9 s per step), 1 + 3 at levels 4 and 3 (< 1 s per
+            # step; SURVEY 8(d): min of three, the median beside it)
+            line["cpu_baseline"] = cpu_baseline(args.level, args.rand_channels, args.cpu_batch, iters=1 if args.level >= 5 else 3)
             if extra:
-                line["l4_bs32"]["cpu_baseline"] = cpu_baseline(4, args.rand_channels, 32, iters=1)
-                line["l3_bs8"]["cpu_baseline"] = cpu_baseline(3, args.rand_channels, 8, iters=2)
+                line["l4_bs32"]["cpu_baseline"] = cpu_baseline(4, args.rand_channels, 32, iters=3)
+                line["l3_bs8"]["cpu_baseline"] = cpu_baseline(3, args.rand_channels, 8, iters=3)
                 wav = torch.rand(44100 * 600, device=device, generator=torch.Generator(device=device).manual_seed(7)) - 0.5
                 line["stft"]["cpu_baseline"] = stft_cpu_baseline(wav)
         print(json.dumps(line), flush=True)

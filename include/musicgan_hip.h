@@ -29,6 +29,7 @@ typedef void* mg_stream_t;
 #define MG_EINVAL (-1)  /* bad shape / flag combination */
 #define MG_ELAUNCH (-2) /* hip launch error */
 #define MG_EWORKSPACE (-3)
+#define MG_EIO (-4)      /* a host file operation failed (mg_pt_write_samples): errno text in mg_last_error() */
 
 int mg_version(void);
 const char* mg_last_error(void);

@@ -256,6 +256,8 @@ def create_dataset(audio_path: str, dataset_output_dir: str, *, packed: bool = T
     available CPU (at most 16)."""
     w_p = glob.glob(audio_path)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC, before the first HIP call: train.py)
     if not exists(dataset_output_dir):
         os.makedirs(dataset_output_dir, exist_ok=True)
     elif not isdir(dataset_output_dir):

@@ -21,6 +21,10 @@ bool write_all(int fd, struct iovec* iov, int cnt) {
       if (errno == EINTR) continue;
       return false;
     }
+    if (w == 0) {  // (no progress: a full device reports ENOSPC on the next call at the latest; never spin)
+      errno = ENOSPC;
+      return false;
+    }
     while (cnt > 0 && (size_t)w >= iov->iov_len) {
       w -= iov->iov_len;
       ++iov;
@@ -39,6 +43,10 @@ bool pwrite_all(int fd, const char* p, size_t n, off_t off) {
     ssize_t w = pwrite(fd, p, n, off);
     if (w < 0) {
       if (errno == EINTR) continue;
+      return false;
+    }
+    if (w == 0) {
+      errno = ENOSPC;
       return false;
     }
     p += w;
@@ -63,14 +71,14 @@ extern "C" int mg_pt_write_samples(const float* rows, int n, int64_t row_floats,
     const float* src = rows + (size_t)i * row_floats;
     if (side_fd >= 0 && !pwrite_all(side_fd, reinterpret_cast<const char*>(src), (size_t)row_floats * 4, (off_t)(side_off + (int64_t)i * row_floats * 4))) {
       mg_set_error("mg_pt_write_samples: side-car write failed: %s", strerror(errno));
-      rc = MG_EINVAL;
+      rc = MG_EIO;
       break;
     }
     for (int64_t k = 0; k < row_floats; ++k) wide[k] = (double)src[k];
     const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
     if (fd < 0) {
       mg_set_error("mg_pt_write_samples: cannot open %s: %s", path, strerror(errno));
-      rc = MG_EINVAL;
+      rc = MG_EIO;
       break;
     }
     struct iovec iov[3] = {{const_cast<unsigned char*>(prefix), (size_t)prefix_len},
@@ -78,9 +86,13 @@ extern "C" int mg_pt_write_samples(const float* rows, int n, int64_t row_floats,
                            {const_cast<unsigned char*>(suffixes + (size_t)i * suffix_len), (size_t)suffix_len}};
     if (!write_all(fd, iov, 3)) {
       mg_set_error("mg_pt_write_samples: write to %s failed: %s", path, strerror(errno));
-      rc = MG_EINVAL;
+      rc = MG_EIO;
     }
-    close(fd);
+    if (close(fd) != 0 && rc == MG_OK) {  // (deferred write errors -- quota, a network file system -- surface here)
+      mg_set_error("mg_pt_write_samples: closing %s failed: %s", path, strerror(errno));
+      rc = MG_EIO;
+    }
+    if (rc != MG_OK) unlink(path);  // never leave a truncated magn_phase_*.pt behind for AudioDataset to load
     path += strlen(path) + 1;
   }
   free(wide);

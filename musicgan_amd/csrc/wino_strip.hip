@@ -588,11 +588,21 @@ int launch_strip(const WinoArgs& a, dim3 grid, hipStream_t s) {
   if (mg_first_use_on_device(once)) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   // persistent workgroups: as many per CU as registers and the filter bank's LDS allow (the one-tile kernels: two, i.e. four waves
   // per SIMD -- the waves are independent, occupancy is what hides a block's load latency), never more than there are groups
-  int per_cu = 1;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * NWAVE, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-  if (per_cu > 16 / NWAVE) per_cu = 16 / NWAVE;
+  // (the occupancy query is a runtime call of microseconds: asked once per (device, LDS size) of this instantiation -- benign race:
+  // every thread computes the same value)
+  static struct { int dev; size_t lds; int v; } occ[8];
+  static int nocc = 0;
+  int per_cu = 0;
+  const int dev = mg_current_device();
+  for (int i = 0; i < nocc && i < 8; ++i)
+    if (occ[i].dev == dev && occ[i].lds == lds) per_cu = occ[i].v;
+  if (per_cu == 0) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * NWAVE, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (per_cu > 16 / NWAVE) per_cu = 16 / NWAVE;
+    if (nocc < 8) { occ[nocc].dev = dev; occ[nocc].lds = lds; occ[nocc].v = per_cu; ++nocc; }
+  }
   {
-    const char* e = getenv("MG_WINO_STRIP_WGS");  // measurement switch: workgroups per CU
+    static const char* const e = getenv("MG_WINO_STRIP_WGS");  // measurement switch (read once): workgroups per CU
     if (e != nullptr && atoi(e) >= 1) per_cu = atoi(e);
   }
   // rows of workgroups (grid.y of the caller = number of rows) laid out in a 1-D grid; a last row whose second tile is padding does

@@ -1376,6 +1376,7 @@ bool ww_rows_takes(const WwPlan& pl, bool ups) {
   const char* e = getenv("MG_WGRAD_ROWS");  // (read per call: tests and A/B runs switch it inside one process)
   const int mode = e == nullptr ? 1 : atoi(e);
   if (mode == 0 || ups || (pl.a.W % 32) != 0 || (pl.a.H % 2) != 0) return false;
+  if (pl.CT == 4 && pl.OT == 4) return false;  // (256 accumulators + raw set + two operand sets: 68 bytes of scratch per lane; not instantiated)
   return mode >= 2 || pl.CT * pl.OT >= 4;  // (blocks of one channel tile on either side: 2 MFMAs per wave and k-step -- the chunk-staged narrow form is as fast or faster, profiles/r06_wgrad_rows_steps.txt)
 }
 
@@ -1428,7 +1429,6 @@ int dispatch_rows(int CT, int OT, const WwArgs& a, dim3 grid, hipStream_t s) {
     case 41: return launch_rows<4, 1>(a, grid, s);
     case 42: return launch_rows<4, 2>(a, grid, s);
     case 43: return launch_rows<4, 3>(a, grid, s);
-    case 44: return launch_rows<4, 4>(a, grid, s);
   }
   mg_set_error("mg_wino3x3_wgrad: internal tile error (CT=%d, OT=%d)", CT, OT);
   return MG_EINVAL;

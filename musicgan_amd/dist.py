@@ -141,6 +141,19 @@ class GradBucket:
             torch.cuda.current_stream().wait_event(ev)
 
 
+def check_world(expected: int, device=None) -> int:
+    """A sum of ones over the data path's backend: the ranks that really take part.  Raises SystemExit(3) when that is not
+    `expected` (WORLD_SIZE) -- a rank that came up on the wrong device, or alone, must not train a model nobody asked for."""
+    seen = 1
+    if dist.is_available() and dist.is_initialized():
+        ones = torch.ones(1, dtype=torch.float32, device=device if device is not None else "cpu")
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        seen = int(round(float(ones.item())))
+    if seen != expected:
+        raise SystemExit(f"musicgan_amd: WORLD_SIZE={expected} but {seen} rank(s) take part in the gradient exchange")
+    return seen
+
+
 def broadcast_parameters(modules: Iterable[torch.nn.Module], src: int = 0) -> None:
     """Identical replicas at start (same seed already gives this; the broadcast makes it independent of host RNG state)."""
     if not is_distributed():

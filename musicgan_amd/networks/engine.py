@@ -401,7 +401,7 @@ def gen_forward(W: GenWeights, z: torch.Tensor, alpha: float, cache: PackCache, 
     old = None
     if W.old_head is not None:
         F = FadeIn.of(alpha)
-        if ops.fuse_ends() and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
+        if ops.head_pair_supported(x.shape[1], x_in_last.shape[1], x.shape[2], x.shape[3]):
             # both heads, the up-sampling of the old one and the blend in one launch
             out, mp, old = ops.head_pair(x, W.head[0], W.head[1], x_in_last, W.old_head[0], W.old_head[1], F.a, F.b, coef=F.dev,
                                          save=save, out=out)
@@ -421,7 +421,7 @@ def gen_backward(W: GenWeights, ctx, g_out: torch.Tensor, cache: PackCache, sink
     saved, x_last, mp, old, alpha = ctx
     F = FadeIn.of(alpha)
     g_out = g_out.contiguous()
-    if W.old_head is not None and ops.fuse_ends() and g_out.shape[2] % 2 == 0 and g_out.shape[3] % 4 == 0:
+    if W.old_head is not None and ops.blend_up_bwd_supported(g_out.shape[2], g_out.shape[3]):
         g_mp, g_old = ops.blend_up_bwd(g_out, F.a, F.b, coef=F.dev)
     elif W.old_head is not None:
         g_mp = ops.axpby(F.a, g_out, coef=F.dev)
@@ -770,7 +770,7 @@ def disc_backward(W: DiscWeights, ctx, g_out: torch.Tensor, cache: PackCache, si
     if keep_h:
         hs["stem"], hs["old"] = gpre_s, gpre_o
     gx = None
-    if need_gx and W.old_stem is not None and ops.fuse_ends() and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
+    if need_gx and W.old_stem is not None and ops.stem_pair_gx_supported(gpre_s.shape[1], gpre_o.shape[1], x.shape[2], x.shape[3]):
         gx = ops.stem_pair_gx(gpre_s[gx_from:], W.stem[0], gpre_o[gx_from:], W.old_stem[0])  # both branches and their sum, one launch
     elif need_gx:  # gx_from > 0: only samples gx_from.. are wanted (the fused critic step needs the interpolated third only)
         gx = ops.conv1x1(gpre_s[gx_from:], W.stem[0], None, 2, transposed=True)

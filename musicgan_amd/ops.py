@@ -584,6 +584,20 @@ def stem_pair_supported(h: int, w: int) -> bool:
     return fuse_ends() and h % 2 == 0 and w % 4 == 0
 
 
+# The shapes the other fused ends take (the MG_CHECK_ARGs of csrc/fade_ends.hip): the engine asks here and falls back to the separate
+# kernels otherwise -- the four waves of pair_few_out_k split at least four channels on either side.
+def stem_pair_gx_supported(c0: int, c1: int, h: int, w: int) -> bool:
+    return fuse_ends() and c0 >= 4 and c1 >= 4 and h % 2 == 0 and w % 2 == 0
+
+
+def head_pair_supported(c: int, cl: int, h: int, w: int) -> bool:
+    return fuse_ends() and c >= 4 and cl >= 4 and h % 2 == 0 and w % 2 == 0
+
+
+def blend_up_bwd_supported(h: int, w: int) -> bool:
+    return fuse_ends() and h % 2 == 0 and w % 4 == 0
+
+
 def stem_pair(x, ws, bs, wo, bo, *, lrelu=True, h0=None, xp=None, o=None, masked=False, want_xp=True, want_mask=False):
     """Critic input while a block fades in (discriminator.py:107-113): h0 = act(ws x + bs), xp = AvgPool2d(x), o = act(wo xp + bo).
     `masked`: the tangent form -- h0 / o hold the forward activations and receive (w x) * lrelu'(activation) in place."""

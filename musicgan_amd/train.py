@@ -118,11 +118,18 @@ def train(run_name: str, input_dataset_path: str, output_dir: str, *, nb_epoch: 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        # dmabuf IPC (RCCL between processes needs it on this image), in this process and before the first HIP call: a run started as
+        # `torchrun ... -m musicgan_amd train` has no launcher of ours in front of it
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     th.cuda.set_device(local_rank)
     device = th.device("cuda", local_rank)
     if world > 1 and not th.distributed.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        th.distributed.init_process_group(backend="nccl", device_id=device)
+        th.distributed.init_process_group(backend=os.environ.get("MG_DIST_BACKEND", "nccl"), device_id=device)
+    if world > 1:
+        from .dist import check_world
+        check_world(world, device)  # every rank takes part in the data path's collectives, or the run ends here (non-zero exit)
     if mlflow is not None and rank == 0:
         mlflow.set_experiment("music_gan")
         mlflow.start_run(run_name=run_name)

@@ -17,6 +17,10 @@ HOT = [
     (r"wino3x3_stripILi[12]E", 0),        # one / two out-channel tiles per wave: two waves per SIMD, everything in registers
     (r"wino3x3_stripILi3E", 0),           # three tiles: 192 accumulators, one wave per SIMD (AGPRs, no scratch)
     (r"wino_wgrad_mfma", 0),
+    (r"wino_wgrad_rows_mfma", 0),         # row-staged form: up to 256 accumulators + one raw operand set, two waves per SIMD
+    (r"wino_wgrad_narrow_mfmaILi2ELi2ELb0ELb0E", 28),  # the general (per-lane addressed) 2 x 2 form: 7 dwords; off the default path
+                                                       # (maps >= 16 wide take the scalar-addressed form, 2 x 2 blocks the row-staged one)
+    (r"wino_wgrad_narrow_mfma(?!ILi2ELi2ELb0ELb0E)", 0),
     (r"wino_wgrad_group_mfma", 0),
     (r"conv3x3_mfma", 0),
     (r"wgrad3x3_mfma", 0),

@@ -70,6 +70,14 @@ def _worker(rank, world, port, out_dir):
         m.weight.fill_(float(rank))
     broadcast_parameters([m], src=0)
     assert float(m.weight.abs().max()) == 0.0
+    # train()'s start-up check: every rank is seen by the data path, a wrong WORLD_SIZE ends the run with a non-zero exit
+    from musicgan_amd.dist import check_world
+    assert check_world(world) == world
+    try:
+        check_world(world + 1)
+        raise AssertionError("check_world accepted a missing rank")
+    except SystemExit as e:
+        assert "WORLD_SIZE=3 but 2 rank(s)" in str(e.code)
     torch.save({"worst": worst}, os.path.join(out_dir, f"r{rank}.pt"))
     dist.destroy_process_group()
 
@@ -111,3 +119,24 @@ def test_own_flat_buffer_is_recognised_in_any_parameter_order():
     assert b._as_own_flat(ps[:2]) is None  # a slice missing
     ps[1].grad = torch.zeros(5)
     assert b._as_own_flat(ps) is None      # a gradient living elsewhere
+
+
+def test_train_sets_the_ipc_mode_itself_when_started_by_torchrun(tmp_path, monkeypatch):
+    """`torchrun ... -m musicgan_amd train` never passes through bench.py's launcher: train() and create_dataset() set
+    HSA_ENABLE_IPC_MODE_LEGACY=0 in their own process before the first HIP call when WORLD_SIZE > 1 (and leave a single-process
+    run's environment alone).  No GPU here: the call then fails at `cuda.set_device`, after the variable is set."""
+    import pytest
+    import musicgan_amd
+    train_fn, create_dataset = musicgan_amd.train, musicgan_amd.create_dataset  # (the package's lazily re-exported drivers)
+    for fn in (lambda: train_fn("t", str(tmp_path), str(tmp_path / "out")),
+               lambda: create_dataset(str(tmp_path / "*.wav"), str(tmp_path / "ds"))):
+        monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+        monkeypatch.setenv("WORLD_SIZE", "1")
+        with pytest.raises(Exception):
+            fn()
+        assert "HSA_ENABLE_IPC_MODE_LEGACY" not in os.environ
+        monkeypatch.setenv("WORLD_SIZE", "8")
+        monkeypatch.setenv("RANK", "0")
+        with pytest.raises(Exception):
+            fn()
+        assert os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"

@@ -331,15 +331,17 @@ def test_bench_with_gpus_n_and_no_launcher_starts_the_ranks_as_a_child_process(t
     seen = json.load(open(tmp_path / "seen.json"))
     argv = seen["argv"]
     assert "--nnodes=1" in argv and "--nproc-per-node=8" in argv
-    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and int(argv[argv.index("--master-port") + 1]) > 0
+    assert "--standalone" in argv and argv[argv.index("--local-addr") + 1] == "127.0.0.1"  # (the launcher binds its own port)
     i = argv.index(os.path.join(root, "bench.py"))
     assert argv[i + 1:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"]
     assert seen["ipc"] == "0"
-    # under a launcher (RANK set) it does not spawn again: it goes on to the GPU check, which fails here
-    env2 = dict(env, RANK="0", WORLD_SIZE="8", LOCAL_RANK="0")
+    # under a launcher (RANK set) it does not spawn again: it goes on to the GPU check, which fails here -- and a rank that a driver
+    # started with `torch.distributed.run ... bench.py --gpus 8` directly (never through launch_ranks) has set the IPC mode itself
+    env2 = {k: v for k, v in dict(env, RANK="0", WORLD_SIZE="8", LOCAL_RANK="0").items() if k != "HSA_ENABLE_IPC_MODE_LEGACY"}
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], capture_output=True, text=True, env=env2,
                         cwd=root, timeout=300)
     assert r2.returncode != 0 and "needs an MI355X" in (r2.stderr + r2.stdout)
+    assert "HSA_ENABLE_IPC_MODE_LEGACY=0" in (r2.stderr + r2.stdout)
 
 
 def test_native_sample_writer_writes_what_torch_save_writes(tmp_path):

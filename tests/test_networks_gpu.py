@@ -418,6 +418,7 @@ def test_full_size_step_is_algorithm_independent(monkeypatch, level, batch):
         assert maxabs_err(terms["product"][k], t) <= 2e-4 * float(t.abs().max()), k
     assert ga.keys() == gb.keys() and len(ga) > 40
     assert abs(la - lb) <= 1e-5 * max(1.0, abs(lb)) and abs(pa - pb) <= 1e-4 * max(1.0, abs(pb)) and abs(qa - qb) <= 1e-5 * max(1.0, abs(qb))
+    flips = []  # bias tensors with ONE element off by a LeakyReLU sign flip (below)
     for net in ("D.", "G."):
         gmax = max(float(v.abs().max()) for k, v in gb.items() if k.startswith(net))
         for k in gb:
@@ -433,9 +434,12 @@ def test_full_size_step_is_algorithm_independent(monkeypatch, level, batch):
                 # derivative is then 1 in one and 0.2 in the other, and ONE summand of ONE out-channel's bias gradient changes by
                 # 0.8 of itself -- 1 / sqrt(#summands) of a cancelled sum (seen at level 6 batch 8 once the Winograd kernel took the
                 # 16x16 x 24-image layers: one element of a deep block's bias gradient 3.3e-5 of its un-cancelled term apart,
-                # every other element of every tensor within the tolerance).  One such element per bias tensor is accepted.
-                assert over == 0 or (ga[k].dim() == 1 and over == 1 and float(err.max()) <= 4 * tol), \
-                    f"{k}: {float(err.max()):.3e} > {tol:.3e} ({over} elements)"
+                # every other element of every tensor within the tolerance).  ONE such element is accepted
+                # -- in the critic only (the cancelled sums are its real - fake terms), and once per configuration.
+                flip = net == "D." and ga[k].dim() == 1 and over == 1 and float(err.max()) <= 4 * tol and not flips
+                if flip:
+                    flips.append(k)
+                assert over == 0 or flip, f"{k}: {float(err.max()):.3e} > {tol:.3e} ({over} elements; sign flips accepted so far: {flips})"
 
 
 @pytest.mark.parametrize("case", ["l1_rc8_fade", "l2_rc16_gpnorm1", "l3_rc32_fade"])

@@ -23,7 +23,7 @@ def _rel(got, ref):
     return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
 
 
-# (N, Cin, Cout, H, W): block shapes <CT, OT> from <1,1> to <4,4>, incl. channel blocks (80 = 2 x 3 tiles, 144 = 3 x 3) and ragged channels
+# (N, Cin, Cout, H, W): block shapes <CT, OT> from <1,1> to <4,3> / <3,4> (<4,4> stays on the chunk-staged kernel), incl. channel blocks (80 = 2 x 3 tiles, 144 = 3 x 3) and ragged channels
 ROWS_SHAPES = [(2, 16, 16, 32, 32), (3, 16, 32, 64, 64), (2, 32, 48, 64, 32), (1, 16, 64, 32, 64), (2, 32, 16, 32, 32), (2, 32, 32, 64, 64),
                (1, 32, 64, 32, 32), (2, 48, 16, 32, 32), (2, 48, 32, 32, 64), (3, 48, 48, 32, 32), (2, 48, 64, 64, 64), (2, 64, 16, 32, 32),
                (1, 64, 32, 32, 32), (2, 64, 48, 32, 64), (3, 64, 64, 32, 32), (2, 80, 80, 32, 32), (1, 144, 96, 32, 32), (5, 24, 40, 2, 32),

@@ -72,6 +72,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "l5":  # the 64-out-channel layers of le
 if len(sys.argv) > 1 and sys.argv[1] == "nt1":  # 16 out-channels: one tile per wave
     cases = [(18, 32, 16, 512, "dgrad_mask"), (6, 32, 16, 512, "dgrad_mask"), (18, 16, 16, 512, "plain"), (6, 32, 16, 256, "pn"),
              (18, 48, 16, 256, "dgrad_mask")]
+if len(sys.argv) > 1 and sys.argv[1] == "small":  # the 32x32 layers of level 5 (192 / 64 images) and the 64x64 ones of level 6 (18 / 6): < 2 048 tile blocks or Cin >= 96
+    cases = [(192, 96, 80, 32, "dgrad_mask"), (192, 80, 80, 32, "unpool"), (192, 80, 96, 32, "fwd_pool_mask"), (192, 80, 80, 32, "plain"),
+             (64, 80, 80, 32, "unpool"), (64, 96, 80, 32, "dgrad_mask"), (64, 80, 80, 32, "dgrad_mask"), (64, 80, 96, 32, "tangent"),
+             (64, 80, 96, 32, "fwd_pool_mask"), (64, 80, 80, 32, "plain"), (18, 64, 80, 64, "fwd_pool_mask"), (18, 80, 64, 64, "dgrad_mask"),
+             (18, 64, 64, 64, "plain"), (6, 64, 64, 64, "plain"), (6, 64, 80, 64, "tangent"), (96, 64, 80, 64, "fwd_pool_mask"), (32, 64, 64, 64, "plain")]
 # variants: "0" the staged kernel; "2" strip, all out-channel tiles in a wave; "2n1" strip, one tile per wave (tiles on grid.y)
 VARIANTS = ["0", "2"] + [v for v in sys.argv[1:] if v.startswith("2")]
 
