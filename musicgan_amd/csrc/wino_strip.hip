@@ -602,7 +602,7 @@ int launch_strip(const WinoArgs& a, dim3 grid, hipStream_t s) {
     if (nocc < 8) { occ[nocc].dev = dev; occ[nocc].lds = lds; occ[nocc].v = per_cu; ++nocc; }
   }
   {
-    static const char* const e = getenv("MG_WINO_STRIP_WGS");  // measurement switch (read once): workgroups per CU
+    const char* e = getenv("MG_WINO_STRIP_WGS");  // measurement switch (tools/ab_wino_strip.py flips it inside one process): workgroups per CU
     if (e != nullptr && atoi(e) >= 1) per_cu = atoi(e);
   }
   // rows of workgroups (grid.y of the caller = number of rows) laid out in a 1-D grid; a last row whose second tile is padding does
@@ -671,6 +671,10 @@ int strip_plan(const WinoArgs& a, bool pn, bool force) {
   const long long blocks = (long long)a.N * (a.H / 2) * (a.W / 32);
   int niw = 0;
   niw = (force || blocks >= strip_min_blocks()) ? (nt == 1 ? 1 : 2) : 0;
+  // 96 .. 160 input channels: the filter bank of TWO out-channel tiles does not fit the LDS (8 KB per 8-channel chunk and tile), that
+  // of one does -- one tile per wave then (the input is read and transformed once per tile, and still 0.82 of the staged kernel's time:
+  // 96 -> 80 @32 x 192 images 168 -> 138 us, profiles/r06_ab_strip_small.txt)
+  if (niw == 2 && (size_t)(a.Cin / WCC) * 2 * 8192 > 160 * 1024) niw = 1;
   if (pn) niw = nt <= 2 ? (niw ? nt : 0) : 0;  // PixelNorm: all channels of a pixel in one wave
   const char* e = getenv("MG_WINO_STRIP_NIW");
   if (e != nullptr && !pn && niw != 0) {

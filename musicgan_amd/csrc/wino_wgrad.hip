@@ -775,10 +775,16 @@ __global__ void __launch_bounds__(512, 4) wino_wgrad_narrow_mfma(const WwArgs a)
 constexpr int RW_RS = 36;              // words per staged x row: pixel p (-1 .. 34) at word p + 1 = 9 pieces
 constexpr int RW_CSX = 4 * RW_RS + 4;  // words per x channel (4 rows + one padding piece = 37 pieces); 148 = 4 * 5 mod 64
 constexpr int RW_CSY = 68;             // words per gy channel: 2 rows x 32 pixels + one padding piece = 17 pieces (= 4 mod 64)
+// UPS (the convolution input is the nearest x2 up-sampling of x, generator.py:24-25): the patch of tile (TY, TX) is the 3x3 low-res
+// neighbourhood with its centre row / column doubled, so a stage holds low-res rows TY-1 .. TY+1, pixels -1 .. 18 (five pieces)
+constexpr int RW_RSU = 20;
+constexpr int RW_CSXU = 3 * RW_RSU + 8;  // 3 rows + two padding pieces = 17 pieces; 68 = 4 mod 32 (4-byte reads: banks modulo 32)
 
-template <int CT, int OT>
+template <int CT, int OT, bool UPS = false>
 struct RwGeom {
-  static constexpr int XI = (16 * CT * 37 + 63) / 64;  // LDS-DMA instructions (64 pieces each) of the x part, of the gy part
+  static constexpr int RS = UPS ? RW_RSU : RW_RS, CSX = UPS ? RW_CSXU : RW_CSX;
+  static constexpr int PPR = UPS ? 5 : 9, ROWS = UPS ? 3 : 4, PPC = CSX / 4;  // pieces per row, rows and pieces per x channel
+  static constexpr int XI = (16 * CT * PPC + 63) / 64;  // LDS-DMA instructions (64 pieces each) of the x part, of the gy part
   static constexpr int YI = (16 * OT * 17 + 63) / 64;
   static constexpr int NI = XI + YI;
   static constexpr int NM = (NI + 7) / 8;  // per wave
@@ -805,14 +811,22 @@ __device__ __forceinline__ f32x2 rw_lds64(unsigned addr) {
   asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
   return v;
 }
+template <int OFF>
+__device__ __forceinline__ float rw_lds32(unsigned addr) {
+  float v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
 __device__ __forceinline__ void rw_lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void rw_tie(float& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void rw_tie(f32x2& v) { asm volatile("" : "+v"(v)); }  // orders the uses of v behind the wait
 typedef __attribute__((address_space(3))) void* rw_lds_ptr;
 
-template <int CT, int OT>
+template <int CT, int OT, bool UPS>
 __global__ void __launch_bounds__(512) wino_wgrad_rows_mfma(const WwArgs a) {
-  using GEO = RwGeom<CT, OT>;
+  using GEO = RwGeom<CT, OT, UPS>;
   constexpr int YB = GEO::YB, STG = GEO::STG, XI = GEO::XI, NI = GEO::NI, NM = GEO::NM;
+  constexpr int RS = GEO::RS, CSX = GEO::CSX, PPR = GEO::PPR, PPC = GEO::PPC, XROWS = GEO::ROWS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = component pair
@@ -822,6 +836,7 @@ __global__ void __launch_bounds__(512) wino_wgrad_rows_mfma(const WwArgs a) {
   const int c0 = cb * CT * 16, o0 = ob * OT * 16;
   const int HW = a.H * a.W;
   const int Ht = a.H >> 1;
+  const int Wx = UPS ? a.W >> 1 : a.W, HWx = UPS ? HW >> 2 : HW;  // the x tensor's row and plane
   constexpr unsigned INV = 0x80000000u;
 
   // ---- loader: slot m of this wave is LDS-DMA instruction k = wave + 8 m of a stage, this lane's piece P = 64 k + lane.
@@ -838,10 +853,11 @@ __global__ void __launch_bounds__(512) wino_wgrad_rows_mfma(const WwArgs a) {
     const int P = 64 * k + lane;
     unsigned v = INV;
     if (k < XI) {
-      const int ch = P / 37, rem = P - 37 * ch, r = rem / 9, sg = rem - 9 * r;
-      if (ch < 16 * CT && rem < 36 && c0 + ch < a.Cin) {
-        v = (unsigned)((ch * HW + r * a.W + 4 * sg + 3) * 4);
-        cls |= (unsigned)(r == 0) << (4 * m) | (unsigned)(r == 3) << (4 * m + 1) | (unsigned)(sg == 0) << (4 * m + 2) | (unsigned)(sg == 8) << (4 * m + 3);
+      const int ch = P / PPC, rem = P - PPC * ch, r = rem / PPR, sg = rem - PPR * r;
+      if (ch < 16 * CT && rem < XROWS * PPR && c0 + ch < a.Cin) {
+        v = (unsigned)((ch * HWx + r * Wx + 4 * sg + 3) * 4);
+        cls |= (unsigned)(r == 0) << (4 * m) | (unsigned)(r == XROWS - 1) << (4 * m + 1) | (unsigned)(sg == 0) << (4 * m + 2) |
+               (unsigned)(sg == PPR - 1) << (4 * m + 3);
       }
     } else if (k < NI) {
       const int Q = P - 64 * XI;
@@ -850,10 +866,11 @@ __global__ void __launch_bounds__(512) wino_wgrad_rows_mfma(const WwArgs a) {
     }
     voff[m] = v;
   }
-  const unsigned xshift = (unsigned)(a.W + 4) * 4u;
+  const unsigned xshift = (unsigned)(Wx + 4) * 4u;
   const char* xbase = reinterpret_cast<const char*>(a.x) - xshift;
-  // the piece that begins at x[-1]: channel 0, patch row 1, piece 0 of the tensor's first stage = lane 9 of wave 0's slot 0
-  const bool own_first = split == 0 && c0 == 0 && wave == 0;
+  // The piece that begins at x[-1], BEFORE the tensor, must not be fetched: image row 0 of channel 0 of image 0, piece 0 -- patch row 1
+  // of the tensor's first stage (lane PPR of wave 0's slot 0) and, in the up-sampled form, also patch row 0 of the stage below it
+  // (lane 0).  That lane's piece is zero-filled and x[0 .. 2] are written behind it once the stage has landed.
 
   bool zl = false, zr = false;  // the stage copied last begins / ends at the image's left / right edge
   int nq = 0, bx, by, bn;
@@ -871,16 +888,18 @@ __global__ void __launch_bounds__(512) wino_wgrad_rows_mfma(const WwArgs a) {
   __amdgpu_buffer_rsrc_t st_xs, st_ys;
   int st_sx = 0, st_sy = 0, st_so = 0;
   bool st_top = false, st_bot = false, st_patch = false;
+  int st_lowlane = -1;
   auto issue_begin = [&](int so) __attribute__((always_inline)) {
     const bool ok = nq < a.per && split * a.per + nq < a.nblk;
     st_top = by == 0;
     st_bot = by == Ht - 1;
     st_xs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xbase), 0, ok ? (int)(a.x_bytes + xshift) : 0, 0x00020000);
     st_ys = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gy), 0, ok ? (int)a.gy_bytes : 0, 0x00020000);
-    st_sx = ((bn * a.Cin + c0) * HW + 2 * by * a.W + 32 * bx) * 4;
+    st_sx = UPS ? ((bn * a.Cin + c0) * HWx + by * Wx + 16 * bx) * 4 : ((bn * a.Cin + c0) * HW + 2 * by * a.W + 32 * bx) * 4;
     st_sy = ((bn * a.Cout + o0) * HW + 2 * by * a.W + 32 * bx) * 4;
-    if (a.TBN & 16) { st_sx = (c0 * HW + (2 + (split & 31) * 2) * a.W) * 4; st_sy = (o0 * HW + (2 + (split & 31) * 2) * a.W) * 4; }  // (rows >= 1: inside the tensor)
-    st_patch = own_first && nq == 0;
+    if (!UPS && (a.TBN & 16)) { st_sx = (c0 * HW + (2 + (split & 31) * 2) * a.W) * 4; st_sy = (o0 * HW + (2 + (split & 31) * 2) * a.W) * 4; }  // (rows >= 1: inside the tensor)
+    st_lowlane = (bn == 0 && c0 == 0 && bx == 0 && ok) ? (by == 0 ? PPR : ((UPS && by == 1) ? 0 : -1)) : -1;
+    st_patch = wave == 0 && st_lowlane >= 0;
     st_so = so;
     zl = bx == 0;
     zr = bx == a.blocks_x - 1;
@@ -903,7 +922,7 @@ __global__ void __launch_bounds__(512) wino_wgrad_rows_mfma(const WwArgs a) {
         if (k < XI) {
           unsigned v = voff[m];
           if (st_top || st_bot || st_patch) {  // (wave-uniform; the common stage takes the offsets as they are)
-            const bool kill = (st_top && ((cls >> (4 * m)) & 1u)) || (st_bot && ((cls >> (4 * m + 1)) & 1u)) || (st_patch && m == 0 && lane == 9);
+            const bool kill = (st_top && ((cls >> (4 * m)) & 1u)) || (st_bot && ((cls >> (4 * m + 1)) & 1u)) || (st_patch && m == 0 && lane == st_lowlane);
             v = kill ? INV : v;
           }
           __builtin_amdgcn_raw_ptr_buffer_load_lds(st_xs, (rw_lds_ptr)dst, 16, (int)v, st_sx, 0, 0);
@@ -922,6 +941,12 @@ __global__ void __launch_bounds__(512) wino_wgrad_rows_mfma(const WwArgs a) {
   // the stage at word offset so has landed (this wave's pieces): zero the pixels beside the image that this wave copied
   auto landed = [&](int so) __attribute__((always_inline)) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (st_patch && lane == st_lowlane) {  // (the piece that begins at x[-1]: zero-filled, now x[0 .. 2] behind the zero)
+      float* pc = smem + so + 4 * lane;
+      pc[1] = a.x[0];
+      pc[2] = a.x[1];
+      pc[3] = a.x[2];
+    }
     if (zl || zr) {  // (wave-uniform)
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
@@ -947,7 +972,8 @@ __global__ void __launch_bounds__(512) wino_wgrad_rows_mfma(const WwArgs a) {
   for (int j = 0; j < OT; ++j) bsum[j] = 0.f;
 
   // LDS byte addresses of this lane's operand reads (the low 32 bits of a shared-aperture address are the LDS offset)
-  const unsigned xrd_a = (unsigned)reinterpret_cast<size_t>(smem + col * RW_CSX + 2 * rq);       // + 16 i CSX + row RS + 8 ks: [e0, p0 | p1, e1] of tile 4 ks + rq
+  // (UPS: tile T's low-res pixels T-1, T, T+1 are words T, T+1, T+2 of a row)
+  const unsigned xrd_a = (unsigned)reinterpret_cast<size_t>(smem + col * CSX + (UPS ? 1 : 2) * rq);  // + 16 i CSX + row RS + 8 ks: [e0, p0 | p1, e1] of tile 4 ks + rq
   const unsigned yrd_a = (unsigned)reinterpret_cast<size_t>(smem + YB + col * RW_CSY + 2 * rq);  // + 16 j CSY + row 32 + 8 ks: (t.0, t.1)
 
   auto tile_loop = [&](auto i_, auto odd_) __attribute__((always_inline)) {
@@ -956,8 +982,15 @@ __global__ void __launch_bounds__(512) wino_wgrad_rows_mfma(const WwArgs a) {
     constexpr int RA = I == 0 ? 0 : (I == 2 ? 2 : 1), RB = I == 0 ? 2 : (I == 1 ? 2 : (I == 2 ? 1 : 3));  // u = d[RA] +- d[RB]
     constexpr bool PLUS = I == 1;
     constexpr bool Y0 = I != 3, Y1 = I != 0;  // which gy rows the component row needs
+    // UPS: the component row is  i = 0: l[TY-1] - l[TY];  1: 2 l[TY];  2: ZERO;  3: l[TY] - l[TY+1]  over the low-res pixels (L, C, R) =
+    // (TX-1, TX, TX+1), the columns  0: uL - uC;  1: 2 uC;  2: ZERO;  3: uC - uR -- 9 of the 16 components.  Row 2 has no wave work
+    // at all (IDLE), an odd wave computes column 1 only (NP = 1); the factors of two are applied once, to the accumulators.
+    constexpr bool IDLE = UPS && I == 2;
+    constexpr int NP = (UPS && ODD) ? 1 : 2;                        // components this wave accumulates
+    constexpr int UA = I == 0 ? 0 : 1, UB = I == 0 ? 1 : 2;         // UPS: low-res rows of u = l[UA] - l[UB]  (I = 1: l[1] alone)
     struct Raw {
       f32x2 al[CT], ah[CT], bl[CT], bh[CT], t0[OT], t1[OT];  // rows RA / RB as (e0, p0) | (p1, e1); gy rows
+      float ua[CT][3], ub[CT][3];                             // UPS: (L, C, R) of the two low-res rows
     };
     struct Ops {
       f32x2 av[CT], bv[OT];  // the wave's two x components per in-channel tile / two gy components (unsigned) per out-channel tile
@@ -966,11 +999,27 @@ __global__ void __launch_bounds__(512) wino_wgrad_rows_mfma(const WwArgs a) {
       constexpr int KS = decltype(ks_)::value;
       rw_static_for<CT>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
-        constexpr int o = (16 * i * RW_CSX + 8 * KS) * 4;
-        r.al[i] = rw_lds64<o + RA * RW_RS * 4>(xa);
-        r.ah[i] = rw_lds64<o + RA * RW_RS * 4 + 8>(xa);
-        r.bl[i] = rw_lds64<o + RB * RW_RS * 4>(xa);
-        r.bh[i] = rw_lds64<o + RB * RW_RS * 4 + 8>(xa);
+        if constexpr (UPS) {
+          constexpr int o = (16 * i * CSX + 4 * KS) * 4;
+          if constexpr (!ODD) {
+            r.ua[i][0] = rw_lds32<o + UA * RS * 4>(xa);
+            r.ua[i][2] = rw_lds32<o + UA * RS * 4 + 8>(xa);
+          }
+          r.ua[i][1] = rw_lds32<o + UA * RS * 4 + 4>(xa);
+          if constexpr (I != 1) {
+            if constexpr (!ODD) {
+              r.ub[i][0] = rw_lds32<o + UB * RS * 4>(xa);
+              r.ub[i][2] = rw_lds32<o + UB * RS * 4 + 8>(xa);
+            }
+            r.ub[i][1] = rw_lds32<o + UB * RS * 4 + 4>(xa);
+          }
+        } else {
+          constexpr int o = (16 * i * CSX + 8 * KS) * 4;
+          r.al[i] = rw_lds64<o + RA * RS * 4>(xa);
+          r.ah[i] = rw_lds64<o + RA * RS * 4 + 8>(xa);
+          r.bl[i] = rw_lds64<o + RB * RS * 4>(xa);
+          r.bh[i] = rw_lds64<o + RB * RS * 4 + 8>(xa);
+        }
       });
     };
     auto read_y = [&](Raw& r, unsigned ya, auto ks_) __attribute__((always_inline)) {
@@ -985,7 +1034,18 @@ __global__ void __launch_bounds__(512) wino_wgrad_rows_mfma(const WwArgs a) {
     auto wait_raw = [&](Raw& r) __attribute__((always_inline)) {
       rw_lds_wait();
 #pragma unroll
-      for (int i = 0; i < CT; ++i) { rw_tie(r.al[i]); rw_tie(r.ah[i]); rw_tie(r.bl[i]); rw_tie(r.bh[i]); }
+      for (int i = 0; i < CT; ++i) {
+        if constexpr (UPS) {
+          if constexpr (!ODD) { rw_tie(r.ua[i][0]); rw_tie(r.ua[i][2]); }
+          rw_tie(r.ua[i][1]);
+          if constexpr (I != 1) {
+            if constexpr (!ODD) { rw_tie(r.ub[i][0]); rw_tie(r.ub[i][2]); }
+            rw_tie(r.ub[i][1]);
+          }
+        } else {
+          rw_tie(r.al[i]); rw_tie(r.ah[i]); rw_tie(r.bl[i]); rw_tie(r.bh[i]);
+        }
+      }
 #pragma unroll
       for (int j = 0; j < OT; ++j) {
         if constexpr (Y0) rw_tie(r.t0[j]);
@@ -994,6 +1054,22 @@ __global__ void __launch_bounds__(512) wino_wgrad_rows_mfma(const WwArgs a) {
     };
     // raw rows -> MFMA operands
     auto transform_x = [&](const Raw& r, Ops& o) __attribute__((always_inline)) {
+      if constexpr (UPS) {
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+          float uL = 0.f, uC, uR = 0.f;
+          if constexpr (I == 1) {
+            uC = r.ua[i][1];
+            if constexpr (!ODD) { uL = r.ua[i][0]; uR = r.ua[i][2]; }
+          } else {
+            uC = r.ua[i][1] - r.ub[i][1];
+            if constexpr (!ODD) { uL = r.ua[i][0] - r.ub[i][0]; uR = r.ua[i][2] - r.ub[i][2]; }
+          }
+          if constexpr (!ODD) o.av[i] = f32x2{uL - uC, uC - uR};
+          else o.av[i] = f32x2{uC, 0.f};
+        }
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < CT; ++i) {
         const f32x2 ul = PLUS ? r.al[i] + r.bl[i] : pk_sub(r.al[i], r.bl[i]);  // (u0, u1)
@@ -1030,7 +1106,7 @@ __global__ void __launch_bounds__(512) wino_wgrad_rows_mfma(const WwArgs a) {
       if constexpr (OT == 4) asm volatile("" : "+v"(o.bv[0]), "+v"(o.bv[1]), "+v"(o.bv[2]), "+v"(o.bv[3]));
     };
     // MFMAs LO .. HI - 1 of a k-step, n = (p CT + i) OT + j
-    constexpr int NMF = 2 * CT * OT;
+    constexpr int NMF = NP * CT * OT;
     auto mma = [&](const Ops& o, auto lo_, auto hi_) __attribute__((always_inline)) {
       constexpr int LO = decltype(lo_)::value, HI = decltype(hi_)::value;
       rw_static_for<HI - LO>([&](auto nc) __attribute__((always_inline)) {
@@ -1050,6 +1126,10 @@ __global__ void __launch_bounds__(512) wino_wgrad_rows_mfma(const WwArgs a) {
     using N3_ = std::integral_constant<int, C3>; using N4_ = std::integral_constant<int, C4>; using N5_ = std::integral_constant<int, C5>;
     using N6_ = std::integral_constant<int, NMF>;
     auto step = [&](const Ops& cur, Ops& nxt, Raw& r, unsigned xa, unsigned ya, auto nks_, bool bias_on, auto&& between) __attribute__((always_inline)) {
+      if constexpr (IDLE) {  // (copies its share of the stages and keeps the barriers; its accumulators stay zero)
+        between();
+        return;
+      }
       mma(cur, N0_{}, N1_{});
       between();
       __builtin_amdgcn_sched_barrier(0);
@@ -1081,19 +1161,16 @@ __global__ void __launch_bounds__(512) wino_wgrad_rows_mfma(const WwArgs a) {
     // prologue: stage 0 in buffer 0, stage 1 on its way into buffer 1, the operands of stage 0's first k-step
     issue_stage(0);
     landed(0);
-    if (own_first && lane == 9) {  // x[0 .. 2] of the tensor's first row (the piece itself was zero-filled: it begins at x[-1])
-      smem[RW_RS + 1] = a.x[0];
-      smem[RW_RS + 2] = a.x[1];
-      smem[RW_RS + 3] = a.x[2];
-    }
     __syncthreads();
     if (a.per > 1 && staging) issue_stage(STG);
-    read_x(r, xrd_a, K0{});
-    read_y(r, yrd_a, K0{});
-    wait_raw(r);
-    transform_x(r, o0);
-    transform_y(r, o0, img < a.bias_n);
-    fence(o0);
+    if constexpr (!IDLE) {
+      read_x(r, xrd_a, K0{});
+      read_y(r, yrd_a, K0{});
+      wait_raw(r);
+      transform_x(r, o0);
+      transform_y(r, o0, img < a.bias_n);
+      fence(o0);
+    }
     __builtin_amdgcn_sched_barrier(0);
     for (int q = 0; q < a.per; ++q) {
       const int so = (q & 1) * STG, sn = STG - so;
@@ -1115,19 +1192,25 @@ __global__ void __launch_bounds__(512) wino_wgrad_rows_mfma(const WwArgs a) {
       });
     }
     // signs of the gy components computed unsigned: (i, 3) for i < 3, (3, 0), (3, 1), (3, 2)
-    constexpr float S0 = I == 3 ? -1.f : 1.f;                                // p = 0: column 0 (even) / 1 (odd)
-    constexpr float S1 = ODD ? (I == 3 ? -1.f : 1.f) : (I == 3 ? 1.f : -1.f);  // p = 1: column 3 (even) / 2 (odd)
+    // (UPS: x 2 for component row 1, x 2 for column 1 -- the transforms above leave those factors out)
+    constexpr float F0 = UPS ? (I == 1 ? 2.f : 1.f) * (ODD ? 2.f : 1.f) : 1.f, F1 = UPS ? (I == 1 ? 2.f : 1.f) : 1.f;
+    constexpr float S0 = (I == 3 ? -1.f : 1.f) * F0;                                  // p = 0: column 0 (even) / 1 (odd)
+    constexpr float S1 = (ODD ? (I == 3 ? -1.f : 1.f) : (I == 3 ? 1.f : -1.f)) * F1;  // p = 1: column 3 (even) / 2 (odd)
 #pragma unroll
     for (int i = 0; i < CT; ++i)
 #pragma unroll
       for (int j = 0; j < OT; ++j) {
-        if constexpr (S0 < 0.f) acc[0][i][j] = -acc[0][i][j];
-        if constexpr (S1 < 0.f) acc[1][i][j] = -acc[1][i][j];
+        if constexpr (S0 != 1.f) acc[0][i][j] = acc[0][i][j] * S0;
+        if constexpr (S1 != 1.f && NP == 2) acc[1][i][j] = acc[1][i][j] * S1;
       }
   };
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-  switch (wave) {
+  // component pair of this wave: rw = 2 i + parity.  UPS: row 2 is idle and an odd wave has half the work, and waves w and w + 4 of a
+  // workgroup share a SIMD (MI355X_MICROARCH.md: cyclic placement), so the pairs there are (row even, row odd) for rows 0, 1, 3 and
+  // (idle, idle): three component-units on three SIMDs instead of four on each
+  const int rw = UPS ? 2 * ((wave & 3) == 2 ? 3 : ((wave & 3) == 3 ? 2 : (wave & 3))) + (wave >> 2) : wave;
+  switch (rw) {
     case 0: tile_loop(I0{}, std::false_type{}); break;
     case 1: tile_loop(I0{}, std::true_type{}); break;
     case 2: tile_loop(I1{}, std::false_type{}); break;
@@ -1153,7 +1236,7 @@ __global__ void __launch_bounds__(512) wino_wgrad_rows_mfma(const WwArgs a) {
           for (int j = 0; j < OT; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-              G[((2 * wave + p) * 32 + ii * 16 + rq * 4 + g) * 64 + ((j ^ rq) * 16 + col)] = acc[p][i][j][g];
+              G[((2 * rw + p) * 32 + ii * 16 + rq * 4 + g) * 64 + ((j ^ rq) * 16 + col)] = acc[p][i][j][g];
         }
       }
     __syncthreads();
@@ -1189,8 +1272,8 @@ __global__ void __launch_bounds__(512) wino_wgrad_rows_mfma(const WwArgs a) {
       }
     }
   }
-  // bias gradient: wave 2 holds, per out-channel tile, lane (rq, col) = its tiles' sums of channel 16 j + col
-  if (wave == 2 && cb == 0) {
+  // bias gradient: the wave of component pair 2 holds, per out-channel tile, lane (rq, col) = its tiles' sums of channel 16 j + col
+  if (rw == 2 && cb == 0) {
 #pragma unroll
     for (int j = 0; j < OT; ++j) {
       float v = bsum[j];
@@ -1375,7 +1458,11 @@ int launch_ww(const WwArgs& a, dim3 grid, hipStream_t s) {
 bool ww_rows_takes(const WwPlan& pl, bool ups) {
   const char* e = getenv("MG_WGRAD_ROWS");  // (read per call: tests and A/B runs switch it inside one process)
   const int mode = e == nullptr ? 1 : atoi(e);
-  if (mode == 0 || ups || (pl.a.W % 32) != 0 || (pl.a.H % 2) != 0) return false;
+  if (mode == 0 || (pl.a.W % 32) != 0 || (pl.a.H % 2) != 0) return false;
+  if (ups) {
+    const char* u = getenv("MG_WGRAD_ROWS_UPS");  // (measurement switch: 0 = the up-sampled-input layers stay on the chunk-staged kernels)
+    if (u != nullptr && atoi(u) == 0) return false;
+  }
   if (pl.CT == 4 && pl.OT == 4) return false;  // (256 accumulators + raw set + two operand sets: 68 bytes of scratch per lane; not instantiated)
   return mode >= 2 || pl.CT * pl.OT >= 4;  // (blocks of one channel tile on either side: 2 MFMAs per wave and k-step -- the chunk-staged narrow form is as fast or faster, profiles/r06_wgrad_rows_steps.txt)
 }
@@ -1399,36 +1486,37 @@ void plan_rows(WwPlan& pl) {
   pl.rows = true;
 }
 
-template <int CT, int OT>
+template <int CT, int OT, bool UPS>
 int launch_rows(const WwArgs& a, dim3 grid, hipStream_t s) {
-  constexpr size_t lds = RwGeom<CT, OT>::lds_bytes();
+  constexpr size_t lds = RwGeom<CT, OT, UPS>::lds_bytes();
   static MgPerDevice once;
   if (mg_first_use_on_device(once)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_wgrad_rows_mfma<CT, OT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_wgrad_rows_mfma<CT, OT, UPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
   }
-  hipLaunchKernelGGL((wino_wgrad_rows_mfma<CT, OT>), grid, dim3(512), lds, s, a);
+  hipLaunchKernelGGL((wino_wgrad_rows_mfma<CT, OT, UPS>), grid, dim3(512), lds, s, a);
   MG_CHECK_LAUNCH("mg_wino3x3_wgrad (rows)");
   return MG_OK;
 }
 
+template <bool UPS>
 int dispatch_rows(int CT, int OT, const WwArgs& a, dim3 grid, hipStream_t s) {
   switch (CT * 10 + OT) {
-    case 11: return launch_rows<1, 1>(a, grid, s);
-    case 12: return launch_rows<1, 2>(a, grid, s);
-    case 13: return launch_rows<1, 3>(a, grid, s);
-    case 14: return launch_rows<1, 4>(a, grid, s);
-    case 21: return launch_rows<2, 1>(a, grid, s);
-    case 22: return launch_rows<2, 2>(a, grid, s);
-    case 23: return launch_rows<2, 3>(a, grid, s);
-    case 24: return launch_rows<2, 4>(a, grid, s);
-    case 31: return launch_rows<3, 1>(a, grid, s);
-    case 32: return launch_rows<3, 2>(a, grid, s);
-    case 33: return launch_rows<3, 3>(a, grid, s);
-    case 34: return launch_rows<3, 4>(a, grid, s);
-    case 41: return launch_rows<4, 1>(a, grid, s);
-    case 42: return launch_rows<4, 2>(a, grid, s);
-    case 43: return launch_rows<4, 3>(a, grid, s);
+    case 11: return launch_rows<1, 1, UPS>(a, grid, s);
+    case 12: return launch_rows<1, 2, UPS>(a, grid, s);
+    case 13: return launch_rows<1, 3, UPS>(a, grid, s);
+    case 14: return launch_rows<1, 4, UPS>(a, grid, s);
+    case 21: return launch_rows<2, 1, UPS>(a, grid, s);
+    case 22: return launch_rows<2, 2, UPS>(a, grid, s);
+    case 23: return launch_rows<2, 3, UPS>(a, grid, s);
+    case 24: return launch_rows<2, 4, UPS>(a, grid, s);
+    case 31: return launch_rows<3, 1, UPS>(a, grid, s);
+    case 32: return launch_rows<3, 2, UPS>(a, grid, s);
+    case 33: return launch_rows<3, 3, UPS>(a, grid, s);
+    case 34: return launch_rows<3, 4, UPS>(a, grid, s);
+    case 41: return launch_rows<4, 1, UPS>(a, grid, s);
+    case 42: return launch_rows<4, 2, UPS>(a, grid, s);
+    case 43: return launch_rows<4, 3, UPS>(a, grid, s);
   }
   mg_set_error("mg_wino3x3_wgrad: internal tile error (CT=%d, OT=%d)", CT, OT);
   return MG_EINVAL;
@@ -1516,7 +1604,7 @@ void fill_job(const WwPlan& pl, float* gw, float* gb, int accumulate, mg_wgrad_j
 
 int launch_single_ww(const WwPlan& pl, bool ups, hipStream_t s) {
   dim3 grid(pl.nsplit, pl.ncb * pl.a.nob);
-  if (pl.rows) return dispatch_rows(pl.CT, pl.OT, pl.a, grid, s);
+  if (pl.rows) return ups ? dispatch_rows<true>(pl.CT, pl.OT, pl.a, grid, s) : dispatch_rows<false>(pl.CT, pl.OT, pl.a, grid, s);
   return ups ? dispatch_ww<true>(pl.CT, pl.OT, pl.a, grid, s) : dispatch_ww<false>(pl.CT, pl.OT, pl.a, grid, s);
 }
 

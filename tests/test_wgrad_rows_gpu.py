@@ -67,6 +67,44 @@ def test_rows_kernel_matches_autograd_and_the_chunk_kernels(shape, monkeypatch):
     assert _rel(res["2"], res["0"]) <= 2e-6
 
 
+# (N, Cin, Cout, H, W) of gy; x is (N, Cin, H/2, W/2) and the convolution input its nearest x2 up-sampling (generator.py:24-31)
+UPS_SHAPES = [(2, 64, 48, 32, 32), (1, 80, 64, 64, 64), (3, 32, 16, 32, 64), (2, 48, 32, 64, 32), (2, 32, 32, 4, 32), (1, 64, 48, 128, 128),
+              (5, 24, 40, 2, 32), (2, 96, 80, 32, 32), (7, 64, 64, 6, 96)]
+
+
+@pytest.mark.parametrize("shape", UPS_SHAPES)
+def test_rows_kernel_with_upsampled_input(shape, monkeypatch):
+    """The up-sampled-input form (9 of the 16 Winograd components are identically zero there and are not computed) against fp64 autograd
+    through `F.interpolate(nearest)` + `F.conv2d`, and against the chunk-staged kernels (MG_WGRAD_ROWS=0)."""
+    ops = _ops()
+    monkeypatch.setenv("MG_WINO_WGRAD_MIN_PIXELS", "1")
+    n, ci, co, h, w = shape
+    g = torch.Generator().manual_seed(67)
+    x = torch.randn(n, ci, h // 2, w // 2, generator=g).double()
+    gy = torch.randn(n, co, h, w, generator=g).double()
+    wt = torch.zeros(co, ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    bt = torch.zeros(co, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), wt, bt, padding=1) * gy).sum().backward()
+    xd, gyd = x.float().to(DEV), gy.float().to(DEV)
+    res = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("MG_WGRAD_ROWS", mode)
+        gw = torch.full((co, ci, 3, 3), 7.0, device=DEV)
+        gb = torch.full((co,), 7.0, device=DEV)
+        ops.conv3x3_wgrad(xd, gyd, gw, gb, ups=True)
+        assert _rel(gw, wt.grad) <= 3e-6, (mode, _rel(gw, wt.grad))
+        assert _rel(gb, bt.grad) <= 3e-6, (mode, _rel(gb, bt.grad))
+        gw2 = torch.empty_like(gw)
+        ops.conv3x3_wgrad(xd, gyd, gw2, None, ups=True)
+        assert torch.equal(gw, gw2)
+        if n > 1:
+            gb3 = torch.empty(co, device=DEV)
+            ops.conv3x3_wgrad(xd, gyd, gw2, gb3, ups=True, bias_n=n // 2)
+            assert _rel(gb3, gy[:n // 2].sum(dim=(0, 2, 3))) <= 3e-6, mode
+        res[mode] = gw
+    assert _rel(res["2"], res["0"]) <= 2e-6
+
+
 def test_rows_kernel_inside_a_deferred_sweep(monkeypatch):
     """Layers of a sweep (conv3x3_wgrad(..., defer=)): large layers take the row-staged kernel, small ones share the grouped launch."""
     ops = _ops()

@@ -52,8 +52,9 @@ def _all_kinds(ops, x, wt, b, gy, act_out, act_up, other, coef):
     return out
 
 
-# (N, Cin, Cout, H, W): one, two and three out-channel tiles per wave; 2..6 chunks; several tile blocks per row; ragged batch
-STRIP_SHAPES = [(2, 16, 32, 32, 64), (3, 32, 16, 16, 96), (1, 48, 48, 48, 32), (2, 32, 32, 64, 32), (1, 16, 16, 16, 32)]
+# (N, Cin, Cout, H, W): one, two and three out-channel tiles per wave; 2..14 chunks; several tile blocks per row; ragged batch
+STRIP_SHAPES = [(2, 16, 32, 32, 64), (3, 32, 16, 16, 96), (1, 48, 48, 48, 32), (2, 32, 32, 64, 32), (1, 16, 16, 16, 32),
+                (2, 96, 80, 32, 32), (1, 112, 96, 16, 32)]  # (96 / 112 input channels: the bank of one out-channel tile per wave; the data gradient's of two)
 
 
 @pytest.mark.parametrize("shape", STRIP_SHAPES)
