@@ -65,6 +65,13 @@ __device__ __forceinline__ c2 sub_conj(c2 a, c2 z) {  // a - conj z
   return r;
 }
 
+// One 8-byte LDS read as `ds_read_b64`.  hipcc merges two such reads at a common base into `ds_read2_b64` / `ds_read2st64_b64`, which
+// this LDS serves at HALF the rate with banks modulo 32 (8 cycles per wave-instruction against 2 x 2; MI355X_MICROARCH.md, LDS) -- the
+// column strides here are laid out for the 64-bank rule of `ds_read_b64`.  A volatile access is not merged (and stays under the
+// compiler's s_waitcnt bookkeeping).
+typedef const volatile __attribute__((address_space(3))) c2* lds_c2_ptr;
+__device__ __forceinline__ c2 lds_c2(const c2* p) { return *(lds_c2_ptr)p; }  // (the explicit LDS address space: a volatile generic load is a flat_load)
+
 // 4-point DFT; MI2: y2 is handed over without its pending factor -i
 template <bool MI2>
 __device__ __forceinline__ void dft4(c2 y0, c2 y1, c2 y2, c2 y3, c2& q0, c2& q1, c2& q2, c2& q3) {
@@ -200,7 +207,7 @@ __global__ void __launch_bounds__(64 * NWAVE, 2) stft1024_kernel(const void* __r
       c2* xb = xbuf + fl * XSTR;
       c2 v[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = xn[r] * *reinterpret_cast<const c2*>(win + 2 * (lane + 64 * r));
+      for (int r = 0; r < 8; ++r) v[r] = xn[r] * lds_c2(reinterpret_cast<const c2*>(win + 2 * (lane + 64 * r)));
       {  // one call site: next frame of this tile, first frame of the next tile, or nothing (t = T reads as zeros)
         const int tnext = tile + (int)gridDim.x < ntiles ? (tile + (int)gridDim.x) * FPB + wave * FPW : T;
         load_frame(f + 1 < FPW ? t0 + fl + 1 : tnext, xn);
@@ -220,7 +227,7 @@ __global__ void __launch_bounds__(64 * NWAVE, 2) stft1024_kernel(const void* __r
         const int k = lane & 7;
 #pragma unroll
         for (int r = 0; r < 8; ++r)  // ((lane >> 4) + 4 r) & 7 = (lane >> 4) ^ 4 (r & 1): two base addresses + immediate offsets
-          v[r] = cmul(xb[((lane ^ (lane >> 4)) ^ (4 * (r & 1))) + 64 * r], tw1[r * 8 + k]);
+          v[r] = cmul(lds_c2(xb + (((lane ^ (lane >> 4)) ^ (4 * (r & 1))) + 64 * r)), lds_c2(tw1 + r * 8 + k));
         dft8(v);
         __builtin_amdgcn_wave_barrier();
         // Exchange 2: element e = 64 g + k + 8 r (g = j >> 3) is stored at e ^ (8 * (g & 1)): the two g of a 16-lane write group
@@ -232,7 +239,7 @@ __global__ void __launch_bounds__(64 * NWAVE, 2) stft1024_kernel(const void* __r
       }
       // pass 2 (Ns = 64): in[j + 64 r] * exp(-2 pi i r j / 512); result Z[j + 64 r] stays in lane j, register r
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = cmul(xb[(lane + 64 * r) ^ (8 * (r & 1))], tw2[r * 64 + lane]);
+      for (int r = 0; r < 8; ++r) v[r] = cmul(lds_c2(xb + ((lane + 64 * r) ^ (8 * (r & 1)))), lds_c2(tw2 + r * 64 + lane));
       dft8(v);
       __builtin_amdgcn_wave_barrier();
       // untangle: X[k] = (Z[k] + conj Z[512-k])/2 - i/2 * e^{-2 pi i k/1024} * (Z[k] - conj Z[512-k]),  k = lane + 64 r.
@@ -251,7 +258,7 @@ __global__ void __launch_bounds__(64 * NWAVE, 2) stft1024_kernel(const void* __r
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const int k = lane + 64 * r;
-        const c2 wd = cmul(tw[k], sub_conj(v[r], zc[r]));
+        const c2 wd = cmul(lds_c2(tw + k), sub_conj(v[r], zc[r]));
         xb[k] = add_mi(add_conj(v[r], zc[r]), wd);  // e - i * wd  (pass 2 has read the column: the exchanges are done with it)
       }
     }
@@ -267,7 +274,7 @@ __global__ void __launch_bounds__(64 * NWAVE, 2) stft1024_kernel(const void* __r
         if (t < T) {  // T even: t + 1 < T too
 #pragma unroll 8
           for (int k = tid / (FPB / 2); k < NB; k += 64 * NWAVE / (FPB / 2)) {
-            const c2 o0 = xbuf[(2 * fp) * XSTR + k], o1 = xbuf[(2 * fp + 1) * XSTR + k];
+            const c2 o0 = lds_c2(xbuf + (2 * fp) * XSTR + k), o1 = lds_c2(xbuf + (2 * fp + 1) * XSTR + k);
             __builtin_nontemporal_store(f32x4{o0.x, o0.y, o1.x, o1.y}, reinterpret_cast<f32x4*>(out_re + 2 * ((size_t)k * T + t)));
           }
         }

@@ -11,6 +11,12 @@ R = lambda *s: torch.randn(*s, device=dev)
 if case == "g54":      # fused ups conv 64->48 @128 + lrelu + pixnorm
     x = R(N, 64, 64, 64); wp = ops.pack_conv3x3(R(48, 64, 3, 3) * 0.05, False); b = R(48)
     fn = lambda: ops.conv3x3(x, wp, b, 48, ups=True, lrelu=True, pixnorm=True, want_y=False)
+elif case == "up54":   # the generator's last up-sampling conv in sub-pixel form: 64 -> 48, 64x64 -> 128x128, LeakyReLU + PixelNorm
+    x = R(N, 64, 64, 64); wp = ops.pack_upconv3x3(R(48, 64, 3, 3) * 0.05); b = R(48)
+    fn = lambda: ops.upconv3x3(x, wp, b, 48, lrelu=True, pixnorm=True, want_y=False)
+elif case == "updg54":  # its data gradient: (N, 48, 128, 128) -> (N, 64, 64, 64)
+    gy = R(N, 48, 128, 128); wp = ops.pack_upconv3x3_dgrad(R(48, 64, 3, 3) * 0.05)
+    fn = lambda: ops.upconv3x3_dgrad(gy, wp, 64)
 elif case == "d20":    # conv 48->64 @128 + lrelu
     x = R(N, 48, 128, 128); wp = ops.pack_conv3x3(R(64, 48, 3, 3) * 0.05, False); b = R(64)
     fn = lambda: ops.conv3x3(x, wp, b, 64, lrelu=True)
