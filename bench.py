@@ -262,7 +262,7 @@ def stft_record(device, cpu: bool):
                         "algorithmic_bytes": 5120.0 * T,
                         "basis": "5 120 algorithmic bytes per frame x frames per launch / HIP-event launch time; traffic = "
                                  "HBM bytes per launch, NOT measured in this run: read from profiles/traffic_stft_kernel.json "
-                                 "(rocprofv3 PMC passes, tools/measure_traffic.sh stft, last re-measured in round 4)"}}
+                                 "(rocprofv3 PMC passes, tools/measure_traffic.sh stft, re-measured in round 6)"}}
     ms_codec = timeit(lambda: audio.stft_to_phase_magn(c_keep), 50, warm=10)
     rec["codec"] = {"workload": "stft_to_phase_magn (functions.py:65-94) of that file's 512 x 103 360 bins -> 201 images",
                     "ms_per_file": ms_codec,
@@ -743,7 +743,7 @@ def main():
                          "step_traffic": step_traffic(args.level, args.batch),
                          "traffic_basis": "NOT measured in this run: rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, separate passes) read "
                                           "from profiles/traffic_dominant_kernel.json (tools/measure_traffic.sh) and "
-                                          "profiles/traffic_step_l5.json (tools/measure_step_traffic.sh), re-measured in round 5",
+                                          "profiles/traffic_step_l5.json (tools/measure_step_traffic.sh), re-measured in round 6",
                          # dominant launch, timed live with HIP events on its stream: frac = executed FLOPs over the peak
                          "dominant_kernel": {**dom, "frac": dom["executed_tflops"] / MFMA_F32_PEAK_TFLOPS,
                                              "algorithmic_frac": dom["tflops"] / MFMA_F32_PEAK_TFLOPS}},
