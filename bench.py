@@ -63,11 +63,12 @@ def flops_per_image(level: int, rand_channels: int) -> float:
 
 def executed_flops_per_image(level: int, rand_channels: int, batch: int) -> float:
     """FLOPs the MFMA pipe actually executes per image and D+G step: the same layer walk as `flops_per_image`, each 3x3
-    convolution pass weighted 1/2.25 where the engine runs it in Winograd F(2x2,3x3) / F(3x3,2x2) or sub-pixel form (the kernel
+    convolution pass weighted 1/2.25 where the engine runs it in Winograd F(2x2,3x3) / F(3x3,2x2) or sub-pixel form, 1/4 where an
+    up-sampling layer runs in 9-component Winograd form (csrc/wino_ups.hip; weight gradient: (1/2.25)(9/16)) (the kernel
     choice predicates of musicgan_amd.ops, evaluated for the batch each pass really sees: 3N in the fused critic step, N
     elsewhere) and 1 where it takes the direct implicit GEMM.  Static arithmetic; padding of odd channel counts not counted."""
     from musicgan_amd import ops
-    from musicgan_amd.networks.engine import gen_conv_executes_reduced
+    from musicgan_amd.networks.engine import gen_conv_exec_factor
     tail = [128, 112, 96, 80, 64, 48, 32, 16]
     ins = [rand_channels] + tail[:-1]
     dch = [(16, 32), (32, 48), (48, 64), (64, 80), (80, 96), (96, 112), (112, 128), (128, 144), (144, 160)]
@@ -78,18 +79,22 @@ def executed_flops_per_image(level: int, rand_channels: int, batch: int) -> floa
         return 18.0 * cin * cout * h * w * nb * (W if ops.wino3x3_supported(nb, cout, h, w, pixnorm=pixnorm, cin=cin) else 1.0)
 
     def wgrad(nb, cin, cout, h, w, ups=False):
-        return 18.0 * cin * cout * h * w * nb * (W if ops.wino_wgrad_supported(nb, cin, cout, h, w, ups=ups) else 1.0)
+        if not ops.wino_wgrad_supported(nb, cin, cout, h, w, ups=ups):
+            return 18.0 * cin * cout * h * w * nb
+        nine = ops.wino_wgrad_form(nb, cin, cout, h, w, ups=ups) == 2  # up-sampled input, row-staged kernel: 9 of the 16 products
+        return 18.0 * cin * cout * h * w * nb * W * (9.0 / 16.0 if nine else 1.0)
 
     def gen_pass(backward: bool) -> float:
         f, s = 0.0, 2
         for i in range(level + 1):
             ci, co = ins[i], tail[i]
             # the two PixelNorm convs of a block: the form the engine really runs (engine.gen_conv_form, shared with PackCache)
-            f += 18.0 * ci * ci * s * s * n * (W if gen_conv_executes_reduced(n, ci, ci, s, s, False) else 1.0)
-            f += 18.0 * ci * co * 4 * s * s * n * (W if gen_conv_executes_reduced(n, ci, co, s, s, True) else 1.0)
+            f += 18.0 * ci * ci * s * s * n * gen_conv_exec_factor(n, ci, ci, s, s, False)
+            f += 18.0 * ci * co * 4 * s * s * n * gen_conv_exec_factor(n, ci, co, s, s, True)
             if backward:
                 f += wgrad(n, ci, co, 2 * s, 2 * s, ups=True) + wgrad(n, ci, ci, s, s)
-                f += 18.0 * ci * co * 4 * s * s * n * (W if ops.upconv3x3_dgrad_supported(s, s, n * co * 4 * s * s, n) else 1.0)
+                f += 18.0 * ci * co * 4 * s * s * n * (0.25 if ops.winoups3x3_supported(n, ci, co, s, s, dgrad=True) else
+                                                       (W if ops.upconv3x3_dgrad_supported(s, s, n * co * 4 * s * s, n) else 1.0))
                 if i > 0:
                     f += conv(n, ci, ci, s, s)
             s *= 2

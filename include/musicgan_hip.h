@@ -67,6 +67,19 @@ int mg_conv3x3(const float* x, const float* wp, const float* bias, const float* 
  * input (16 instead of 36 multiply-adds per low-res pixel and channel pair; same result up to fp32 summation order).
  * x: (N,Cin,Hin,Win); y/p: (N,Cout,2Hin,2Win); rn: (N,1,2Hin,2Win).  flags: MG_CONV_LRELU, MG_CONV_PIXNORM.  wp from
  * mg_upconv3x3_pack (effective weights, mg_upconv3x3_packed_floats floats).  Cout <= 96 recommended (register budget). */
+/* The same layer -- Upsample(x2 nearest) -> Conv2d(3x3) [generator.py:24-39] (+ LeakyReLU + PixelNorm, layers.py:11-17) -- and its
+ * data gradient (aten::convolution_backward input + upsample_nearest2d_backward) in Winograd F(2x2,3x3) form on the up-sampled grid
+ * without the 7 of 16 components that vanish there: 9 multiply-adds per output tile and channel pair (sub-pixel form: 16, direct on
+ * the up-sampled tensor: 36).  up: MG_PACK_WINOUPS filters of the module weight [Cout][Cin][3][3] (mg_pack_multi, dgrad = 0 / 1;
+ * mg_winoups3x3_packed_floats floats).  Forward: x (N,Cin,Hin,Win) -> y / p (N,Cout,2Hin,2Win), rn (N,1,2Hin,2Win); flags
+ * MG_CONV_LRELU, MG_CONV_PIXNORM (then p is written, y optional).  Data gradient: gy (N,Cout,2Hin,2Win) -> gx (N,Cin,Hin,Win).
+ * mg_winoups3x3_supported: Win a multiple of 16, Hin of 8, 16..64 out-channels of the call in whole tiles, the 9-component filter
+ * bank within the LDS. */
+int mg_winoups3x3_supported(int N, int Cin, int Cout, int Hin, int Win, int dgrad);
+size_t mg_winoups3x3_packed_floats(int Cin, int Cout, int dgrad);
+int mg_winoups3x3(const float* x, const float* up, const float* bias, float* y, float* p, float* rn, int N, int Cin, int Cout,
+                  int Hin, int Win, int flags, float slope, mg_stream_t stream);
+int mg_winoups3x3_dgrad(const float* gy, const float* up, float* gx, int N, int Cin, int Cout, int Hin, int Win, mg_stream_t stream);
 size_t mg_upconv3x3_packed_floats(int Cin, int Cout);
 int mg_upconv3x3_pack(const float* w, float* wp, int Co, int Ci, mg_stream_t stream);
 int mg_upconv3x3(const float* x, const float* wp, const float* bias, float* y, float* p, float* rn, int N, int Cin, int Cout,
@@ -102,6 +115,10 @@ int mg_wino3x3_fade(const float* x, const float* up, const float* bias, const un
 /* Weight (+ bias) gradient of the same convolution in Winograd F(3x3,2x2) form (even H, W; flags: MG_CONV_UPS_IN): same result as
  * mg_conv3x3_wgrad within fp32 rounding, 2.25x fewer multiplies, split-K slabs reduced in a fixed order (deterministic).
  * gw[Cout][Cin][3][3] (+)= ..., gb[Cout] (+)= sum of gy over samples n < bias_n (0: all; gb may be NULL). */
+/* Which kernel mg_wino3x3_wgrad_partial(_multi) runs for a layer (accounting of executed FLOPs, tests): 0 = chunk-staged forms
+ * (16 Winograd products per tile), 1 = row-staged form, 2 = row-staged form for an up-sampled input (MG_CONV_UPS_IN: 9 of the 16
+ * products), -1 = shape not supported.  group_max_chunks as passed to mg_wino3x3_wgrad_partial_multi (0: single launches). */
+int mg_wino3x3_wgrad_form(int N, int Cin, int Cout, int H, int W, int flags, int group_max_chunks);
 size_t mg_wino3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W);
 int mg_wino3x3_wgrad(const float* x, const float* gy, float* gw, float* gb, void* ws, size_t ws_bytes, int N, int Cin, int Cout,
                      int H, int W, int flags, int accumulate, int bias_n, mg_stream_t stream);
@@ -267,11 +284,11 @@ int mg_group_means(const float* x, int groups, int n, float* out, mg_stream_t st
  * All of mg_conv3x3_pack / mg_wino3x3_pack / mg_upconv3x3_pack / mg_upconv3x3_dgrad_pack for a list of weights in ONE launch (the
  * reference has no counterpart: these layouts replace what MIOpen / oneDNN re-derive from nn.Conv2d.weight inside every call).
  * descs is a HOST array; `out` buffers are sized by the matching *_packed_floats(). */
-enum { MG_PACK_CONV3X3 = 0, MG_PACK_WINO3X3 = 1, MG_PACK_UPCONV3X3 = 2, MG_PACK_UPCONV3X3_DGRAD = 3, MG_PACK_SMALLNET = 4 };
+enum { MG_PACK_CONV3X3 = 0, MG_PACK_WINO3X3 = 1, MG_PACK_UPCONV3X3 = 2, MG_PACK_UPCONV3X3_DGRAD = 3, MG_PACK_SMALLNET = 4, MG_PACK_WINOUPS = 5 };
 typedef struct {
   const float* w; /* module weight [Co][Ci][3][3] */
   float* out;
-  int32_t kind, Co, Ci, dgrad; /* dgrad: data-gradient variant (kinds 0, 1 and 4 only) */
+  int32_t kind, Co, Ci, dgrad; /* dgrad: data-gradient variant (kinds 0, 1, 4 and 5 only) */
 } mg_pack_desc_t;
 int mg_pack_multi(const mg_pack_desc_t* descs, int n, mg_stream_t stream);
 

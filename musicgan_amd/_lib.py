@@ -49,7 +49,7 @@ class PackDesc(Structure):
     _fields_ = [("w", c_void_p), ("out", c_void_p), ("kind", c_int), ("Co", c_int), ("Ci", c_int), ("dgrad", c_int)]
 
 
-MG_PACK_CONV3X3, MG_PACK_WINO3X3, MG_PACK_UPCONV3X3, MG_PACK_UPCONV3X3_DGRAD, MG_PACK_SMALLNET = 0, 1, 2, 3, 4
+MG_PACK_CONV3X3, MG_PACK_WINO3X3, MG_PACK_UPCONV3X3, MG_PACK_UPCONV3X3_DGRAD, MG_PACK_SMALLNET, MG_PACK_WINOUPS = 0, 1, 2, 3, 4, 5
 
 (MG_SN_LOAD, MG_SN_STORE, MG_SN_CONV, MG_SN_MASK, MG_SN_PIXNORM, MG_SN_PNBWD, MG_SN_POOL, MG_SN_POOLBWD, MG_SN_UP, MG_SN_UPBWD,
  MG_SN_LINEAR, MG_SN_LINBWD) = range(12)
@@ -71,6 +71,11 @@ SIGNATURES = {
     "mg_conv3x3_packed_floats": (c_size_t, [c_int, c_int]),
     "mg_conv3x3_pack": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "mg_conv3x3": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
+    "mg_wino3x3_wgrad_form": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "mg_winoups3x3_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "mg_winoups3x3_packed_floats": (c_size_t, [c_int, c_int, c_int]),
+    "mg_winoups3x3": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
+    "mg_winoups3x3_dgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "mg_upconv3x3_packed_floats": (c_size_t, [c_int, c_int]),
     "mg_upconv3x3_pack": (c_int, [_P, _P, c_int, c_int, _P]),
     "mg_upconv3x3": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P]),

@@ -18,6 +18,7 @@ __global__ void __launch_bounds__(256) pack_multi_k(const PackChunk c) {
     case MG_PACK_WINO3X3: total = pack_wino3x3_threads(d.Co, d.Ci, d.dgrad); break;
     case MG_PACK_UPCONV3X3: total = pack_upconv3x3_total(d.Co, d.Ci); break;
     case MG_PACK_SMALLNET: total = pack_smallnet_total(d.Co, d.Ci, d.dgrad); break;
+    case MG_PACK_WINOUPS: total = pack_winoups_threads(d.Co, d.Ci, d.dgrad); break;
     default: total = pack_downconv_total(d.Co, d.Ci); break;
   }
   const int NT = pack_wino_nt_padded(d.dgrad ? d.Ci : d.Co);
@@ -27,6 +28,7 @@ __global__ void __launch_bounds__(256) pack_multi_k(const PackChunk c) {
       case MG_PACK_WINO3X3: pack_wino3x3_elem(e, d.w, d.out, d.Co, d.Ci, d.dgrad, NT); break;
       case MG_PACK_UPCONV3X3: pack_upconv3x3_elem(e, d.w, d.out, d.Co, d.Ci); break;
       case MG_PACK_SMALLNET: pack_smallnet_elem(e, d.w, d.out, d.Co, d.Ci, d.dgrad); break;
+      case MG_PACK_WINOUPS: pack_winoups_elem(e, d.w, d.out, d.Co, d.Ci, d.dgrad); break;
       default: pack_downconv_elem(e, d.w, d.out, d.Co, d.Ci); break;
     }
   }
@@ -42,7 +44,7 @@ extern "C" int mg_pack_multi(const mg_pack_desc_t* descs, int n, mg_stream_t str
     size_t most = 0;
     for (int i = 0; i < m; ++i) {
       const mg_pack_desc_t& d = descs[first + i];
-      MG_CHECK_ARG(d.w && d.out && d.Co > 0 && d.Ci > 0 && d.kind >= MG_PACK_CONV3X3 && d.kind <= MG_PACK_SMALLNET,
+      MG_CHECK_ARG(d.w && d.out && d.Co > 0 && d.Ci > 0 && d.kind >= MG_PACK_CONV3X3 && d.kind <= MG_PACK_WINOUPS,
                    "mg_pack_multi: bad record %d", first + i);
       c.d[i] = d;
       size_t total;
@@ -51,6 +53,7 @@ extern "C" int mg_pack_multi(const mg_pack_desc_t* descs, int n, mg_stream_t str
         case MG_PACK_WINO3X3: total = pack_wino3x3_threads(d.Co, d.Ci, d.dgrad); break;
         case MG_PACK_UPCONV3X3: total = pack_upconv3x3_total(d.Co, d.Ci); break;
         case MG_PACK_SMALLNET: total = pack_smallnet_total(d.Co, d.Ci, d.dgrad); break;
+        case MG_PACK_WINOUPS: total = pack_winoups_threads(d.Co, d.Ci, d.dgrad); break;
         default: total = pack_downconv_total(d.Co, d.Ci); break;
       }
       if (total > most) most = total;

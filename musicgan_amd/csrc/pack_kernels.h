@@ -73,6 +73,56 @@ __host__ __device__ static inline size_t pack_wino3x3_threads(int Co, int Ci, in
   return (size_t)mg_cdiv(cin_call, MG_PACK_CC) * pack_wino_nt_padded(cout_call) * 128;
 }
 
+// Winograd filters for an up-sampled input (wino_ups.hip): the 9 components (xi, nu), xi, nu in {0, 1, 3}, of U = G g G^T -- rows and
+// columns 2 of the INPUT transform vanish on an up-sampled grid (forward), and drop out of the block-summed output transform (data
+// gradient, dgrad = 1: flipped taps, channels transposed).  Factors folded in: forward 2 per index 1 (B^T d doubles the centre row /
+// column); data gradient s = A 1 = (1, 2, ., -1).  Layout [chunk][out tile][component 3 i + j][64 lanes][2 k-steps]; one thread per
+// (chunk, out tile, lane, k-step) = one (channel, out-channel) filter.
+__device__ __forceinline__ void pack_winoups_elem(size_t e, const float* __restrict__ w, float* __restrict__ up, int Co, int Ci, int dgrad) {
+  const int cin_call = dgrad ? Co : Ci, cout_call = dgrad ? Ci : Co;
+  const int NT = mg_cdiv(cout_call, 16);
+  const int ks = (int)(e & 1);
+  const int lane = (int)((e >> 1) & 63);
+  const size_t r = e >> 7;
+  const int ct = (int)(r % NT);
+  const int ch = (int)(r / NT);
+  const int c = ch * MG_PACK_CC + 2 * (lane >> 4) + ks;
+  const int o = ct * 16 + (lane & 15);
+  float g[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) g[t] = 0.f;
+  if (c < cin_call && o < cout_call) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) g[t] = dgrad ? w[((size_t)c * Ci + o) * 9 + (8 - t)] : w[((size_t)o * Ci + c) * 9 + t];
+  }
+  float h[12];  // G g : 4x3
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const float g0 = g[j], g1 = g[3 + j], g2 = g[6 + j];
+    h[j] = g0;
+    h[3 + j] = 0.5f * ((g0 + g1) + g2);
+    h[6 + j] = 0.5f * ((g0 - g1) + g2);
+    h[9 + j] = g2;
+  }
+  const float f1 = 2.0f, f3 = dgrad ? -1.0f : 1.0f;  // factor of index 1 / index 3 (index 0: 1)
+  float* dst = up + (((size_t)ch * NT + ct) * 9) * 128 + lane * 2 + ks;
+  constexpr int XI[3] = {0, 1, 3};
+#pragma unroll
+  for (int ii = 0; ii < 3; ++ii) {
+    const int i = XI[ii];
+    const float fi = ii == 1 ? f1 : (ii == 2 ? f3 : 1.0f);
+    const float h0 = h[3 * i], h1 = h[3 * i + 1], h2 = h[3 * i + 2];
+    dst[(size_t)(3 * ii + 0) * 128] = fi * h0;
+    dst[(size_t)(3 * ii + 1) * 128] = fi * f1 * (0.5f * ((h0 + h1) + h2));
+    dst[(size_t)(3 * ii + 2) * 128] = fi * f3 * h2;
+  }
+}
+__host__ __device__ static inline size_t pack_winoups_threads(int Co, int Ci, int dgrad) {
+  const int cin_call = dgrad ? Co : Ci, cout_call = dgrad ? Ci : Co;
+  return (size_t)mg_cdiv(cin_call, MG_PACK_CC) * mg_cdiv(cout_call, 16) * 128;
+}
+__host__ __device__ static inline size_t pack_winoups_total(int Co, int Ci, int dgrad) { return pack_winoups_threads(Co, Ci, dgrad) * 9; }
+
 // taps k in {0,1,2} of the original filter landing on low-res offset t for sub-pixel phase p:  p=0: t=0 <- {0}, t=1 <- {1,2};  p=1: t=0 <- {0,1}, t=1 <- {2}
 __device__ __forceinline__ float pack_subpixel_sum(const float* __restrict__ wk, int py, int ta, int px, int tb) {
   const int ky0 = py == 0 ? (ta == 0 ? 0 : 1) : (ta == 0 ? 0 : 2);

@@ -1610,6 +1610,17 @@ int launch_single_ww(const WwPlan& pl, bool ups, hipStream_t s) {
 
 }  // namespace
 
+extern "C" int mg_wino3x3_wgrad_form(int N, int Cin, int Cout, int H, int W, int flags, int group_max_chunks) {
+  if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (H % 2) || (W % 2)) return -1;
+  WwPlan pl;
+  plan_ww(N, Cin, Cout, H, W, pl);
+  const bool ups = (flags & MG_CONV_UPS_IN) != 0;
+  const long long work = (long long)pl.a.nblk * pl.ncb * pl.a.nob;
+  const bool small = group_max_chunks > 0 && ww_groupable(pl.CT, pl.OT) && work <= (long long)group_max_chunks * mg_cu_count();
+  if (small || !ww_rows_takes(pl, ups)) return 0;
+  return ups ? 2 : 1;
+}
+
 extern "C" size_t mg_wino3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W) {
   WwPlan pl;
   plan_ww(N, Cin, Cout, H, W, pl);

@@ -45,6 +45,14 @@ def gen_conv_form(n: int, cin: int, cout: int, h: int, wd: int, ups: bool) -> st
     return "fused"
 
 
+def gen_conv_exec_factor(n: int, cin: int, cout: int, h: int, wd: int, ups: bool) -> float:
+    """Executed / direct multiplies of that convolution's forward pass: 1, 1 / 2.25 (Winograd, sub-pixel) or 0.25 (9-component
+    Winograd on the up-sampled grid)."""
+    if ups and gen_conv_form(n, cin, cout, h, wd, ups) == "subpixel-fused" and ops.winoups3x3_supported(n, cin, cout, h, wd):
+        return 0.25
+    return 1.0 / 2.25 if gen_conv_executes_reduced(n, cin, cout, h, wd, ups) else 1.0
+
+
 def gen_conv_executes_reduced(n: int, cin: int, cout: int, h: int, wd: int, ups: bool) -> bool:
     """True when that convolution's forward issues 1/2.25 of the direct-convolution multiplies (Winograd or sub-pixel form)."""
     form = gen_conv_form(n, cin, cout, h, wd, ups)
@@ -161,8 +169,11 @@ class PackCache:
             # more than 64 channels cannot take the Winograd kernel's fused PixelNorm (all channels of a pixel in one workgroup)
             # and the direct kernel's fused form puts 5-8 channel tiles on one wave: the Winograd conv + a PixelNorm pass is faster
             return ops.pixelnorm_fwd(self.conv(x, w, False, bias, cout, lrelu=True))
-        if form == "subpixel-fused":  # sub-pixel form: 2.25x fewer MFMAs
-            _, p, rn = ops.upconv3x3(x, self.get_up(w), bias, cout, lrelu=True, pixnorm=True, want_y=False)
+        if form == "subpixel-fused":
+            if ops.winoups3x3_supported(n, cin, cout, h, wd):  # Winograd on the up-sampled grid, 9 of 16 components: 4x fewer MFMAs
+                _, p, rn = ops.winoups3x3(x, self.get_wu(w, False), bias, cout, lrelu=True, pixnorm=True, want_y=False)
+                return p, rn
+            _, p, rn = ops.upconv3x3(x, self.get_up(w), bias, cout, lrelu=True, pixnorm=True, want_y=False)  # sub-pixel form: 2.25x fewer
             return p, rn
         if form == "fused":
             _, p, rn = self.conv(x, w, False, bias, cout, ups=ups, lrelu=True, pixnorm=True, want_y=False)
@@ -176,6 +187,10 @@ class PackCache:
     def get_up(self, w: torch.Tensor) -> torch.Tensor:
         """Effective sub-pixel weights of Upsample(x2) -> Conv3x3 (ops.upconv3x3)."""
         return self._get(w, _lib.MG_PACK_UPCONV3X3, False)
+
+    def get_wu(self, w: torch.Tensor, dgrad: bool) -> torch.Tensor:
+        """9-component Winograd filters of Upsample(x2) -> Conv3x3 / its data gradient (ops.winoups3x3, ops.winoups3x3_dgrad)."""
+        return self._get(w, _lib.MG_PACK_WINOUPS, dgrad)
 
     def get_up_dgrad(self, w: torch.Tensor) -> torch.Tensor:
         """4x4 stride-2 effective kernel of the upsample-conv data gradient (ops.upconv3x3_dgrad)."""
@@ -443,7 +458,9 @@ def gen_backward(W: GenWeights, ctx, g_out: torch.Tensor, cache: PackCache, sink
         gw2, acc = sink.slot(w2)
         gb2, _ = sink.slot(b2)
         ops.conv3x3_wgrad(p1, gpre2, gw2, gb2, ups=True, accumulate=acc, defer=defer)
-        if ops.upconv3x3_dgrad_supported(p1.shape[2], p1.shape[3], gpre2.numel(), p1.shape[0]):
+        if ops.winoups3x3_supported(p1.shape[0], ci, w2.shape[0], p1.shape[2], p1.shape[3], dgrad=True):
+            gp1 = ops.winoups3x3_dgrad(gpre2, cache.get_wu(w2, True), ci)  # 9-component Winograd form, block sums in the epilogue
+        elif ops.upconv3x3_dgrad_supported(p1.shape[2], p1.shape[3], gpre2.numel(), p1.shape[0]):
             gp1 = ops.upconv3x3_dgrad(gpre2, cache.get_up_dgrad(w2), ci)  # stride-2 4x4 form: no high-res intermediate
         else:
             gp1 = cache.conv_upsum(gpre2, w2, ci)

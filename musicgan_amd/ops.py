@@ -80,6 +80,8 @@ def packed_floats(kind: int, co: int, ci: int, dgrad: bool) -> int:
         return lib.mg_upconv3x3_packed_floats(ci, co)
     if kind == _lib.MG_PACK_SMALLNET:
         return lib.mg_smallnet_packed_floats(cin_call, cout_call)
+    if kind == _lib.MG_PACK_WINOUPS:
+        return lib.mg_winoups3x3_packed_floats(ci, co, int(dgrad))
     return lib.mg_upconv3x3_dgrad_packed_floats(ci, co)
 
 
@@ -261,6 +263,45 @@ def upconv3x3(x, wp, bias, cout: int, *, lrelu=False, pixnorm=False, want_y=True
     return (y, p, rn) if pixnorm else y
 
 
+def winoups3x3_supported(n: int, cin: int, cout: int, hin: int, win: int, *, dgrad: bool = False) -> bool:
+    """Whether Upsample(x2) -> Conv3x3 (cin -> cout, input hin x win) / its data gradient takes the 9-component Winograd kernels of
+    csrc/wino_ups.hip (MG_WINOUPS=0: never -- the sub-pixel kernels then)."""
+    if os.environ.get("MG_WINOUPS", "1") == "0":
+        return False
+    return bool(_lib.load().mg_winoups3x3_supported(n, cin, cout, hin, win, int(dgrad)))
+
+
+def pack_winoups3x3(w: torch.Tensor, dgrad: bool) -> torch.Tensor:
+    _chk(w)
+    out = torch.empty(packed_floats(_lib.MG_PACK_WINOUPS, w.shape[0], w.shape[1], dgrad), dtype=torch.float32, device=w.device)
+    pack_multi([(_lib.MG_PACK_WINOUPS, w, dgrad, out)])
+    return out
+
+
+def winoups3x3(x, up, bias, cout: int, *, lrelu=False, pixnorm=False, want_y=True):
+    """Upsample(x2 nearest) -> Conv3x3 (+ LeakyReLU + PixelNorm) in 9-component Winograd form.  Returns y or (y, p, rn)."""
+    _chk(x, up, bias)
+    n, cin, hin, win = x.shape
+    h, w = 2 * hin, 2 * win
+    flags = (MG_CONV_LRELU if lrelu else 0) | (MG_CONV_PIXNORM if pixnorm else 0)
+    y = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device) if (want_y or not pixnorm) else None
+    p = rn = None
+    if pixnorm:
+        p = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+        rn = torch.empty((n, 1, h, w), dtype=torch.float32, device=x.device)
+    check(_lib.load().mg_winoups3x3(_p(x), _p(up), _p(bias), _p(y), _p(p), _p(rn), n, cin, cout, hin, win, flags, SLOPE, _s()), "mg_winoups3x3")
+    return (y, p, rn) if pixnorm else y
+
+
+def winoups3x3_dgrad(gy, up, cin: int):
+    """Gradient of Upsample(x2) -> Conv3x3 w.r.t. its low-resolution input in 9-component Winograd form: (N,Cout,2H,2W) -> (N,Cin,H,W)."""
+    _chk(gy, up)
+    n, cout, h2, w2 = gy.shape
+    gx = torch.empty((n, cin, h2 // 2, w2 // 2), dtype=torch.float32, device=gy.device)
+    check(_lib.load().mg_winoups3x3_dgrad(_p(gy), _p(up), _p(gx), n, cin, cout, h2 // 2, w2 // 2, _s()), "mg_winoups3x3_dgrad")
+    return gx
+
+
 def pack_upconv3x3_dgrad(w: torch.Tensor) -> torch.Tensor:
     _chk(w)
     co, ci = w.shape[0], w.shape[1]
@@ -308,6 +349,11 @@ def wino_wgrad_supported(n: int, cin: int, cout: int, h: int, w: int, *, ups=Fal
     if n * max(cin, cout) * h * w >= (1 << 29):
         return False
     return n * h * w >= int(os.environ.get("MG_WINO_WGRAD_MIN_PIXELS", "64"))
+
+
+def wino_wgrad_form(n: int, cin: int, cout: int, h: int, w: int, *, ups=False) -> int:
+    """0 / 1 / 2: chunk-staged, row-staged, row-staged 9-component (up-sampled input) Winograd weight gradient (mg_wino3x3_wgrad_form)."""
+    return int(_lib.load().mg_wino3x3_wgrad_form(n, cin, cout, h, w, MG_CONV_UPS_IN if ups else 0, wgrad_group_chunks()))
 
 
 def wgrad_group_chunks() -> int:
