@@ -77,6 +77,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "small":  # the 32x32 layers of level 5 
              (64, 80, 80, 32, "unpool"), (64, 96, 80, 32, "dgrad_mask"), (64, 80, 80, 32, "dgrad_mask"), (64, 80, 96, 32, "tangent"),
              (64, 80, 96, 32, "fwd_pool_mask"), (64, 80, 80, 32, "plain"), (18, 64, 80, 64, "fwd_pool_mask"), (18, 80, 64, 64, "dgrad_mask"),
              (18, 64, 64, 64, "plain"), (6, 64, 64, 64, "plain"), (6, 64, 80, 64, "tangent"), (96, 64, 80, 64, "fwd_pool_mask"), (32, 64, 64, 64, "plain")]
+if len(sys.argv) > 1 and sys.argv[1] == "l4":  # level 4 at batch 32 (96 / 32 images): the 32x32 layers have 1 536 / 512 tile blocks
+    cases = [(96, 80, 96, 32, "fwd_pool_mask"), (96, 96, 80, 32, "dgrad_mask"), (96, 80, 80, 32, "unpool"), (96, 80, 80, 32, "plain"),
+             (32, 80, 96, 32, "tangent"), (32, 80, 80, 32, "plain"), (32, 96, 80, 32, "dgrad_mask"), (32, 80, 80, 32, "unpool"),
+             (96, 96, 96, 16, "plain"), (96, 96, 112, 16, "fwd_pool_mask")]
 # variants: "0" the staged kernel; "2" strip, all out-channel tiles in a wave; "2n1" strip, one tile per wave (tiles on grid.y)
 VARIANTS = ["0", "2"] + [v for v in sys.argv[1:] if v.startswith("2")]
 
