@@ -440,43 +440,30 @@ def host_io_probe(device, scratch_dir: str, threads: int, samples_per_thread: in
             os.remove(os.path.join(scratch_dir, f"probe_side_{t}.bin"))
     # The bound itself must not be the product's own call: the two things a sample costs the host whatever the code around them --
     # (i) plain `write` of 8 MiB into a new file + `pwrite` of 4 MiB into a per-thread file, from a zero buffer (page cache, inode
-    # and directory work of this file system), (ii) a float32 -> float64 widening of 2 x 512 x 512 values (numpy, one pass) -- each
-    # on `threads` threads at once.
+    # and directory work of this file system), (ii) a float32 -> float64 widening of 2 x 512 x 512 values -- each on `threads`
+    # threads at once, as native loops (mg_host_io_probe: through ctypes without the interpreter lock; the same calls made from
+    # Python threads measured the lock hand-over, 2x slower than the product's writer path).
     import numpy as np
-    zeros8, zeros4 = bytes(8 << 20), bytes(4 << 20)
     src32 = [np.random.default_rng(t).random(row_floats, dtype=np.float32) for t in range(threads)]
     n_ind = max(8, samples_per_thread // 2)
+    wsec, dsec = [0.0] * threads, [0.0] * threads
 
-    def raw_writer(tid, busy):
-        side = os.open(os.path.join(scratch_dir, f"probe_rawside_{tid}.bin"), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
-        t0 = time.perf_counter()
-        for i in range(n_ind):
-            fd = os.open(os.path.join(scratch_dir, f"probe_raw_{tid}_{i}.bin"), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
-            os.write(fd, zeros8)
-            os.close(fd)
-            os.pwrite(side, zeros4, i * len(zeros4))
-        busy[tid] = time.perf_counter() - t0
-        os.close(side)
+    def prober(tid):
+        ws, ds = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        rc = lib.mg_host_io_probe(os.fsencode(scratch_dir), tid, n_ind, 8 << 20, 4 << 20, ctypes.c_void_p(src32[tid].ctypes.data), row_floats,
+                                  ctypes.byref(ws), ctypes.byref(ds))
+        assert rc == 0, lib.mg_last_error()
+        wsec[tid], dsec[tid] = ws.value, ds.value
 
-    def widener(tid, busy):
-        dst = np.empty(row_floats, dtype=np.float64)
-        t0 = time.perf_counter()
-        for i in range(n_ind):
-            np.copyto(dst, src32[tid], casting="safe")
-        busy[tid] = time.perf_counter() - t0
-
-    indep = {}
-    for what, fn in (("raw_write", raw_writer), ("widen", widener)):
-        busy = [0.0] * threads
-        ths = [threading.Thread(target=fn, args=(t, busy)) for t in range(threads)]
-        t0 = time.perf_counter()
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
-        wall = time.perf_counter() - t0
-        indep[what] = wall / n_ind  # seconds per sample and thread, all threads busy
-        out[f"{what}_ms_per_sample_{threads}_threads"] = 1e3 * wall / n_ind
+    ths = [threading.Thread(target=prober, args=(t,)) for t in range(threads)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    # (every thread runs its n_ind writes, then its n_ind widenings; seconds per sample and thread with all threads busy)
+    indep = {"raw_write": max(wsec) / n_ind, "widen": max(dsec) / n_ind}
+    out[f"raw_write_ms_per_sample_{threads}_threads"] = 1e3 * indep["raw_write"]
+    out[f"widen_ms_per_sample_{threads}_threads"] = 1e3 * indep["widen"]
     for t in range(threads):
         for i in range(n_ind):
             os.remove(os.path.join(scratch_dir, f"probe_raw_{t}_{i}.bin"))
@@ -489,9 +476,10 @@ def host_io_probe(device, scratch_dir: str, threads: int, samples_per_thread: in
                 "product_writer_path_s_per_file": per_file_write,
                 "bound_files_per_s": 1.0 / max(per_file_d2h, per_file_indep),
                 "basis": "per 10-minute file: 421 MB over the measured pinned D2H rate; 201 samples x (plain write of 8 MiB to a new file + "
-                         "pwrite of 4 MiB + one numpy float32 -> float64 pass), zero / random buffers, on the writer threads' count of "
-                         "threads at once, in the record's scratch directory; the larger one.  `product_writer_path_*`: the loop's own "
-                         "native call (mg_pt_write_samples) on the same threads, for comparison -- not part of the bound"})
+                         "pwrite of 4 MiB + one float32 -> float64 pass; native loops, mg_host_io_probe), zero / random buffers, on the "
+                         "writer threads' count of threads at once, in the record's scratch directory; the larger one.  "
+                         "`product_writer_path_*`: the loop's own native call (mg_pt_write_samples) on the same threads, for comparison "
+                         "-- not part of the bound"})
     return out
 
 

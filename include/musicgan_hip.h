@@ -440,6 +440,11 @@ int mg_crc32_f64(const float* x, uint32_t* crc_out, void* ws, size_t ws_bytes, i
  * interpreter lock. */
 int mg_pt_write_samples(const float* rows, int n, int64_t row_floats, const char* paths, const unsigned char* prefix, int64_t prefix_len,
                         const unsigned char* suffixes, int64_t suffix_len, int side_fd, int64_t side_off);
+/* Measurement helper (bench.py `host_io_probe`, no GPU work): what one writer thread's sample costs the host as plain system calls
+ * -- n x { new file of file_bytes from a zero buffer; pwrite of side_bytes } and n x { row_floats float32 -> float64 } -- timed
+ * separately; called from several threads at once.  The files <dir>/probe_raw_<tid>_<i>.bin, probe_rawside_<tid>.bin are left. */
+int mg_host_io_probe(const char* dir, int tid, int n, int64_t file_bytes, int64_t side_bytes, const float* src, int64_t row_floats,
+                     double* write_seconds, double* widen_seconds);
 
 /* Per-batch input transform of the training loop, fused: ChannelMinMaxNorm -> ChangeRange(-1,1) -> Resize(S) (bilinear with
  * anti-aliasing, align_corners = False: torchvision's tensor path) [audio/transforms.py:4-40, utils.py:70-86, train.py:138-140].

@@ -148,6 +148,7 @@ SIGNATURES = {
     "mg_crc32_f64_ws_bytes": (c_size_t, [c_int, c_int64]),
     "mg_crc32_f64": (c_int, [_P, _P, _P, c_size_t, c_int, c_int64, _P]),
     "mg_pt_write_samples": (c_int, [_P, c_int, c_int64, ctypes.c_char_p, ctypes.c_char_p, c_int64, ctypes.c_char_p, c_int64, c_int, c_int64]),
+    "mg_host_io_probe": (c_int, [ctypes.c_char_p, c_int, c_int, ctypes.c_int64, ctypes.c_int64, _P, ctypes.c_int64, _P, _P]),
     "mg_codec_fwd_ws_bytes": (c_size_t, [c_int]),
     "mg_codec_fwd": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, _P]),
     "mg_codec_fwd_strided": (c_int, [_P, _P, _P, _P, c_size_t, _P, c_size_t, c_int, c_int, _P]),

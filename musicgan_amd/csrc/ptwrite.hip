@@ -10,6 +10,9 @@
 #include <sys/uio.h>
 #include <unistd.h>
 
+#include <chrono>
+#include <string>
+
 #include "mg_common.h"
 
 namespace {
@@ -95,6 +98,52 @@ extern "C" int mg_pt_write_samples(const float* rows, int n, int64_t row_floats,
     if (rc != MG_OK) unlink(path);  // never leave a truncated magn_phase_*.pt behind for AudioDataset to load
     path += strlen(path) + 1;
   }
+  free(wide);
+  return rc;
+}
+
+// Measurement helper of bench.py's host-io bound (create_dataset end to end): what ONE writer thread's sample costs the host whatever
+// the product code around it -- n times { a new file <dir>/probe_raw_<tid>_<i>.bin: open, write(file_bytes from a zero buffer), close;
+// pwrite(side_bytes) into <dir>/probe_rawside_<tid>.bin } and n times { row_floats float32 -> float64 into a scratch row } -- as plain
+// system calls / one loop, timed separately.  Called from several Python threads at once through ctypes (no interpreter lock): a
+// Python-level probe of the same calls measured the lock hand-over between threads, not the file system (2x slower than the product).
+// The files are left for the caller to remove.
+extern "C" int mg_host_io_probe(const char* dir, int tid, int n, int64_t file_bytes, int64_t side_bytes, const float* src,
+                                int64_t row_floats, double* write_seconds, double* widen_seconds) {
+  MG_CHECK_ARG(dir && n > 0 && file_bytes > 0 && side_bytes >= 0 && src && row_floats > 0 && write_seconds && widen_seconds,
+               "mg_host_io_probe: bad arguments");
+  const size_t zb = (size_t)(file_bytes > side_bytes ? file_bytes : side_bytes);
+  char* zeros = static_cast<char*>(calloc(zb, 1));
+  double* wide = static_cast<double*>(malloc((size_t)row_floats * sizeof(double)));
+  MG_CHECK_ARG(zeros && wide, "mg_host_io_probe: out of memory");
+  int rc = MG_OK;
+  const std::string base(dir);
+  const std::string side_path = base + "/probe_rawside_" + std::to_string(tid) + ".bin";
+  const int side = open(side_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  if (side < 0) {
+    mg_set_error("mg_host_io_probe: cannot open %s: %s", side_path.c_str(), strerror(errno));
+    rc = MG_EIO;
+  }
+  auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < n && rc == MG_OK; ++i) {
+    const std::string path = base + "/probe_raw_" + std::to_string(tid) + "_" + std::to_string(i) + ".bin";
+    const int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0 || !pwrite_all(fd, zeros, (size_t)file_bytes, 0) || close(fd) != 0 ||
+        !pwrite_all(side, zeros, (size_t)side_bytes, (off_t)((int64_t)i * side_bytes))) {
+      mg_set_error("mg_host_io_probe: write to %s failed: %s", path.c_str(), strerror(errno));
+      rc = MG_EIO;
+    }
+  }
+  *write_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (side >= 0) close(side);
+  t0 = std::chrono::steady_clock::now();
+  double sink = 0.0;
+  for (int i = 0; i < n; ++i) {
+    for (int64_t k = 0; k < row_floats; ++k) wide[k] = (double)src[k];
+    sink += wide[(size_t)i % (size_t)row_floats];
+  }
+  *widen_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() + (sink == 12345.678 ? 1e-12 : 0.0);
+  free(zeros);
   free(wide);
   return rc;
 }

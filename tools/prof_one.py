@@ -17,6 +17,12 @@ elif case == "up54":   # the generator's last up-sampling conv in sub-pixel form
 elif case == "updg54":  # its data gradient: (N, 48, 128, 128) -> (N, 64, 64, 64)
     gy = R(N, 48, 128, 128); wp = ops.pack_upconv3x3_dgrad(R(48, 64, 3, 3) * 0.05)
     fn = lambda: ops.upconv3x3_dgrad(gy, wp, 64)
+elif case == "wu54":   # the same layer in 9-component Winograd form (wino_ups.hip)
+    x = R(N, 64, 64, 64); up = ops.pack_winoups3x3(R(48, 64, 3, 3) * 0.05, False); b = R(48)
+    fn = lambda: ops.winoups3x3(x, up, b, 48, lrelu=True, pixnorm=True, want_y=False)
+elif case == "wudg54":  # and its data gradient
+    gy = R(N, 48, 128, 128); up = ops.pack_winoups3x3(R(48, 64, 3, 3) * 0.05, True)
+    fn = lambda: ops.winoups3x3_dgrad(gy, up, 64)
 elif case == "d20":    # conv 48->64 @128 + lrelu
     x = R(N, 48, 128, 128); wp = ops.pack_conv3x3(R(64, 48, 3, 3) * 0.05, False); b = R(64)
     fn = lambda: ops.conv3x3(x, wp, b, 64, lrelu=True)
