@@ -920,6 +920,7 @@ __global__ void __launch_bounds__(512) wino_wgrad_rows_mfma(const WwArgs a) {
       if (k < NI) {  // (wave-uniform)
         float* dst = smem + st_so + 256 * k;
         if (k < XI) {
+          if ((a.TBN & 64) && (k & 1)) continue;  // (measurement: every second x copy instruction dropped)
           unsigned v = voff[m];
           if (st_top || st_bot || st_patch) {  // (wave-uniform; the common stage takes the offsets as they are)
             const bool kill = (st_top && ((cls >> (4 * m)) & 1u)) || (st_bot && ((cls >> (4 * m + 1)) & 1u)) || (st_patch && m == 0 && lane == st_lowlane);
@@ -1471,8 +1472,8 @@ void plan_rows(WwPlan& pl) {
   WwArgs& a = pl.a;
   a.TBW = 16; a.TBH = 1; a.TBN = 1; a.lgTBW = 4; a.lgTBH = 0;
   {
-    const char* e = getenv("MG_WGRAD_ROWS_ABLATE");  // measurement switch (wrong results): 2 = no staging, 4 = no barriers, 8 = staging never waited for, 16 = every stage re-reads the slab's first one
-    if (e != nullptr) a.TBN |= atoi(e) & 62;
+    const char* e = getenv("MG_WGRAD_ROWS_ABLATE");  // measurement switch (wrong results): 2 = no staging, 4 = no barriers, 8 = staging never waited for, 16 = every stage re-reads the slab's first one, 64 = every second x copy instruction dropped
+    if (e != nullptr) a.TBN |= atoi(e) & 126;
   }
   a.blocks_x = a.W / 32; a.blocks_y = a.H / 2; a.blocks_n = a.N;
   a.nblk = a.blocks_x * a.blocks_y * a.blocks_n;
