@@ -423,21 +423,8 @@ def host_io_probe(device, scratch_dir: str, threads: int, samples_per_thread: in
         busy[tid] = time.perf_counter() - t0
         os.close(side)
 
-    for nthr in (1, threads):
-        busy = [0.0] * nthr
-        ths = [threading.Thread(target=writer, args=(t, busy)) for t in range(nthr)]
-        t0 = time.perf_counter()
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
-        wall = time.perf_counter() - t0
-        out[f"writer_path_samples_per_s_{nthr}_thread{'s' if nthr > 1 else ''}"] = nthr * batches * 8 / wall
-        out[f"writer_path_ms_per_sample_{nthr}_thread{'s' if nthr > 1 else ''}"] = 1e3 * sum(busy) / (nthr * batches * 8)
-        for t in range(nthr):
-            for i in range(batches * 8):
-                os.remove(os.path.join(scratch_dir, f"probe_{t}_{i}.pt"))
-            os.remove(os.path.join(scratch_dir, f"probe_side_{t}.bin"))
+    # (the independent loops run BEFORE the product's own path: each leaves gigabytes of dirty pages behind, and whoever writes second
+    # is throttled by the page cache -- measured the other way round, the "bound" came out 1.4x slower than the product)
     # The bound itself must not be the product's own call: the two things a sample costs the host whatever the code around them --
     # (i) plain `write` of 8 MiB into a new file + `pwrite` of 4 MiB into a per-thread file, from a zero buffer (page cache, inode
     # and directory work of this file system), (ii) a float32 -> float64 widening of 2 x 512 x 512 values -- each on `threads`
@@ -445,7 +432,7 @@ def host_io_probe(device, scratch_dir: str, threads: int, samples_per_thread: in
     # Python threads measured the lock hand-over, 2x slower than the product's writer path).
     import numpy as np
     src32 = [np.random.default_rng(t).random(row_floats, dtype=np.float32) for t in range(threads)]
-    n_ind = max(8, samples_per_thread // 2)
+    n_ind = batches * 8  # (as many samples per thread as the product path below)
     wsec, dsec = [0.0] * threads, [0.0] * threads
 
     def prober(tid):
@@ -468,6 +455,21 @@ def host_io_probe(device, scratch_dir: str, threads: int, samples_per_thread: in
         for i in range(n_ind):
             os.remove(os.path.join(scratch_dir, f"probe_raw_{t}_{i}.bin"))
         os.remove(os.path.join(scratch_dir, f"probe_rawside_{t}.bin"))
+    for nthr in (1, threads):
+        busy = [0.0] * nthr
+        ths = [threading.Thread(target=writer, args=(t, busy)) for t in range(nthr)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        wall = time.perf_counter() - t0
+        out[f"writer_path_samples_per_s_{nthr}_thread{'s' if nthr > 1 else ''}"] = nthr * batches * 8 / wall
+        out[f"writer_path_ms_per_sample_{nthr}_thread{'s' if nthr > 1 else ''}"] = 1e3 * sum(busy) / (nthr * batches * 8)
+        for t in range(nthr):
+            for i in range(batches * 8):
+                os.remove(os.path.join(scratch_dir, f"probe_{t}_{i}.pt"))
+            os.remove(os.path.join(scratch_dir, f"probe_side_{t}.bin"))
     d2h = max(out["d2h_GB_per_s_1_stream"], out["d2h_GB_per_s_2_streams"])
     per_file_d2h = 201 * 2 * 512 * 512 * 4 / (d2h * 1e9)
     per_file_write = 201 / out[f"writer_path_samples_per_s_{threads}_thread{'s' if threads > 1 else ''}"]
