@@ -19,8 +19,9 @@
 //   all out-channels of a pixel sit in one wave: bias + LeakyReLU + PixelNorm in the epilogue.
 //   data gradient: the hi-res patch rows as in wino_strip.hip (8-byte own pair + 4-byte edge pixel), 9 of the 16 components of the
 //   input transform, 18 NT MFMAs per chunk, epilogue = sum of the nine accumulators (one low-res pixel per tile and channel).
-// Filter reads are volatile LDS-address-space loads: hipcc would merge neighbours into ds_read2st64_b64 (half rate on this LDS).
+// Filter reads are inline-assembly ds_read_b64, one component ahead of the MFMAs (wu_mma).
 #include <cstdlib>
+#include <utility>
 
 #include "mg_common.h"
 #include "pack_kernels.h"
@@ -50,8 +51,6 @@ __device__ __forceinline__ f32x2 wu_sub(f32x2 a, f32x2 b) {
   asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
-typedef const volatile __attribute__((address_space(3))) f32x2* wu_lds_ptr;
-__device__ __forceinline__ f32x2 wu_lds(const float* p) { return *(wu_lds_ptr)p; }
 __device__ __forceinline__ int wu_f2i(float v) { return __builtin_bit_cast(int, v); }
 __device__ __forceinline__ float wu_i2f(int v) { return __builtin_bit_cast(float, v); }
 // lane - 1's / lane + 1's value inside a row of 16 lanes; at the row's ends the destination keeps `old`
@@ -60,17 +59,56 @@ __device__ __forceinline__ float wu_from_right(float old, float v) { return wu_i
 
 // The nine products of one chunk: acc[c][t] += U[c](filters of tile t) x V[c], both k-steps (the lane's two channels)
 // (FIRST: a block's first chunk starts its sums from the zero constant -- no 36 NT register clears per block)
+template <class F, int... Is>
+__device__ __forceinline__ void wu_static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void wu_static_for(F&& f) {
+  wu_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+// 8 bytes of LDS at byte address addr + OFF as ONE ds_read_b64, outside hipcc's s_waitcnt bookkeeping (wu_wait before the first use):
+// left to the compiler, the filter reads either merge into half-rate ds_read2st64_b64 or -- as volatile loads -- sink back to their
+// uses, where every pair of MFMAs waits out an LDS round trip (first version: 165 us for 64 -> 48 @128x128 x 64)
+template <int OFF>
+__device__ __forceinline__ f32x2 wu_lds64(unsigned addr) {
+  f32x2 v;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+__device__ __forceinline__ void wu_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wu_tie(f32x2& v) { asm volatile("" : "+v"(v)); }
+
+// The nine products of one chunk: acc[c][t] += U[c](filters of tile t) x V[c], both k-steps (the lane's two channels).  The filters of
+// component c + 1 are requested before the MFMAs of component c are issued (two register sets).
 template <int NT, bool FIRST>
-__device__ __forceinline__ void wu_mma(const float* bank_chunk, int lane, const f32x2 (&V)[9], f32x4 (&acc)[9][NT]) {
+__device__ __forceinline__ void wu_mma(unsigned bank_addr, const f32x2 (&V)[9], f32x4 (&acc)[9][NT]) {
+  f32x2 fa[2][NT];
+  wu_static_for<NT>([&](auto tc) __attribute__((always_inline)) {
+    constexpr int t = decltype(tc)::value;
+    fa[0][t] = wu_lds64<(t * 9) * 512>(bank_addr);
+  });
+  wu_static_for<9>([&](auto cc) __attribute__((always_inline)) {
+    constexpr int c = decltype(cc)::value;
+    wu_wait();
 #pragma unroll
-  for (int c = 0; c < 9; ++c)
+    for (int t = 0; t < NT; ++t) wu_tie(fa[c & 1][t]);
+    if constexpr (c + 1 < 9) {
+      wu_static_for<NT>([&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value;
+        fa[(c + 1) & 1][t] = wu_lds64<(t * 9 + c + 1) * 512>(bank_addr);
+      });
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const f32x2 a = wu_lds(bank_chunk + ((t * 9 + c) * 64 + lane) * 2);
+      const f32x2 a = fa[c & 1][t];
       const f32x4 z = FIRST ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[c][t];
       acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], V[c][0], z, 0, 0, 0);
       acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], V[c][1], acc[c][t], 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+  });
 }
 
 // Work items: groups of 8 vertically adjacent tile blocks, item = (image * groups_y + gy) * blocks_x + bx, walked with stride G.
@@ -110,6 +148,7 @@ __global__ void __launch_bounds__(64 * WU_NWAVE, 1) winoups_fwd(const WuArgs a) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int HWl = a.Hl * a.Wl, H = 2 * a.Hl, W = 2 * a.Wl, HW = H * W;
   wu_load_bank(Us, a.up, a.nchunk * NT * 9 * 32, tid);
+  const unsigned us_addr = (unsigned)reinterpret_cast<size_t>(Us + lane * 2);  // (low 32 bits of a shared-aperture address = LDS offset)
   WuWalk w;
   w.init(blockIdx.x, a.G, a.N, a.Hl / WU_NWAVE, a.blocks_x);
   if (w.item >= w.nitems) return;
@@ -181,11 +220,11 @@ __global__ void __launch_bounds__(64 * WU_NWAVE, 1) winoups_fwd(const WuArgs a) 
     // (at least two chunks: wu_shape_ok)
     transform();
     load_rows(1);
-    wu_mma<NT, true>(Us, lane, V, acc);
+    wu_mma<NT, true>(us_addr, V, acc);
     for (int ch = 1; ch + 1 < a.nchunk; ++ch) {
       transform();
       load_rows(ch + 1);
-      wu_mma<NT, false>(Us + (size_t)ch * NT * 9 * 128, lane, V, acc);
+      wu_mma<NT, false>(us_addr + (unsigned)ch * (NT * 9 * 512), V, acc);
     }
     transform();
     // the first chunk of this wave's next block rides under the last chunk's MFMAs and the epilogue
@@ -193,7 +232,7 @@ __global__ void __launch_bounds__(64 * WU_NWAVE, 1) winoups_fwd(const WuArgs a) 
     ty = w.gy * WU_NWAVE + wave;
     geometry(ty);
     load_rows(0);
-    wu_mma<NT, false>(Us + (size_t)(a.nchunk - 1) * NT * 9 * 128, lane, V, acc);
+    wu_mma<NT, false>(us_addr + (unsigned)(a.nchunk - 1) * (NT * 9 * 512), V, acc);
     // ---- epilogue: 2x2 outputs of the lane's tile from the nine components (A^T M A without row / column 2):
     //   y00 = M00 + M01 + M10 + M11   y01 = M01 - M03 + M11 - M13   y10 = M10 + M11 - M30 - M31   y11 = M11 - M13 - M31 + M33
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y ? a.y + (size_t)en * a.Cout * HW : nullptr, 0, a.y ? a.Cout * HW * 4 : 0, 0x00020000);
@@ -270,6 +309,7 @@ __global__ void __launch_bounds__(64 * WU_NWAVE, 1) winoups_dgrad(const WuArgs a
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int HWl = a.Hl * a.Wl, H = 2 * a.Hl, W = 2 * a.Wl, HW = H * W;
   wu_load_bank(Us, a.up, a.nchunk * NT * 9 * 32, tid);
+  const unsigned us_addr = (unsigned)reinterpret_cast<size_t>(Us + lane * 2);  // (low 32 bits of a shared-aperture address = LDS offset)
   WuWalk w;
   w.init(blockIdx.x, a.G, a.N, a.Hl / WU_NWAVE, a.blocks_x);
   if (w.item >= w.nitems) return;
@@ -335,11 +375,11 @@ __global__ void __launch_bounds__(64 * WU_NWAVE, 1) winoups_dgrad(const WuArgs a
     // (at least two chunks: wu_shape_ok)
     transform();
     load_rows(1);
-    wu_mma<NT, true>(Us, lane, V, acc);
+    wu_mma<NT, true>(us_addr, V, acc);
     for (int ch = 1; ch + 1 < a.nchunk; ++ch) {
       transform();
       load_rows(ch + 1);
-      wu_mma<NT, false>(Us + (size_t)ch * NT * 9 * 128, lane, V, acc);
+      wu_mma<NT, false>(us_addr + (unsigned)ch * (NT * 9 * 512), V, acc);
     }
     transform();
     // the first chunk of this wave's next block rides under the last chunk's MFMAs and the epilogue
@@ -347,7 +387,7 @@ __global__ void __launch_bounds__(64 * WU_NWAVE, 1) winoups_dgrad(const WuArgs a
     ty = w.gy * WU_NWAVE + wave;
     geometry(ty);
     load_rows(0);
-    wu_mma<NT, false>(Us + (size_t)(a.nchunk - 1) * NT * 9 * 128, lane, V, acc);
+    wu_mma<NT, false>(us_addr + (unsigned)(a.nchunk - 1) * (NT * 9 * 512), V, acc);
     // gx(tile) = s^T M s: the factors of s are in the filters, so the low-res pixel is the plain sum of the nine accumulators
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)en * a.Cout * HWl, 0, a.Cout * HWl * 4, 0x00020000);
     const int lo = ((rq * 4) * HWl + col) * 4, so0 = (ety * a.Wl + 16 * ebx) * 4;
