@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(256) conv1x1_few_out(const C1Args a) {
 
 // ---------------------------------------------------------------- weight / bias gradient
 // M = the many-channel tensor, F = the few-channel one.  S[m][f] = sum_{n,p} M[m] F[f];  sums of gy per channel.
-constexpr int MC = 16;  // many-channels per grid.y slice
+constexpr int MC = 8;   // many-channels per grid.y slice (8: 80 registers, six waves per SIMD; 16 ran at two)
 struct W1Args {
   const float* many;
   const float* few;
@@ -283,42 +283,41 @@ __device__ __forceinline__ void w1_locate(int e, int Cm, int Cf, int gy_is_many,
   }
 }
 
-template <int V>
+template <int V, int CF>
 __global__ void __launch_bounds__(256) conv1x1_wgrad_part(const W1Args a) {
   __shared__ float red[4][MC * (FEW + 1) + FEW];
   const int m0 = blockIdx.y * MC;
   const int q = a.HW / V;
   const size_t total = (size_t)a.N * q;
-  float s[MC][FEW], sm[MC], sf[FEW];
+  float s[MC][CF], sm[MC], sf[CF];
 #pragma unroll
   for (int m = 0; m < MC; ++m) {
     sm[m] = 0.f;
 #pragma unroll
-    for (int f = 0; f < FEW; ++f) s[m][f] = 0.f;
+    for (int f = 0; f < CF; ++f) s[m][f] = 0.f;
   }
 #pragma unroll
-  for (int f = 0; f < FEW; ++f) sf[f] = 0.f;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int n = (int)(i / q);
-    const int p = (int)(i - (size_t)n * q) * V;
-    float fv[FEW][V];
+  for (int f = 0; f < CF; ++f) sf[f] = 0.f;
+  // position = (sample n, pixel group p) walked with the grid's stride: one division before the loop, none inside
+  const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int dn = (int)(stride / q), dp = (int)(stride - (size_t)dn * q);
+  int n = (int)(i0 / q), pq = (int)(i0 - (size_t)n * q);
+  for (size_t i = i0; i < total; i += stride) {
+    const int p = pq * V;
+    float fv[CF][V];
 #pragma unroll
-    for (int f = 0; f < FEW; ++f) {
+    for (int f = 0; f < CF; ++f) {
+      const size_t idx = ((size_t)n * CF + f) * a.HW + p;
+      load_v<V>(a.few + idx, fv[f]);
+      if (a.tanh_few) {
+        float th[V];
+        load_v<V>(a.tanh_few + idx, th);
 #pragma unroll
-      for (int v = 0; v < V; ++v) fv[f][v] = 0.f;
-      if (f < a.Cf) {
-        const size_t idx = ((size_t)n * a.Cf + f) * a.HW + p;
-        load_v<V>(a.few + idx, fv[f]);
-        if (a.tanh_few) {
-          float th[V];
-          load_v<V>(a.tanh_few + idx, th);
+        for (int v = 0; v < V; ++v) fv[f][v] *= (1.f - th[v] * th[v]);
+      }
+      if (n < a.bias_n) {
 #pragma unroll
-          for (int v = 0; v < V; ++v) fv[f][v] *= (1.f - th[v] * th[v]);
-        }
-        if (n < a.bias_n) {
-#pragma unroll
-          for (int v = 0; v < V; ++v) sf[f] += fv[f][v];
-        }
+        for (int v = 0; v < V; ++v) sf[f] += fv[f][v];
       }
     }
     // the MC loads first (channels past Cm re-read the last one and are discarded), then the arithmetic: with the range test
@@ -336,10 +335,13 @@ __global__ void __launch_bounds__(256) conv1x1_wgrad_part(const W1Args a) {
         for (int v = 0; v < V; ++v) {
           sm[m] += n < a.bias_n ? mvs[m][v] : 0.f;
 #pragma unroll
-          for (int f = 0; f < FEW; ++f) s[m][f] = fmaf(mvs[m][v], fv[f][v], s[m][f]);
+          for (int f = 0; f < CF; ++f) s[m][f] = fmaf(mvs[m][v], fv[f][v], s[m][f]);
         }
       }
     }
+    n += dn;
+    pq += dp;
+    if (pq >= q) { pq -= q; ++n; }
   }
   // wave reduce, then across the 4 waves through LDS
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -348,7 +350,7 @@ __global__ void __launch_bounds__(256) conv1x1_wgrad_part(const W1Args a) {
   for (int m = 0; m < MC; ++m) {
 #pragma unroll
     for (int f = 0; f < FEW; ++f) {
-      const float r = mg_wave_sum_to_lane63(s[m][f]);
+      const float r = f < CF ? mg_wave_sum_to_lane63(s[m][f < CF ? f : 0]) : 0.f;
       if (lane == 63) red[wave][m * (FEW + 1) + f] = r;
     }
     const float r = mg_wave_sum_to_lane63(sm[m]);
@@ -356,7 +358,7 @@ __global__ void __launch_bounds__(256) conv1x1_wgrad_part(const W1Args a) {
   }
 #pragma unroll
   for (int f = 0; f < FEW; ++f) {
-    const float r = mg_wave_sum_to_lane63(sf[f]);
+    const float r = f < CF ? mg_wave_sum_to_lane63(sf[f < CF ? f : 0]) : 0.f;
     if (lane == 63) red[wave][MC * (FEW + 1) + f] = r;
   }
   __syncthreads();
@@ -439,6 +441,20 @@ __global__ void __launch_bounds__(256) conv1x1_wgrad_final(const float* __restri
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
   if (lane == 0) dst[idx] = accumulate ? dst[idx] + s : s;
+}
+
+template <int V>
+void w1_launch_part_v(const W1Args& a, dim3 grid, hipStream_t s) {
+  switch (a.Cf) {  // (the few side's channel count is a template parameter: no arithmetic on absent channels)
+    case 1: hipLaunchKernelGGL((conv1x1_wgrad_part<V, 1>), grid, dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((conv1x1_wgrad_part<V, 2>), grid, dim3(256), 0, s, a); break;
+    case 3: hipLaunchKernelGGL((conv1x1_wgrad_part<V, 3>), grid, dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL((conv1x1_wgrad_part<V, 4>), grid, dim3(256), 0, s, a); break;
+  }
+}
+void w1_launch_part(const W1Args& a, bool vec4, dim3 grid, hipStream_t s) {
+  if (vec4) w1_launch_part_v<4>(a, grid, s);
+  else w1_launch_part_v<1>(a, grid, s);
 }
 
 int c1_grid(size_t work_items) {
@@ -544,8 +560,7 @@ extern "C" int mg_conv1x1_wgrad(const float* x, const float* gy, const float* ta
     }
     a.counter = base + (seq.fetch_add(1) & 63u);
   }
-  if ((HW & 3) == 0) hipLaunchKernelGGL(conv1x1_wgrad_part<4>, dim3(nx, ny), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(conv1x1_wgrad_part<1>, dim3(nx, ny), dim3(256), 0, s, a);
+  w1_launch_part(a, (HW & 3) == 0, dim3(nx, ny), s);
   MG_CHECK_LAUNCH("mg_conv1x1_wgrad");
   if (a.counter != nullptr) return MG_OK;
   const int total = a.Cm * a.Cf + Cout;
