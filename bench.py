@@ -383,7 +383,7 @@ def host_io_probe(device, scratch_dir: str, threads: int, samples_per_thread: in
     """What bounds create_dataset end to end on THIS box (BASELINE configs[4]; reference create_dataset.py:34-64 leaves 201 float64
     (2,512,512) .pt files = 843 MB per 10-minute file behind, ours additionally the 421 MB float32 side-car): (a) the pinned
     device-to-host rate in the loop's 64 MiB chunks, one and two copy streams; (b) the writer path of one sample -- float32 ->
-    float64 (numpy), `writev` of the 8 MiB .pt file, `pwrite` of the 4 MiB side-car row -- on one thread and on `threads` threads,
+    float64, `writev` of the 4 MiB .pt file, `pwrite` of the 2 MiB side-car row -- on one thread and on `threads` threads,
     in the scratch directory the record uses.  bound per file = max(421 MB / D2H rate, 201 samples / writer-path rate)."""
     import threading
     chunk_bytes = 32 * 2 * 512 * 512 * 4
@@ -426,7 +426,7 @@ def host_io_probe(device, scratch_dir: str, threads: int, samples_per_thread: in
     # (the independent loops run BEFORE the product's own path: each leaves gigabytes of dirty pages behind, and whoever writes second
     # is throttled by the page cache -- measured the other way round, the "bound" came out 1.4x slower than the product)
     # The bound itself must not be the product's own call: the two things a sample costs the host whatever the code around them --
-    # (i) plain `write` of 8 MiB into a new file + `pwrite` of 4 MiB into a per-thread file, from a zero buffer (page cache, inode
+    # (i) plain `write` of the sample's 4 MiB into a new file + `pwrite` of its 2 MiB side-car row into a per-thread file, from a zero buffer (page cache, inode
     # and directory work of this file system), (ii) a float32 -> float64 widening of 2 x 512 x 512 values -- each on `threads`
     # threads at once, as native loops (mg_host_io_probe: through ctypes without the interpreter lock; the same calls made from
     # Python threads measured the lock hand-over, 2x slower than the product's writer path).
@@ -437,7 +437,7 @@ def host_io_probe(device, scratch_dir: str, threads: int, samples_per_thread: in
 
     def prober(tid):
         ws, ds = ctypes.c_double(0.0), ctypes.c_double(0.0)
-        rc = lib.mg_host_io_probe(os.fsencode(scratch_dir), tid, n_ind, 8 << 20, 4 << 20, ctypes.c_void_p(src32[tid].ctypes.data), row_floats,
+        rc = lib.mg_host_io_probe(os.fsencode(scratch_dir), tid, n_ind, row_floats * 8 + len(prefix) + len(suffix), row_floats * 4, ctypes.c_void_p(src32[tid].ctypes.data), row_floats,
                                   ctypes.byref(ws), ctypes.byref(ds))
         assert rc == 0, lib.mg_last_error()
         wsec[tid], dsec[tid] = ws.value, ds.value
@@ -477,8 +477,8 @@ def host_io_probe(device, scratch_dir: str, threads: int, samples_per_thread: in
     out.update({"threads": threads, "bound_s_per_file_d2h": per_file_d2h, "bound_s_per_file_host_write_and_widen": per_file_indep,
                 "product_writer_path_s_per_file": per_file_write,
                 "bound_files_per_s": 1.0 / max(per_file_d2h, per_file_indep),
-                "basis": "per 10-minute file: 421 MB over the measured pinned D2H rate; 201 samples x (plain write of 8 MiB to a new file + "
-                         "pwrite of 4 MiB + one float32 -> float64 pass; native loops, mg_host_io_probe), zero / random buffers, on the "
+                "basis": "per 10-minute file: 421 MB over the measured pinned D2H rate; 201 samples x (plain write of 4 MiB to a new file + "
+                         "pwrite of 2 MiB + one float32 -> float64 pass; native loops, mg_host_io_probe), zero / random buffers, on the "
                          "writer threads' count of threads at once, in the record's scratch directory; the larger one.  "
                          "`product_writer_path_*`: the loop's own native call (mg_pt_write_samples) on the same threads, for comparison "
                          "-- not part of the bound"})
