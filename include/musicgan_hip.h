@@ -209,7 +209,12 @@ int mg_conv1x1_wgrad(const float* x, const float* gy, const float* tanh_y, float
  * mg_stem_pair_gx [the same lines, backward to x]: gx = ws^T gs + 0.25 * up2(wo^T go), gs (N,C0,H,W), go (N,C1,H/2,W/2), gx (N,2,H,W).
  * mg_head_pair [generator.py:118-126]: mp = tanh(wh x + bh) (N,2,H,W), old = tanh(wo xl + bo) (N,2,H/2,W/2), out = a mp + b up2(old);
  *   (a, b) = coef[0..1] from device memory if coef != NULL, else (ca, cb); mp / old may be NULL (not kept).  wh (2,C), wo (2,Cl).
- * mg_blend_up_bwd: gx = a g, gy = b * (2x2 block sums of g): the blend's backward (g: (NC,H,W), gy: (NC,H/2,W/2)). */
+ * mg_blend_up_bwd: gx = a g, gy = b * (2x2 block sums of g): the blend's backward (g: (NC,H,W), gy: (NC,H/2,W/2)).
+ * mg_gen_head_bwd [generator.py:118-126 backward + layers.py:11-17 / generator.py:31-39 backward of the block in front]: from the
+ *   gradient g_mp (N,2,H,W) at the head's tanh output mp: t = g_mp (1 - mp^2); gw (2,C) (+)= sum t p, gb (2) (+)= sum t (autograd's
+ *   convolution_backward of the 1x1 head, x = p (N,C,H,W) the last block's PixelNorm output); g = w^T t; gpre = lrelu'(p) rn
+ *   (g - p mean_c(g p)) (N,C,H,W) = the gradient at the last conv's pre-activation (PixelNorm + LeakyReLU backward, rn (N,1,H,W) the
+ *   stored 1/norm).  One read of p, one write of gpre.  C in {16, 32, 48, 64}; ws: mg_gen_head_bwd_ws_floats(N, C, HW) floats. */
 int mg_stem_pair(const float* x, const float* ws, const float* bs, const float* wo, const float* bo, float* h0, float* xp, float* o,
                  unsigned char* h0_mask, int N, int C0, int C1, int H, int W, int flags, float slope, mg_stream_t stream);
 int mg_stem_pair_gx(const float* gs, const float* ws, const float* go, const float* wo, float* gx, int N, int C0, int C1, int H, int W,
@@ -218,6 +223,10 @@ int mg_head_pair(const float* x, const float* wh, const float* bh, const float* 
                  float ca, float cb, float* mp, float* old, float* out, int N, int C, int Cl, int H, int W, mg_stream_t stream);
 int mg_blend_up_bwd(const float* g, const float* coef, float ca, float cb, float* gx, float* gy, int NC, int H, int W,
                     mg_stream_t stream);
+int mg_gen_head_bwd_supported(int C, int Cout);
+size_t mg_gen_head_bwd_ws_floats(int N, int C, int HW);
+int mg_gen_head_bwd(const float* g_mp, const float* mp, const float* w, const float* p, const float* rn, float* gpre, float* gw, float* gb,
+                    float* ws, size_t ws_floats, int N, int C, int HW, float slope, int accumulate, mg_stream_t stream);
 
 /* ------------------------------------------------------------------ element-wise / small ops */
 /* PixelNorm forward [layers.py:11-17]: p = y*rn, rn[n,hw] = 1/sqrt(mean_c y^2 + 1e-8) */

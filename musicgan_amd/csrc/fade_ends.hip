@@ -277,6 +277,115 @@ int grid_for(size_t items, int per_block, int cap) {
   return (int)b;
 }
 
+
+// ---- generator head, backward, with the PixelNorm + LeakyReLU backward of the last block's second conv in the same pass
+// [generator.py:118-126 ToMagnPhaseLayer = tanh(conv1x1), layers.py:11-17 PixelNorm, generator.py:31-39]: replaces, per pixel,
+//   t_f     = g_mp[f] (1 - mp[f]^2)                              tanh backward (conv1x1.hip: MG_C1_TANH_BWD_IN)
+//   gw[f][c] += t_f p[c],  gb[f] += t_f                         conv1x1_wgrad (head weights (2, C), x = p: the block's output)
+//   g[c]    = w[0][c] t_0 + w[1][c] t_1                         conv1x1 transposed (the head's data gradient)
+//   gpre[c] = lrelu'(p[c]) rn (g[c] - p[c] mean_c(g p))         pixelnorm_lrelu_bwd, from_p form (elementwise.hip)
+// -- three launches that read p twice and wrote / re-read the C-channel g (5 tensor passes) -- as one read of p and one write of gpre.
+// One pixel per thread and turn; the pixel's C values of p wait in LDS between the two sweeps (a thread reads back its own column only:
+// no barrier); the 2 C weight-gradient sums stay in registers over the thread's pixels and are reduced once per workgroup.
+template <int C>
+__global__ void __launch_bounds__(256) gen_head_bwd_k(const float* __restrict__ gm, const float* __restrict__ mp, const float* __restrict__ w,
+                                                      const float* __restrict__ p, const float* __restrict__ rn, float* __restrict__ gpre,
+                                                      float* __restrict__ part, int N, int HW, float slope) {
+  extern __shared__ __attribute__((aligned(16))) float park[];  // [C][256], then (reduction) [4][2 C + 2]
+  const int tid = threadIdx.x;
+  float s0[C], s1[C], sb0 = 0.f, sb1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) s0[c] = s1[c] = 0.f;
+  const size_t total = (size_t)N * HW, stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + tid; i < total; i += stride) {
+    const int n = (int)(i / HW);
+    const int px = (int)(i - (size_t)n * HW);
+    const size_t fb = (size_t)n * 2 * HW + px, base = (size_t)n * C * HW + px;
+    const float m0 = mp[fb], m1 = mp[fb + HW];
+    const float t0 = gm[fb] * (1.f - m0 * m0), t1 = gm[fb + HW] * (1.f - m1 * m1);
+    const float r = rn[i];
+    sb0 += t0;
+    sb1 += t1;
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float t = p[base + (size_t)c * HW];
+      park[c * 256 + tid] = t;
+      const float g = fmaf(w[C + c], t1, w[c] * t0);
+      dot = fmaf(g, t, dot);
+      s0[c] = fmaf(t0, t, s0[c]);
+      s1[c] = fmaf(t1, t, s1[c]);
+    }
+    dot /= (float)C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float t = park[c * 256 + tid];
+      const float g = fmaf(w[C + c], t1, w[c] * t0);
+      gpre[base + (size_t)c * HW] = mg_lrelu_mask(t, slope) * r * (g - t * dot);
+    }
+  }
+  // the workgroup's sums: wave totals by DPP, the four waves through LDS, one row of 2 C + 2 partials per workgroup
+  __syncthreads();  // (every thread is done with its parked column)
+  const int lane = tid & 63, wave = tid >> 6;
+  constexpr int PER = 2 * C + 2;
+  float* red = park;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float a0 = mg_wave_sum_to_lane63(s0[c]), a1 = mg_wave_sum_to_lane63(s1[c]);
+    if (lane == 63) {
+      red[wave * PER + c] = a0;
+      red[wave * PER + C + c] = a1;
+    }
+  }
+  {
+    const float a0 = mg_wave_sum_to_lane63(sb0), a1 = mg_wave_sum_to_lane63(sb1);
+    if (lane == 63) {
+      red[wave * PER + 2 * C] = a0;
+      red[wave * PER + 2 * C + 1] = a1;
+    }
+  }
+  __syncthreads();
+  if (tid < PER) part[(size_t)blockIdx.x * PER + tid] = (red[tid] + red[PER + tid]) + (red[2 * PER + tid] + red[3 * PER + tid]);
+}
+
+// gw (2, C) and gb (2) from the per-workgroup partials: one wave per output, lanes stride over the workgroups, a fixed shuffle tree
+__global__ void __launch_bounds__(256) gen_head_bwd_final_k(const float* __restrict__ part, int G, int C, float* __restrict__ gw,
+                                                            float* __restrict__ gb, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6), per = 2 * C + 2;
+  if (e >= per) return;
+  float s = 0.f;
+  for (int b = lane; b < G; b += 64) s += part[(size_t)b * per + e];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+  if (lane == 0) {
+    float* dst = e < 2 * C ? gw + e : gb + (e - 2 * C);
+    *dst = accumulate ? *dst + s : s;
+  }
+}
+
+template <int C>
+int gen_head_bwd_launch(const float* gm, const float* mp, const float* w, const float* p, const float* rn, float* gpre, float* part, int G,
+                        int N, int HW, float slope, hipStream_t s) {
+  static MgPerDevice once;
+  if (mg_first_use_on_device(once))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_head_bwd_k<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(gen_head_bwd_k<C>, dim3(G), dim3(256), (size_t)C * 256 * sizeof(float), s, gm, mp, w, p, rn, gpre, part, N, HW, slope);
+  MG_CHECK_LAUNCH("mg_gen_head_bwd");
+  return MG_OK;
+}
+
+// workgroups: as many as fit the chip at once (LDS: C KB each), never more than there are 256-pixel groups
+int gen_head_bwd_grid(int C, size_t pixels) {
+  int per_cu = (160 * 1024) / (C * 1024);
+  if (per_cu > 8) per_cu = 8;
+  if (per_cu < 1) per_cu = 1;
+  size_t g = (size_t)per_cu * mg_cu_count();
+  const size_t need = (pixels + 255) / 256;
+  if (g > need) g = need;
+  return (int)(g < 1 ? 1 : g);
+}
+
 }  // namespace
 
 extern "C" int mg_stem_pair(const float* x, const float* ws, const float* bs, const float* wo, const float* bo, float* h0, float* xp,
@@ -337,5 +446,32 @@ extern "C" int mg_blend_up_bwd(const float* g, const float* coef, float ca, floa
   hipLaunchKernelGGL(blend_up_bwd_k, dim3(grid_for(total, 256, 2048)), dim3(256), 0, (hipStream_t)stream, g, coef, ca, cb, gx, gy, total,
                      H / 2, W / 4);
   MG_CHECK_LAUNCH("mg_blend_up_bwd");
+  return MG_OK;
+}
+
+extern "C" int mg_gen_head_bwd_supported(int C, int Cout) { return (Cout == 2 && (C == 16 || C == 32 || C == 48 || C == 64)) ? 1 : 0; }
+
+extern "C" size_t mg_gen_head_bwd_ws_floats(int N, int C, int HW) {
+  return (size_t)gen_head_bwd_grid(C, (size_t)N * HW) * (2 * C + 2);
+}
+
+extern "C" int mg_gen_head_bwd(const float* g_mp, const float* mp, const float* w, const float* p, const float* rn, float* gpre, float* gw,
+                               float* gb, float* ws, size_t ws_floats, int N, int C, int HW, float slope, int accumulate,
+                               mg_stream_t stream) {
+  MG_CHECK_ARG(g_mp && mp && w && p && rn && gpre && gw && gb && ws && N > 0 && HW > 0, "mg_gen_head_bwd: bad arguments");
+  MG_CHECK_ARG(mg_gen_head_bwd_supported(C, 2), "mg_gen_head_bwd: C = %d (16, 32, 48 or 64)", C);
+  const int G = gen_head_bwd_grid(C, (size_t)N * HW);
+  MG_CHECK_ARG(ws_floats >= (size_t)G * (2 * C + 2), "mg_gen_head_bwd: workspace of %zu floats, needs %zu", ws_floats, (size_t)G * (2 * C + 2));
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  switch (C) {
+    case 16: rc = gen_head_bwd_launch<16>(g_mp, mp, w, p, rn, gpre, ws, G, N, HW, slope, s); break;
+    case 32: rc = gen_head_bwd_launch<32>(g_mp, mp, w, p, rn, gpre, ws, G, N, HW, slope, s); break;
+    case 48: rc = gen_head_bwd_launch<48>(g_mp, mp, w, p, rn, gpre, ws, G, N, HW, slope, s); break;
+    default: rc = gen_head_bwd_launch<64>(g_mp, mp, w, p, rn, gpre, ws, G, N, HW, slope, s); break;
+  }
+  if (rc != MG_OK) return rc;
+  hipLaunchKernelGGL(gen_head_bwd_final_k, dim3((2 * C + 2 + 3) / 4), dim3(256), 0, s, ws, G, C, gw, gb, accumulate);
+  MG_CHECK_LAUNCH("mg_gen_head_bwd(final)");
   return MG_OK;
 }

@@ -446,15 +446,21 @@ def gen_backward(W: GenWeights, ctx, g_out: torch.Tensor, cache: PackCache, sink
         g_mp, g_old = g_out, None
     gw, acc = sink.slot(W.head[0])
     gb, _ = sink.slot(W.head[1])
-    ops.conv1x1_wgrad(x_last, g_mp, gw, gb, tanh_y=mp, accumulate=acc)
-    g = ops.conv1x1(g_mp, W.head[0], None, x_last.shape[1], transposed=True, tanh_bwd_in=mp)
     last = len(W.blocks) - 1
+    gpre_head = None
+    if ops.gen_head_bwd_supported(x_last.shape[1], W.head[0].shape[0]) and saved[last][4] is x_last:
+        # the head's weight gradient, its data gradient and the PixelNorm / LeakyReLU backward of the last conv: one pass over p
+        gpre_head = ops.gen_head_bwd(g_mp, mp, W.head[0], x_last, saved[last][3], gw, gb, accumulate=acc)
+        g = None
+    else:
+        ops.conv1x1_wgrad(x_last, g_mp, gw, gb, tanh_y=mp, accumulate=acc)
+        g = ops.conv1x1(g_mp, W.head[0], None, x_last.shape[1], transposed=True, tanh_bwd_in=mp)
     gz = None
     for i in range(last, -1, -1):
         w1, b1, w2, b2 = W.blocks[i]
         xin, rn1, p1, rn2, p2 = saved[i]
         ci = w1.shape[0]
-        gpre2 = ops.pixelnorm_lrelu_bwd(g, p2, rn2, from_p=True)
+        gpre2 = gpre_head if (i == last and gpre_head is not None) else ops.pixelnorm_lrelu_bwd(g, p2, rn2, from_p=True)
         gw2, acc = sink.slot(w2)
         gb2, _ = sink.slot(b2)
         ops.conv3x3_wgrad(p1, gpre2, gw2, gb2, ups=True, accumulate=acc, defer=defer)

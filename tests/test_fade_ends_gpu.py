@@ -177,3 +177,36 @@ def test_update_with_fused_ends_equals_the_separate_kernels(level, batch, monkey
         assert float((a_ - b_).abs().max()) <= 1e-5 * float(a_.abs().max()) + 1e-12
     for k, v in grads["0"][2].items():
         assert abs(v - grads["1"][2][k]) <= 1e-5 * max(1.0, abs(v)), k
+
+
+@pytest.mark.parametrize("shape", [(3, 48, 16, 24), (2, 64, 8, 8), (5, 32, 32, 16), (2, 16, 64, 64), (1, 48, 128, 128)])
+def test_gen_head_bwd_matches_the_three_launches_and_autograd(shape):
+    """mg_gen_head_bwd (head weight / data gradient + PixelNorm / LeakyReLU backward of the block in front, one pass) against the
+    three launches it replaces and against fp64 autograd of tanh(conv1x1(PixelNorm(LeakyReLU(y)))) -- generator.py:31-39, 118-126."""
+    ops = _ops()
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(23)
+    y = torch.randn(n, c, h, w, generator=g, dtype=torch.float64, requires_grad=True)
+    wt = (torch.randn(2, c, 1, 1, generator=g, dtype=torch.float64) / c ** 0.5).requires_grad_(True)
+    bt = torch.randn(2, generator=g, dtype=torch.float64, requires_grad=True)
+    g_mp = torch.randn(n, 2, h, w, generator=g, dtype=torch.float64)
+    a = torch.nn.functional.leaky_relu(y, 0.2)
+    p = a / torch.sqrt((a * a).mean(dim=1, keepdim=True) + 1e-8)
+    mp = torch.tanh(torch.nn.functional.conv2d(p, wt, bt))
+    (mp * g_mp).sum().backward()
+    pd, mpd, gd, wd = p.detach().float().to(DEV), mp.detach().float().to(DEV), g_mp.float().to(DEV), wt.detach().float().to(DEV)
+    rn = (1.0 / torch.sqrt((a * a).mean(dim=1, keepdim=True) + 1e-8)).detach().float().to(DEV)
+    gw, gb = torch.full((2, c, 1, 1), 3.0, device=DEV), torch.full((2,), 3.0, device=DEV)
+    assert ops.gen_head_bwd_supported(c)
+    gpre = ops.gen_head_bwd(gd, mpd, wd, pd, rn, gw, gb)
+    rel = lambda got, ref: float((got.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert rel(gpre, y.grad) <= 5e-6 and rel(gw, wt.grad) <= 5e-6 and rel(gb, bt.grad) <= 5e-6
+    # the separate launches
+    gw0, gb0 = torch.empty_like(gw), torch.empty_like(gb)
+    ops.conv1x1_wgrad(pd, gd, gw0, gb0, tanh_y=mpd)
+    g0 = ops.conv1x1(gd, wd, None, c, transposed=True, tanh_bwd_in=mpd)
+    gpre0 = ops.pixelnorm_lrelu_bwd(g0, pd, rn, from_p=True)
+    assert rel(gpre, gpre0.double().cpu()) <= 2e-6 and rel(gw, gw0.double().cpu()) <= 2e-6 and rel(gb, gb0.double().cpu()) <= 2e-6
+    gpre2 = ops.gen_head_bwd(gd, mpd, wd, pd, rn, gw, gb, accumulate=True)
+    assert torch.equal(gpre, gpre2) and rel(gw, 2 * wt.grad) <= 5e-6 and rel(gb, 2 * bt.grad) <= 5e-6
+    assert not ops.gen_head_bwd_supported(40) and not ops.gen_head_bwd_supported(48, 3)

@@ -44,3 +44,18 @@ for (n, c, hw) in [(64, 48, 128), (64, 64, 64)]:
     gp, p = R(n, c, hw, hw), R(n, c, hw, hw)
     rn = torch.rand(n, 1, hw, hw, device=dev, generator=g) + 0.5
     row(f"pixelnorm_lrelu_bwd from_p {n}x{c}@{hw}", timeit(lambda: ops.pixelnorm_lrelu_bwd(gp, p, rn, from_p=True)), (3 * gp.numel() + rn.numel()) * 4)
+# generator head backward: three launches (1x1 weight gradient, transposed 1x1, PixelNorm + LeakyReLU backward) against the fused one
+for (n, c, hw) in [(64, 48, 128), (6, 32, 256), (6, 16, 512), (16, 16, 512), (32, 64, 64)]:
+    p, gm, mp = R(n, c, hw, hw), R(n, 2, hw, hw), torch.tanh(R(n, 2, hw, hw))
+    rn = torch.rand(n, 1, hw, hw, device=dev, generator=g) + 0.5
+    w = R(2, c, 1, 1) * 0.1
+    gw, gb = torch.empty(2, c, 1, 1, device=dev), torch.empty(2, device=dev)
+
+    def three():
+        ops.conv1x1_wgrad(p, gm, gw, gb, tanh_y=mp)
+        gg = ops.conv1x1(gm, w, None, c, transposed=True, tanh_bwd_in=mp)
+        return ops.pixelnorm_lrelu_bwd(gg, p, rn, from_p=True)
+
+    row(f"head backward, three launches {n}x{c}@{hw}", timeit(three), (5 * p.numel()) * 4)
+    if ops.gen_head_bwd_supported(c):
+        row(f"head backward, fused {n}x{c}@{hw}", timeit(lambda: ops.gen_head_bwd(gm, mp, w, p, rn, gw, gb)), (2 * p.numel()) * 4)
