@@ -80,6 +80,11 @@ size_t mg_winoups3x3_packed_floats(int Cin, int Cout, int dgrad);
 int mg_winoups3x3(const float* x, const float* up, const float* bias, float* y, float* p, float* rn, int N, int Cin, int Cout,
                   int Hin, int Win, int flags, float slope, mg_stream_t stream);
 int mg_winoups3x3_dgrad(const float* gy, const float* up, float* gx, int N, int Cin, int Cout, int Hin, int Win, mg_stream_t stream);
+/* mg_winoups3x3 (LeakyReLU + PixelNorm) with the generator's 1x1 head [generator.py:118-126 ToMagnPhaseLayer] on the normalised
+ * activation in the same epilogue: mp = tanh(hw p + hb), hw (2,Cout), hb (2) or NULL, mp (N,2,2Hin,2Win); p, rn as above, y optional. */
+int mg_winoups3x3_head_supported(int N, int Cin, int Cout, int Hin, int Win); /* mg_winoups3x3_supported and at most 48 out-channels */
+int mg_winoups3x3_head(const float* x, const float* up, const float* bias, float* y, float* p, float* rn, const float* hw, const float* hb,
+                       float* mp, int N, int Cin, int Cout, int Hin, int Win, float slope, mg_stream_t stream);
 size_t mg_upconv3x3_packed_floats(int Cin, int Cout);
 int mg_upconv3x3_pack(const float* w, float* wp, int Co, int Ci, mg_stream_t stream);
 int mg_upconv3x3(const float* x, const float* wp, const float* bias, float* y, float* p, float* rn, int N, int Cin, int Cout,
@@ -223,6 +228,9 @@ int mg_head_pair(const float* x, const float* wh, const float* bh, const float* 
                  float ca, float cb, float* mp, float* old, float* out, int N, int C, int Cl, int H, int W, mg_stream_t stream);
 int mg_blend_up_bwd(const float* g, const float* coef, float ca, float cb, float* gx, float* gy, int NC, int H, int W,
                     mg_stream_t stream);
+/* mg_head_pair with mp given (written by mg_winoups3x3_head): old = tanh(wo xl + bo), out = a mp + b up2(old). */
+int mg_head_pair_from_mp(const float* mp, const float* xl, const float* wo, const float* bo, const float* coef, float ca, float cb,
+                         float* old, float* out, int N, int Cl, int H, int W, mg_stream_t stream);
 int mg_gen_head_bwd_supported(int C, int Cout);
 size_t mg_gen_head_bwd_ws_floats(int N, int C, int HW);
 int mg_gen_head_bwd(const float* g_mp, const float* mp, const float* w, const float* p, const float* rn, float* gpre, float* gw, float* gb,

@@ -76,6 +76,8 @@ SIGNATURES = {
     "mg_winoups3x3_packed_floats": (c_size_t, [c_int, c_int, c_int]),
     "mg_winoups3x3": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "mg_winoups3x3_dgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "mg_winoups3x3_head_supported": (c_int, [c_int] * 5),
+    "mg_winoups3x3_head": (c_int, [_P] * 9 + [c_int] * 5 + [c_float, _P]),
     "mg_upconv3x3_packed_floats": (c_size_t, [c_int, c_int]),
     "mg_upconv3x3_pack": (c_int, [_P, _P, c_int, c_int, _P]),
     "mg_upconv3x3": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
@@ -127,6 +129,7 @@ SIGNATURES = {
     "mg_stem_pair_gx": (c_int, [_P] * 5 + [c_int] * 5 + [_P]),
     "mg_head_pair": (c_int, [_P] * 7 + [c_float, c_float] + [_P] * 3 + [c_int] * 5 + [_P]),
     "mg_blend_up_bwd": (c_int, [_P, _P, c_float, c_float, _P, _P, c_int, c_int, c_int, _P]),
+    "mg_head_pair_from_mp": (c_int, [_P] * 5 + [c_float, c_float, _P, _P] + [c_int] * 4 + [_P]),
     "mg_gen_head_bwd_supported": (c_int, [c_int, c_int]),
     "mg_gen_head_bwd_ws_floats": (c_size_t, [c_int, c_int, c_int]),
     "mg_gen_head_bwd": (c_int, [_P] * 9 + [c_size_t, c_int, c_int, c_int, c_float, c_int, _P]),

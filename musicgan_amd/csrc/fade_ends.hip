@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(256) pair_few_out_k(const PairArgs a) {
   const size_t HW = (size_t)a.H * a.W, PP = (size_t)Hh * Wh;
   const size_t total = (size_t)a.N * PP;
   float ca = a.ca, cb = a.cb;
-  if (MODE == 1 && a.coef != nullptr) { ca = a.coef[0]; cb = a.coef[1]; }
+  if (MODE != 0 && a.coef != nullptr) { ca = a.coef[0]; cb = a.coef[1]; }
   for (size_t base = (size_t)blockIdx.x * 64; base < total; base += (size_t)gridDim.x * 64) {
     const size_t i = base + lane;
     const bool ok = i < total;
@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(256) pair_few_out_k(const PairArgs a) {
     constexpr int U = 8;
     if (ok) {
       const float* xp = a.xf + (size_t)n * a.Cf * HW + off;
-      for (int c0 = wave; c0 < a.Cf; c0 += 4 * U) {
+      for (int c0 = wave; MODE != 2 && c0 < a.Cf; c0 += 4 * U) {  // (MODE 2: the front head's values are given in yf)
         f32x2 r0[U], r1[U];
         float w[U][2];
 #pragma unroll
@@ -233,13 +233,19 @@ __global__ void __launch_bounds__(256) pair_few_out_k(const PairArgs a) {
           const float bfv = a.bf ? a.bf[o] : 0.f, blv = a.bl ? a.bl[o] : 0.f;
           const float t = tanhf(sl + blv);
           float m[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) m[e] = tanhf(s[e] + bfv);
           if (a.yl != nullptr) a.yl[((size_t)n * 2 + o) * PP + q] = t;
-          if (a.yf != nullptr) {
-            float* pm = a.yf + ((size_t)n * 2 + o) * HW + off;
-            *reinterpret_cast<f32x2*>(pm) = f32x2{m[0], m[1]};
-            *reinterpret_cast<f32x2*>(pm + a.W) = f32x2{m[2], m[3]};
+          if (MODE == 2) {
+            const float* pm = a.yf + ((size_t)n * 2 + o) * HW + off;
+            const f32x2 r0 = *reinterpret_cast<const f32x2*>(pm), r1 = *reinterpret_cast<const f32x2*>(pm + a.W);
+            m[0] = r0[0]; m[1] = r0[1]; m[2] = r1[0]; m[3] = r1[1];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[e] = tanhf(s[e] + bfv);
+            if (a.yf != nullptr) {
+              float* pm = a.yf + ((size_t)n * 2 + o) * HW + off;
+              *reinterpret_cast<f32x2*>(pm) = f32x2{m[0], m[1]};
+              *reinterpret_cast<f32x2*>(pm + a.W) = f32x2{m[2], m[3]};
+            }
           }
           const float yl = cb * t;
           *reinterpret_cast<f32x2*>(po) = f32x2{fmaf(ca, m[0], yl), fmaf(ca, m[1], yl)};
@@ -435,6 +441,23 @@ extern "C" int mg_head_pair(const float* x, const float* wh, const float* bh, co
   const size_t quads = (size_t)N * (H / 2) * (W / 2);
   hipLaunchKernelGGL(pair_few_out_k<1>, dim3(grid_for(quads, 64, 4096)), dim3(256), 0, (hipStream_t)stream, a);
   MG_CHECK_LAUNCH("mg_head_pair");
+  return MG_OK;
+}
+
+// mg_head_pair with the new head's values given (mg_winoups3x3_head wrote them in the last conv's epilogue): old = tanh(wo xl + bo),
+// out = a mp + b up2(old)
+extern "C" int mg_head_pair_from_mp(const float* mp, const float* xl, const float* wo, const float* bo, const float* coef, float ca, float cb,
+                                    float* old, float* out, int N, int Cl, int H, int W, mg_stream_t stream) {
+  MG_CHECK_ARG(mp && xl && wo && out && N > 0 && Cl >= 4, "mg_head_pair_from_mp: bad arguments (at least 4 channels)");
+  MG_CHECK_ARG(H > 0 && W > 0 && (H % 2) == 0 && (W % 2) == 0, "mg_head_pair_from_mp: needs even H and W (got %dx%d)", H, W);
+  PairArgs a = {};
+  a.xf = xl; a.xl = xl; a.wf = wo; a.wl = wo; a.bf = nullptr; a.bl = bo;  // (the front side's operands are not read in this mode)
+  a.sof = Cl; a.scf = 1; a.sol = Cl; a.scl = 1;
+  a.coef = coef; a.ca = ca; a.cb = cb;
+  a.yf = const_cast<float*>(mp); a.yl = old; a.out = out; a.N = N; a.Cf = Cl; a.Cl = Cl; a.H = H; a.W = W; a.mode = 2;
+  const size_t quads = (size_t)N * (H / 2) * (W / 2);
+  hipLaunchKernelGGL(pair_few_out_k<2>, dim3(grid_for(quads, 64, 4096)), dim3(256), 0, (hipStream_t)stream, a);
+  MG_CHECK_LAUNCH("mg_head_pair_from_mp");
   return MG_OK;
 }
 

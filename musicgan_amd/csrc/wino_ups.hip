@@ -40,6 +40,8 @@ struct WuArgs {
   float* y;           // forward: (N, Cout, 2 Hl, 2 Wl) activation (may be NULL with PixelNorm);  dgrad: gx (N, Cout, Hl, Wl)
   float* p;           // forward + PixelNorm: normalised activation
   float* rn;          // forward + PixelNorm: (N, 1, 2 Hl, 2 Wl) 1 / norm
+  const float *hw, *hb;  // forward + PixelNorm + HEAD: the 1x1 head on the normalised activation, weights (2, Cout), bias (2) or NULL
+  float* mp;             //   its output tanh(hw p + hb), (N, 2, 2 Hl, 2 Wl)
   int N, K, Cout, Hl, Wl;  // K = channels of the kernel's input tensor
   int flags;
   float slope;
@@ -141,7 +143,7 @@ __device__ __forceinline__ void wu_load_bank(float* Us, const float* up, int n16
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int NT, bool PN>
+template <int NT, bool PN, bool HEAD>
 __global__ void __launch_bounds__(64 * WU_NWAVE, 1) winoups_fwd(const WuArgs a) {
   extern __shared__ __attribute__((aligned(16))) float Us[];
   const int tid = threadIdx.x, lane = tid & 63, col = lane & 15, rq = lane >> 4;
@@ -211,6 +213,19 @@ __global__ void __launch_bounds__(64 * WU_NWAVE, 1) winoups_fwd(const WuArgs a) 
 
   f32x4 acc[9][NT];
   const int ly = ((rq * 4) * HW + 2 * col) * 4;
+  // HEAD: the 1x1 head's weights of this lane's channels (tile t, accumulator row g <-> channel 16 t + 4 rq + g)
+  float hwv[HEAD ? 2 : 1][NT][4];
+  float hbv[2] = {0.f, 0.f};
+  if constexpr (HEAD) {
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      if (a.hb != nullptr) hbv[f] = a.hb[f];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) hwv[f][t][g] = a.hw[f * a.Cout + t * 16 + rq * 4 + g];
+    }
+  }
   int ty = w.gy * WU_NWAVE + wave;
   geometry(ty);
   load_rows(0);
@@ -295,6 +310,31 @@ __global__ void __launch_bounds__(64 * WU_NWAVE, 1) winoups_fwd(const WuArgs a) 
         float* rn = a.rn + ((size_t)en * H + 2 * ety) * W + 32 * ebx + 2 * col;
         *reinterpret_cast<float2*>(rn) = make_float2(rnv[0], rnv[1]);
         *reinterpret_cast<float2*>(rn + W) = make_float2(rnv[2], rnv[3]);
+      }
+      if constexpr (HEAD) {
+        // tanh(conv1x1(p)): the lane's channels, then the four channel groups of a pixel (lanes 16 apart) -- the sum PixelNorm took
+        float hs[2][4];
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float v = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+              for (int g = 0; g < 4; ++g) v = fmaf(hwv[f][t][g], o[t][q][g] * rnv[q], v);
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            hs[f][q] = v;
+          }
+        if (rq == 0) {
+#pragma unroll
+          for (int f = 0; f < 2; ++f) {
+            float* m = a.mp + (((size_t)en * 2 + f) * H + 2 * ety) * W + 32 * ebx + 2 * col;
+            *reinterpret_cast<float2*>(m) = make_float2(tanhf(hs[f][0] + hbv[f]), tanhf(hs[f][1] + hbv[f]));
+            *reinterpret_cast<float2*>(m + W) = make_float2(tanhf(hs[f][2] + hbv[f]), tanhf(hs[f][3] + hbv[f]));
+          }
+        }
       }
     }
     if (w.item >= w.nitems) break;
@@ -402,12 +442,12 @@ __global__ void __launch_bounds__(64 * WU_NWAVE, 1) winoups_dgrad(const WuArgs a
   }
 }
 
-template <int NT, bool PN>
+template <int NT, bool PN, bool HEAD = false>
 int wu_launch_fwd(const WuArgs& a, size_t lds, hipStream_t s) {
   static MgPerDevice once;
   if (mg_first_use_on_device(once))
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&winoups_fwd<NT, PN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL((winoups_fwd<NT, PN>), dim3(a.G), dim3(64 * WU_NWAVE), lds, s, a);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&winoups_fwd<NT, PN, HEAD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL((winoups_fwd<NT, PN, HEAD>), dim3(a.G), dim3(64 * WU_NWAVE), lds, s, a);
   MG_CHECK_LAUNCH("mg_winoups3x3");
   return MG_OK;
 }
@@ -457,6 +497,7 @@ extern "C" int mg_winoups3x3(const float* x, const float* up, const float* bias,
   MG_CHECK_ARG(pn ? (p != nullptr) : (y != nullptr), "mg_winoups3x3: no output");
   WuArgs a;
   a.x = x; a.up = up; a.bias = bias; a.y = y; a.p = p; a.rn = rn; a.flags = flags; a.slope = slope;
+  a.hw = nullptr; a.hb = nullptr; a.mp = nullptr;
   wu_fill(a, N, Cin, Cout, Hin, Win);
   const size_t lds = (size_t)a.nchunk * (Cout / 16) * 9 * 512;
   hipStream_t s = (hipStream_t)stream;
@@ -472,12 +513,37 @@ extern "C" int mg_winoups3x3(const float* x, const float* up, const float* bias,
   }
 }
 
+// (at most three out-channel tiles: with four the head's weights and sums no longer fit the register file beside 144 accumulators)
+extern "C" int mg_winoups3x3_head_supported(int N, int Cin, int Cout, int Hin, int Win) {
+  return (wu_shape_ok(N, Cin, Cout, Hin, Win) && Cout <= 48) ? 1 : 0;
+}
+
+// The same with the generator's 1x1 head on the normalised activation in the epilogue (generator.py:118-126 ToMagnPhaseLayer on the last
+// block's output): mp = tanh(hw p + hb), (N, 2, 2 Hin, 2 Win) -- the head kernel's pass over p is gone.  LeakyReLU + PixelNorm implied.
+extern "C" int mg_winoups3x3_head(const float* x, const float* up, const float* bias, float* y, float* p, float* rn, const float* hw,
+                                  const float* hb, float* mp, int N, int Cin, int Cout, int Hin, int Win, float slope, mg_stream_t stream) {
+  MG_CHECK_ARG(x && up && mg_winoups3x3_head_supported(N, Cin, Cout, Hin, Win), "mg_winoups3x3_head: unsupported shape (N=%d %d->%d %dx%d)", N, Cin, Cout, Hin, Win);
+  MG_CHECK_ARG(p && hw && mp, "mg_winoups3x3_head: p, head weights and mp are required");
+  WuArgs a;
+  a.x = x; a.up = up; a.bias = bias; a.y = y; a.p = p; a.rn = rn; a.flags = MG_CONV_LRELU | MG_CONV_PIXNORM; a.slope = slope;
+  a.hw = hw; a.hb = hb; a.mp = mp;
+  wu_fill(a, N, Cin, Cout, Hin, Win);
+  const size_t lds = (size_t)a.nchunk * (Cout / 16) * 9 * 512;
+  hipStream_t s = (hipStream_t)stream;
+  switch (Cout / 16) {
+    case 1: return wu_launch_fwd<1, true, true>(a, lds, s);
+    case 2: return wu_launch_fwd<2, true, true>(a, lds, s);
+    default: return wu_launch_fwd<3, true, true>(a, lds, s);
+  }
+}
+
 extern "C" int mg_winoups3x3_dgrad(const float* gy, const float* up, float* gx, int N, int Cin, int Cout, int Hin, int Win,
                                    mg_stream_t stream) {
   MG_CHECK_ARG(gy && up && gx && wu_shape_ok(N, Cout, Cin, Hin, Win), "mg_winoups3x3_dgrad: unsupported shape (N=%d %d<-%d %dx%d)", N, Cin,
                Cout, Hin, Win);
   WuArgs a;
   a.x = gy; a.up = up; a.bias = nullptr; a.y = gx; a.p = nullptr; a.rn = nullptr; a.flags = 0; a.slope = 1.0f;
+  a.hw = nullptr; a.hb = nullptr; a.mp = nullptr;
   wu_fill(a, N, Cout, Cin, Hin, Win);
   const size_t lds = (size_t)a.nchunk * (Cin / 16) * 9 * 512;
   hipStream_t s = (hipStream_t)stream;

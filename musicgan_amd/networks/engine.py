@@ -153,14 +153,18 @@ class PackCache:
             return ops.conv3x3_small(gy, self.get_sn(w, True), None, cout, upsum=True, want_y=False)[1]
         return ops.upsample2x_bwd(self.conv(gy, w, True, None, cout))
 
-    def conv_lrelu_pixnorm(self, x: torch.Tensor, w: torch.Tensor, bias, cout: int, ups: bool = False):
+    def conv_lrelu_pixnorm(self, x: torch.Tensor, w: torch.Tensor, bias, cout: int, ups: bool = False, head=None):
         """conv3x3 (+ nearest x2 up-sampling of its input) + LeakyReLU + PixelNorm -> (p, 1/norm).  The fused kernels keep all
         output channels of a pixel in one wave, so the grid is output pixels / 64 workgroups; on the small maps at the start of the
         generator that is 8 .. 128 workgroups for 256 CUs, each walking all of Cin x 9 taps x Cout alone (60-80 us for 0.1-1.4
         GFLOP).  There the convolution runs sliced over out-channels (many short workgroups) and PixelNorm as its own pass over
-        the (tiny) result."""
+        the (tiny) result.  `head` = [hw, hb, mp_out or None, None]: where the conv runs as the 9-component up-sampling kernel the
+        generator's 1x1 head is computed in its epilogue and head[3] receives tanh(hw p + hb); elsewhere head[3] stays None."""
         n, cin, h, wd = x.shape
         form = gen_conv_form(n, cin, cout, h, wd, ups)
+        if head is not None and form == "subpixel-fused" and ops.winoups3x3_head_supported(n, cin, cout, h, wd) and ops.fuse_ends():
+            _, p, rn, head[3] = ops.winoups3x3_head(x, self.get_wu(w, False), bias, cout, head[0], head[1], mp_out=head[2])
+            return p, rn
         if form == "upsample+wino+pixnorm":
             # an under-filled sub-pixel launch (one 4-wave workgroup per 64 low-res pixels, all channels in a wave): the up-sampled
             # tensor written out once + the Winograd conv sliced over out-channels + PixelNorm as its own pass fill the chip
@@ -340,6 +344,8 @@ class GenWeights:
 def gen_forward(W: GenWeights, z: torch.Tensor, alpha: float, cache: PackCache, save: bool, out=None):
     x = z.contiguous()
     saved = []
+    # the 1x1 head in the last conv's epilogue where that conv is the 9-component up-sampling kernel: [hw, hb, mp buffer, result]
+    head_req = [W.head[0], W.head[1], out if W.old_head is None else None, None] if W.head[0].shape[0] == 2 else None
     head = gen_head_ok(W, x)
     if head:
         # block 0 and the first conv of block 1 in one launch (activations in LDS); only what the backward pass needs is stored
@@ -382,7 +388,7 @@ def gen_forward(W: GenWeights, z: torch.Tensor, alpha: float, cache: PackCache, 
             if gen_conv_form(n_, ci_, cout, h_, w_, ups) == "conv+pixnorm" and PackCache.small_ok(cur, cout, ups=ups, lrelu=True):
                 raw = cache.conv(cur, w, False, b, cout, ups=ups, lrelu=True)  # its PixelNorm: by the next conv, or below
             else:
-                cur, rn_k = cache.conv_lrelu_pixnorm(cur, w, b, cout, ups=ups)
+                cur, rn_k = cache.conv_lrelu_pixnorm(cur, w, b, cout, ups=ups, head=head_req if k == len(convs) - 1 else None)
                 pr[k] = (cur, rn_k)
         if raw is not None:
             cur, rn_k = ops.pixelnorm_fwd(raw)
@@ -409,12 +415,19 @@ def gen_forward(W: GenWeights, z: torch.Tensor, alpha: float, cache: PackCache, 
             p1, rn1 = p1b, rn1b
         else:
             p1, rn1 = cache.conv_lrelu_pixnorm(x, w1, b1, ci)
-        p2, rn2 = cache.conv_lrelu_pixnorm(p1, w2, b2, co, ups=True)
+        p2, rn2 = cache.conv_lrelu_pixnorm(p1, w2, b2, co, ups=True, head=head_req if bi == len(W.blocks) - 1 else None)
         if save:
             saved.append((x, rn1, p1, rn2, p2))
         x_in_last, x = x, p2
     old = None
-    if W.old_head is not None:
+    mp_epi = head_req[3] if head_req is not None else None
+    if mp_epi is not None and W.old_head is None:
+        out = mp = mp_epi
+    elif mp_epi is not None and ops.head_pair_supported(x.shape[1], x_in_last.shape[1], x.shape[2], x.shape[3]):
+        F = FadeIn.of(alpha)
+        mp = mp_epi
+        out, old = ops.head_pair_from_mp(mp, x_in_last, W.old_head[0], W.old_head[1], F.a, F.b, coef=F.dev, save=save, out=out)
+    elif W.old_head is not None:
         F = FadeIn.of(alpha)
         if ops.head_pair_supported(x.shape[1], x_in_last.shape[1], x.shape[2], x.shape[3]):
             # both heads, the up-sampling of the old one and the blend in one launch

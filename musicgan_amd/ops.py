@@ -293,6 +293,32 @@ def winoups3x3(x, up, bias, cout: int, *, lrelu=False, pixnorm=False, want_y=Tru
     return (y, p, rn) if pixnorm else y
 
 
+def _head_fuse(bit: int) -> bool:
+    """MG_HEAD_FUSE (default 3): bit 0 = the generator head's backward with the PixelNorm backward in front of it in one launch, bit 1 =
+    the head's forward in the last conv's epilogue (A/B switch)."""
+    return (int(os.environ.get("MG_HEAD_FUSE", "3")) & bit) != 0
+
+
+def winoups3x3_head_supported(n: int, cin: int, cout: int, hin: int, win: int) -> bool:
+    return _head_fuse(2) and winoups3x3_supported(n, cin, cout, hin, win) and bool(_lib.load().mg_winoups3x3_head_supported(n, cin, cout, hin, win))
+
+
+def winoups3x3_head(x, up, bias, cout: int, hw, hb, *, want_y=False, mp_out=None):
+    """winoups3x3(lrelu, pixnorm) with the generator's 1x1 head on the normalised activation in the epilogue: returns (y, p, rn, mp),
+    mp = tanh(hw p + hb) of shape (N, 2, 2H, 2W) (written into `mp_out` if given)."""
+    _chk(x, up, bias, hw, hb, mp_out)
+    n, cin, hin, win = x.shape
+    h, w = 2 * hin, 2 * win
+    assert hw.shape[0] == 2 and hw.shape[1] == cout
+    new = lambda c: torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    y = new(cout) if want_y else None
+    p, rn = new(cout), new(1)
+    mp = new(2) if mp_out is None else mp_out
+    check(_lib.load().mg_winoups3x3_head(_p(x), _p(up), _p(bias), _p(y), _p(p), _p(rn), _p(hw), _p(hb), _p(mp), n, cin, cout, hin, win,
+                                         SLOPE, _s()), "mg_winoups3x3_head")
+    return y, p, rn, mp
+
+
 def winoups3x3_dgrad(gy, up, cin: int):
     """Gradient of Upsample(x2) -> Conv3x3 w.r.t. its low-resolution input in 9-component Winograd form: (N,Cout,2H,2W) -> (N,Cin,H,W)."""
     _chk(gy, up)
@@ -690,6 +716,20 @@ def head_pair(x, wh, bh, xl, wo, bo, a: float, b: float, *, coef=None, save=True
     return out, mp, old
 
 
+def head_pair_from_mp(mp, xl, wo, bo, a: float, b: float, *, coef=None, save=True, out=None):
+    """head_pair when the new head's values mp are already there (winoups3x3_head): returns (out, old)."""
+    _chk(mp, xl, wo, bo, coef, out)
+    n, _, h, w = mp.shape
+    cl = xl.shape[1]
+    assert xl.shape[0] == n and xl.shape[2] == h // 2 and xl.shape[3] == w // 2
+    new = lambda hh, ww: torch.empty((n, 2, hh, ww), dtype=torch.float32, device=mp.device)
+    old = new(h // 2, w // 2) if save else None
+    out = new(h, w) if out is None else out
+    check(_lib.load().mg_head_pair_from_mp(_p(mp), _p(xl), _p(wo), _p(bo), _p(coef), float(a), float(b), _p(old), _p(out), n, cl, h, w,
+                                           _s()), "mg_head_pair_from_mp")
+    return out, old
+
+
 def blend_up_bwd(g, a: float, b: float, coef=None):
     """(a g, b * 2x2 block sums of g): backward of blend_up."""
     _chk(g, coef)
@@ -702,7 +742,7 @@ def blend_up_bwd(g, a: float, b: float, coef=None):
 
 def gen_head_bwd_supported(c: int, cout: int = 2) -> bool:
     """The generator head's backward + the PixelNorm / LeakyReLU backward in front of it as one launch (MG_FUSE_ENDS=0: never)."""
-    return fuse_ends() and bool(_lib.load().mg_gen_head_bwd_supported(int(c), int(cout)))
+    return fuse_ends() and _head_fuse(1) and bool(_lib.load().mg_gen_head_bwd_supported(int(c), int(cout)))
 
 
 def gen_head_bwd(g_mp, mp, w, p, rn, gw, gb, *, accumulate=False, slope: float = SLOPE):

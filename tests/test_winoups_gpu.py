@@ -80,3 +80,40 @@ def test_unsupported_shapes_are_refused():
     assert not ops.winoups3x3_supported(2, 64, 48, 4, 16)           # fewer than 8 low-res rows
     with pytest.raises(Exception, match="unsupported shape"):
         ops.winoups3x3(torch.randn(2, 64, 16, 8, device=DEV), torch.empty(8, device=DEV), None, 48)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 48, 16, 16), (1, 48, 32, 8, 32), (3, 32, 16, 8, 16), (2, 16, 48, 8, 16)])
+def test_forward_with_the_head_in_the_epilogue(shape):
+    """mg_winoups3x3_head: p, rn as mg_winoups3x3's (same bits) and mp = tanh(conv1x1(p)) against the 1x1 kernel on that p and against
+    fp64 (generator.py:118-126 on the block output of :24-39); then the old head + blend from the given mp against mg_head_pair."""
+    ops = _ops()
+    n, ci, co, h, w = shape
+    assert ops.winoups3x3_head_supported(n, ci, co, h, w) and not ops.winoups3x3_head_supported(n, 16, 64, h, w)
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(9 * ci)
+    b = torch.randn(co, generator=g) * 0.1
+    hw = torch.randn(2, co, 1, 1, generator=g) / math.sqrt(co)
+    hb = torch.randn(2, generator=g) * 0.1
+    xd, bd, hwd, hbd = x.to(DEV), b.to(DEV), hw.to(DEV), hb.to(DEV)
+    up = ops.pack_winoups3x3(wt.to(DEV), False)
+    _, p0, rn0 = ops.winoups3x3(xd, up, bd, co, lrelu=True, pixnorm=True, want_y=False)
+    y1, p1, rn1, mp = ops.winoups3x3_head(xd, up, bd, co, hwd, hbd, want_y=True)
+    assert torch.equal(p0, p1) and torch.equal(rn0, rn1) and y1 is not None
+    ref_k = ops.conv1x1(p0, hwd, hbd, 2, tanh=True)
+    assert float((mp - ref_k).abs().max()) <= 2e-6
+    ref = torch.tanh(F.conv2d(p0.double().cpu(), hw.double(), hb.double()))
+    assert float((mp.double().cpu() - ref).abs().max()) <= 2e-6
+    mp2 = torch.empty_like(mp)
+    _, _, _, mp3 = ops.winoups3x3_head(xd, up, bd, co, hwd, None, mp_out=mp2)
+    assert mp3 is mp2 and float((mp2 - ops.conv1x1(p0, hwd, None, 2, tanh=True)).abs().max()) <= 2e-6
+    # the fade-in pair from the given mp
+    cl = 24
+    xl = torch.randn(n, cl, h, w, generator=g).to(DEV)
+    wo, bo = (torch.randn(2, cl, 1, 1, generator=g) / math.sqrt(cl)).to(DEV), (torch.randn(2, generator=g) * 0.1).to(DEV)
+    coef = torch.tensor([0.3, 0.7], device=DEV)
+    out0, mp0, old0 = ops.head_pair(p0, hwd, hbd, xl, wo, bo, 0.3, 0.7, coef=coef)
+    out1, old1 = ops.head_pair_from_mp(mp0, xl, wo, bo, 0.3, 0.7, coef=coef)
+    assert torch.equal(out0, out1) and torch.equal(old0, old1)
+    out2, old2 = ops.head_pair_from_mp(mp0, xl, wo, bo, 0.3, 0.7, save=False)
+    assert old2 is None and float((out2 - out0).abs().max()) <= 1e-6
