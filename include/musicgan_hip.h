@@ -219,7 +219,9 @@ int mg_conv1x1_wgrad(const float* x, const float* gy, const float* tanh_y, float
  *   gradient g_mp (N,2,H,W) at the head's tanh output mp: t = g_mp (1 - mp^2); gw (2,C) (+)= sum t p, gb (2) (+)= sum t (autograd's
  *   convolution_backward of the 1x1 head, x = p (N,C,H,W) the last block's PixelNorm output); g = w^T t; gpre = lrelu'(p) rn
  *   (g - p mean_c(g p)) (N,C,H,W) = the gradient at the last conv's pre-activation (PixelNorm + LeakyReLU backward, rn (N,1,H,W) the
- *   stored 1/norm).  One read of p, one write of gpre.  C in {16, 32, 48, 64}; ws: mg_gen_head_bwd_ws_floats(N, C, HW) floats. */
+ *   stored 1/norm).  One read of p, one write of gpre.  g_in (optional, (N,C,H,W)): a second gradient arriving at p, added to g (the old
+ *   head of a fading-in level: p is also the input of the last block's first conv, g_in that conv's data gradient).
+ *   C in {16, 32, 48, 64}; ws: mg_gen_head_bwd_ws_floats(N, C, HW) floats. */
 int mg_stem_pair(const float* x, const float* ws, const float* bs, const float* wo, const float* bo, float* h0, float* xp, float* o,
                  unsigned char* h0_mask, int N, int C0, int C1, int H, int W, int flags, float slope, mg_stream_t stream);
 int mg_stem_pair_gx(const float* gs, const float* ws, const float* go, const float* wo, float* gx, int N, int C0, int C1, int H, int W,
@@ -233,8 +235,8 @@ int mg_head_pair_from_mp(const float* mp, const float* xl, const float* wo, cons
                          float* old, float* out, int N, int Cl, int H, int W, mg_stream_t stream);
 int mg_gen_head_bwd_supported(int C, int Cout);
 size_t mg_gen_head_bwd_ws_floats(int N, int C, int HW);
-int mg_gen_head_bwd(const float* g_mp, const float* mp, const float* w, const float* p, const float* rn, float* gpre, float* gw, float* gb,
-                    float* ws, size_t ws_floats, int N, int C, int HW, float slope, int accumulate, mg_stream_t stream);
+int mg_gen_head_bwd(const float* g_mp, const float* mp, const float* w, const float* p, const float* rn, const float* g_in, float* gpre,
+                    float* gw, float* gb, float* ws, size_t ws_floats, int N, int C, int HW, float slope, int accumulate, mg_stream_t stream);
 
 /* ------------------------------------------------------------------ element-wise / small ops */
 /* PixelNorm forward [layers.py:11-17]: p = y*rn, rn[n,hw] = 1/sqrt(mean_c y^2 + 1e-8) */

@@ -132,7 +132,7 @@ SIGNATURES = {
     "mg_head_pair_from_mp": (c_int, [_P] * 5 + [c_float, c_float, _P, _P] + [c_int] * 4 + [_P]),
     "mg_gen_head_bwd_supported": (c_int, [c_int, c_int]),
     "mg_gen_head_bwd_ws_floats": (c_size_t, [c_int, c_int, c_int]),
-    "mg_gen_head_bwd": (c_int, [_P] * 9 + [c_size_t, c_int, c_int, c_int, c_float, c_int, _P]),
+    "mg_gen_head_bwd": (c_int, [_P] * 10 + [c_size_t, c_int, c_int, c_int, c_float, c_int, _P]),
     "mg_channel_sum": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "mg_adam_step": (c_int, [_P, c_int, c_float, c_float, c_float, c_float, _P]),
     "mg_group_means": (c_int, [_P, c_int, c_int, _P, _P]),

@@ -293,17 +293,23 @@ int grid_for(size_t items, int per_block, int cap) {
 // -- three launches that read p twice and wrote / re-read the C-channel g (5 tensor passes) -- as one read of p and one write of gpre.
 // One pixel per thread and turn; the pixel's C values of p wait in LDS between the two sweeps (a thread reads back its own column only:
 // no barrier); the 2 C weight-gradient sums stay in registers over the thread's pixels and are reduced once per workgroup.
-template <int C>
-__global__ void __launch_bounds__(256) gen_head_bwd_k(const float* __restrict__ gm, const float* __restrict__ mp, const float* __restrict__ w,
-                                                      const float* __restrict__ p, const float* __restrict__ rn, float* __restrict__ gpre,
-                                                      float* __restrict__ part, int N, int HW, float slope) {
-  extern __shared__ __attribute__((aligned(16))) float park[];  // [C][256], then (reduction) [4][2 C + 2]
+// GIN: a second gradient arriving at p (the data gradient of the conv that reads p; the OLD head of a fading-in level sits on the input
+// of the last block, which that block's first conv reads too) is added to the head's: g[c] = gin[c] + w^T t; the second sweep reads gin
+// again (the workgroup's own lines, minutes of L2 residency ago) rather than parking it beside p (twice the LDS, half the waves).
+// Channels go in groups of 16 (a scheduling fence between groups): all C loads of a pixel in flight at once cost C registers on top of
+// the 2 C sums and left one wave per SIMD at C = 64.
+template <int C, int NT, bool GIN>
+__global__ void __launch_bounds__(NT) gen_head_bwd_k(const float* __restrict__ gm, const float* __restrict__ mp, const float* __restrict__ w,
+                                                     const float* __restrict__ p, const float* __restrict__ rn, const float* __restrict__ gin,
+                                                     float* __restrict__ gpre, float* __restrict__ part, int N, int HW, float slope) {
+  extern __shared__ __attribute__((aligned(16))) float park[];  // [C][NT], then (reduction) [NT / 64][2 C + 2]
+  constexpr int GS = 16;  // channels per group
   const int tid = threadIdx.x;
   float s0[C], s1[C], sb0 = 0.f, sb1 = 0.f;
 #pragma unroll
   for (int c = 0; c < C; ++c) s0[c] = s1[c] = 0.f;
-  const size_t total = (size_t)N * HW, stride = (size_t)gridDim.x * 256;
-  for (size_t i = (size_t)blockIdx.x * 256 + tid; i < total; i += stride) {
+  const size_t total = (size_t)N * HW, stride = (size_t)gridDim.x * NT;
+  for (size_t i = (size_t)blockIdx.x * NT + tid; i < total; i += stride) {
     const int n = (int)(i / HW);
     const int px = (int)(i - (size_t)n * HW);
     const size_t fb = (size_t)n * 2 * HW + px, base = (size_t)n * C * HW + px;
@@ -314,20 +320,46 @@ __global__ void __launch_bounds__(256) gen_head_bwd_k(const float* __restrict__ 
     sb1 += t1;
     float dot = 0.f;
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const float t = p[base + (size_t)c * HW];
-      park[c * 256 + tid] = t;
-      const float g = fmaf(w[C + c], t1, w[c] * t0);
-      dot = fmaf(g, t, dot);
-      s0[c] = fmaf(t0, t, s0[c]);
-      s1[c] = fmaf(t1, t, s1[c]);
+    for (int c0 = 0; c0 < C; c0 += GS) {
+      float tv[GS], gv[GIN ? GS : 1];
+#pragma unroll
+      for (int u = 0; u < GS; ++u) {
+        tv[u] = p[base + (size_t)(c0 + u) * HW];
+        if constexpr (GIN) gv[u] = gin[base + (size_t)(c0 + u) * HW];
+      }
+#pragma unroll
+      for (int u = 0; u < GS; ++u) {
+        const int c = c0 + u;
+        const float t = tv[u];
+        park[c * NT + tid] = t;
+        float g = fmaf(w[C + c], t1, w[c] * t0);
+        if constexpr (GIN) g += gv[u];
+        dot = fmaf(g, t, dot);
+        s0[c] = fmaf(t0, t, s0[c]);
+        s1[c] = fmaf(t1, t, s1[c]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     dot /= (float)C;
+    // (an opaque copy of the pointer: hipcc would otherwise keep the first sweep's C values of gin in registers for this one)
+    const float* gin2 = gin;
+    if constexpr (GIN) asm volatile("" : "+s"(gin2));
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const float t = park[c * 256 + tid];
-      const float g = fmaf(w[C + c], t1, w[c] * t0);
-      gpre[base + (size_t)c * HW] = mg_lrelu_mask(t, slope) * r * (g - t * dot);
+    for (int c0 = 0; c0 < C; c0 += GS) {
+      float gv[GIN ? GS : 1];
+      if constexpr (GIN) {
+#pragma unroll
+        for (int u = 0; u < GS; ++u) gv[u] = gin2[base + (size_t)(c0 + u) * HW];
+      }
+#pragma unroll
+      for (int u = 0; u < GS; ++u) {
+        const int c = c0 + u;
+        const float t = park[c * NT + tid];
+        float g = fmaf(w[C + c], t1, w[c] * t0);
+        if constexpr (GIN) g += gv[u];
+        gpre[base + (size_t)c * HW] = mg_lrelu_mask(t, slope) * r * (g - t * dot);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   // the workgroup's sums: wave totals by DPP, the four waves through LDS, one row of 2 C + 2 partials per workgroup
@@ -351,7 +383,12 @@ __global__ void __launch_bounds__(256) gen_head_bwd_k(const float* __restrict__ 
     }
   }
   __syncthreads();
-  if (tid < PER) part[(size_t)blockIdx.x * PER + tid] = (red[tid] + red[PER + tid]) + (red[2 * PER + tid] + red[3 * PER + tid]);
+  for (int e = tid; e < PER; e += NT) {
+    float v = red[e];
+#pragma unroll
+    for (int wv = 1; wv < NT / 64; ++wv) v += red[wv * PER + e];
+    part[(size_t)blockIdx.x * PER + e] = v;
+  }
 }
 
 // gw (2, C) and gb (2) from the per-workgroup partials: one wave per output, lanes stride over the workgroups, a fixed shuffle tree
@@ -370,24 +407,32 @@ __global__ void __launch_bounds__(256) gen_head_bwd_final_k(const float* __restr
   }
 }
 
-template <int C>
-int gen_head_bwd_launch(const float* gm, const float* mp, const float* w, const float* p, const float* rn, float* gpre, float* part, int G,
-                        int N, int HW, float slope, hipStream_t s) {
+template <int C, int NT, bool GIN>
+int gen_head_bwd_launch_v(const float* gm, const float* mp, const float* w, const float* p, const float* rn, const float* gin, float* gpre,
+                          float* part, int G, int N, int HW, float slope, hipStream_t s) {
   static MgPerDevice once;
   if (mg_first_use_on_device(once))
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_head_bwd_k<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(gen_head_bwd_k<C>, dim3(G), dim3(256), (size_t)C * 256 * sizeof(float), s, gm, mp, w, p, rn, gpre, part, N, HW, slope);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_head_bwd_k<C, NT, GIN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+  hipLaunchKernelGGL((gen_head_bwd_k<C, NT, GIN>), dim3(G), dim3(NT), (size_t)C * NT * sizeof(float), s, gm, mp, w, p, rn, gin,
+                     gpre, part, N, HW, slope);
   MG_CHECK_LAUNCH("mg_gen_head_bwd");
   return MG_OK;
 }
+template <int C>
+int gen_head_bwd_launch(const float* gm, const float* mp, const float* w, const float* p, const float* rn, const float* gin, float* gpre,
+                        float* part, int G, int N, int HW, float slope, hipStream_t s) {
+  if (gin != nullptr) return gen_head_bwd_launch_v<C, 256, true>(gm, mp, w, p, rn, gin, gpre, part, G, N, HW, slope, s);
+  return gen_head_bwd_launch_v<C, 256, false>(gm, mp, w, p, rn, nullptr, gpre, part, G, N, HW, slope, s);
+}
 
-// workgroups: as many as fit the chip at once (LDS: C KB each), never more than there are 256-pixel groups
-int gen_head_bwd_grid(int C, size_t pixels) {
+// workgroups: as many as fit the chip at once (LDS: C KB each), never more than there are pixel groups
+int gen_head_bwd_grid(int C, size_t pixels, bool) {
   int per_cu = (160 * 1024) / (C * 1024);
   if (per_cu > 8) per_cu = 8;
   if (per_cu < 1) per_cu = 1;
   size_t g = (size_t)per_cu * mg_cu_count();
-  const size_t need = (pixels + 255) / 256;
+  const size_t nt = 256, need = (pixels + nt - 1) / nt;
   if (g > need) g = need;
   return (int)(g < 1 ? 1 : g);
 }
@@ -475,23 +520,23 @@ extern "C" int mg_blend_up_bwd(const float* g, const float* coef, float ca, floa
 extern "C" int mg_gen_head_bwd_supported(int C, int Cout) { return (Cout == 2 && (C == 16 || C == 32 || C == 48 || C == 64)) ? 1 : 0; }
 
 extern "C" size_t mg_gen_head_bwd_ws_floats(int N, int C, int HW) {
-  return (size_t)gen_head_bwd_grid(C, (size_t)N * HW) * (2 * C + 2);
+  return (size_t)gen_head_bwd_grid(C, (size_t)N * HW, true) * (2 * C + 2);  // (the larger of the two forms' grids)
 }
 
-extern "C" int mg_gen_head_bwd(const float* g_mp, const float* mp, const float* w, const float* p, const float* rn, float* gpre, float* gw,
-                               float* gb, float* ws, size_t ws_floats, int N, int C, int HW, float slope, int accumulate,
-                               mg_stream_t stream) {
+extern "C" int mg_gen_head_bwd(const float* g_mp, const float* mp, const float* w, const float* p, const float* rn, const float* g_in,
+                               float* gpre, float* gw, float* gb, float* ws, size_t ws_floats, int N, int C, int HW, float slope,
+                               int accumulate, mg_stream_t stream) {
   MG_CHECK_ARG(g_mp && mp && w && p && rn && gpre && gw && gb && ws && N > 0 && HW > 0, "mg_gen_head_bwd: bad arguments");
   MG_CHECK_ARG(mg_gen_head_bwd_supported(C, 2), "mg_gen_head_bwd: C = %d (16, 32, 48 or 64)", C);
-  const int G = gen_head_bwd_grid(C, (size_t)N * HW);
+  const int G = gen_head_bwd_grid(C, (size_t)N * HW, g_in != nullptr);
   MG_CHECK_ARG(ws_floats >= (size_t)G * (2 * C + 2), "mg_gen_head_bwd: workspace of %zu floats, needs %zu", ws_floats, (size_t)G * (2 * C + 2));
   hipStream_t s = (hipStream_t)stream;
   int rc;
   switch (C) {
-    case 16: rc = gen_head_bwd_launch<16>(g_mp, mp, w, p, rn, gpre, ws, G, N, HW, slope, s); break;
-    case 32: rc = gen_head_bwd_launch<32>(g_mp, mp, w, p, rn, gpre, ws, G, N, HW, slope, s); break;
-    case 48: rc = gen_head_bwd_launch<48>(g_mp, mp, w, p, rn, gpre, ws, G, N, HW, slope, s); break;
-    default: rc = gen_head_bwd_launch<64>(g_mp, mp, w, p, rn, gpre, ws, G, N, HW, slope, s); break;
+    case 16: rc = gen_head_bwd_launch<16>(g_mp, mp, w, p, rn, g_in, gpre, ws, G, N, HW, slope, s); break;
+    case 32: rc = gen_head_bwd_launch<32>(g_mp, mp, w, p, rn, g_in, gpre, ws, G, N, HW, slope, s); break;
+    case 48: rc = gen_head_bwd_launch<48>(g_mp, mp, w, p, rn, g_in, gpre, ws, G, N, HW, slope, s); break;
+    default: rc = gen_head_bwd_launch<64>(g_mp, mp, w, p, rn, g_in, gpre, ws, G, N, HW, slope, s); break;
   }
   if (rc != MG_OK) return rc;
   hipLaunchKernelGGL(gen_head_bwd_final_k, dim3((2 * C + 2 + 3) / 4), dim3(256), 0, s, ws, G, C, gw, gb, accumulate);

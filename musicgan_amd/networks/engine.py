@@ -469,11 +469,21 @@ def gen_backward(W: GenWeights, ctx, g_out: torch.Tensor, cache: PackCache, sink
         ops.conv1x1_wgrad(x_last, g_mp, gw, gb, tanh_y=mp, accumulate=acc)
         g = ops.conv1x1(g_mp, W.head[0], None, x_last.shape[1], transposed=True, tanh_bwd_in=mp)
     gz = None
+    old_pending = None
     for i in range(last, -1, -1):
         w1, b1, w2, b2 = W.blocks[i]
         xin, rn1, p1, rn2, p2 = saved[i]
         ci = w1.shape[0]
-        gpre2 = gpre_head if (i == last and gpre_head is not None) else ops.pixelnorm_lrelu_bwd(g, p2, rn2, from_p=True)
+        if i == last and gpre_head is not None:
+            gpre2 = gpre_head
+        elif old_pending is not None:
+            # the old head's weight / data gradient joins the conv's data gradient g inside the PixelNorm backward's pass over p2
+            gwo, acc = sink.slot(W.old_head[0])
+            gbo, _ = sink.slot(W.old_head[1])
+            gpre2 = ops.gen_head_bwd(g_old, old, W.old_head[0], p2, rn2, gwo, gbo, accumulate=acc, g_in=g)
+            old_pending = None
+        else:
+            gpre2 = ops.pixelnorm_lrelu_bwd(g, p2, rn2, from_p=True)
         gw2, acc = sink.slot(w2)
         gb2, _ = sink.slot(b2)
         ops.conv3x3_wgrad(p1, gpre2, gw2, gb2, ups=True, accumulate=acc, defer=defer)
@@ -514,7 +524,10 @@ def gen_backward(W: GenWeights, ctx, g_out: torch.Tensor, cache: PackCache, sink
         ops.conv3x3_wgrad(xin, gpre1, gw1, gb1, accumulate=acc, defer=defer)
         if i > 0:
             g = cache.conv(gpre1, w1, True, None, ci)
-            if g_old is not None and i == last:
+            if g_old is not None and i == last and ops.gen_head_bwd_supported(xin.shape[1], W.old_head[0].shape[0]) \
+                    and saved[last - 1][4] is xin:
+                old_pending = True  # (handled at the top of the next turn)
+            elif g_old is not None and i == last:
                 gwo, acc = sink.slot(W.old_head[0])
                 gbo, _ = sink.slot(W.old_head[1])
                 ops.conv1x1_wgrad(xin, g_old, gwo, gbo, tanh_y=old, accumulate=acc)

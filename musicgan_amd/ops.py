@@ -745,18 +745,19 @@ def gen_head_bwd_supported(c: int, cout: int = 2) -> bool:
     return fuse_ends() and _head_fuse(1) and bool(_lib.load().mg_gen_head_bwd_supported(int(c), int(cout)))
 
 
-def gen_head_bwd(g_mp, mp, w, p, rn, gw, gb, *, accumulate=False, slope: float = SLOPE):
+def gen_head_bwd(g_mp, mp, w, p, rn, gw, gb, *, accumulate=False, slope: float = SLOPE, g_in=None):
     """gw (2,C) (+)= sum t p, gb (2) (+)= sum t with t = g_mp (1 - mp^2); returns the gradient at the pre-activation of the conv whose
     LeakyReLU + PixelNorm output is p (rn: its stored 1/norm): what conv1x1_wgrad(tanh_y=) + conv1x1(transposed, tanh_bwd_in=) +
-    pixelnorm_lrelu_bwd(from_p=True) return, in one pass over p."""
-    _chk(g_mp, mp, w, p, rn, gw, gb)
+    pixelnorm_lrelu_bwd(from_p=True) return, in one pass over p.  `g_in`: a second gradient at p, added to the head's."""
+    _chk(g_mp, mp, w, p, rn, gw, gb, g_in)
+    assert g_in is None or g_in.shape == p.shape
     n, c, h, wd = p.shape
     assert g_mp.shape == (n, 2, h, wd) and mp.shape == g_mp.shape and w.shape[0] == 2 and w.shape[1] == c
     lib = _lib.load()
     nfl = lib.mg_gen_head_bwd_ws_floats(n, c, h * wd)
     ws = workspace(4 * nfl, p.device)
     out = torch.empty_like(p)
-    check(lib.mg_gen_head_bwd(_p(g_mp), _p(mp), _p(w), _p(p), _p(rn), _p(out), _p(gw), _p(gb), _p(ws), ws.numel() // 4, n, c, h * wd,
+    check(lib.mg_gen_head_bwd(_p(g_mp), _p(mp), _p(w), _p(p), _p(rn), _p(g_in), _p(out), _p(gw), _p(gb), _p(ws), ws.numel() // 4, n, c, h * wd,
                               float(slope), int(accumulate), _s()), "mg_gen_head_bwd")
     return out
 

@@ -210,3 +210,9 @@ def test_gen_head_bwd_matches_the_three_launches_and_autograd(shape):
     gpre2 = ops.gen_head_bwd(gd, mpd, wd, pd, rn, gw, gb, accumulate=True)
     assert torch.equal(gpre, gpre2) and rel(gw, 2 * wt.grad) <= 5e-6 and rel(gb, 2 * bt.grad) <= 5e-6
     assert not ops.gen_head_bwd_supported(40) and not ops.gen_head_bwd_supported(48, 3)
+    # a second gradient arriving at p (the old head of a fading-in level)
+    g_in = torch.randn(n, c, h, w, generator=g).to(DEV)
+    gw3, gb3 = torch.empty_like(gw), torch.empty_like(gb)
+    gpre3 = ops.gen_head_bwd(gd, mpd, wd, pd, rn, gw3, gb3, g_in=g_in)
+    ref3 = ops.pixelnorm_lrelu_bwd(g0 + g_in, pd, rn, from_p=True)
+    assert rel(gpre3, ref3.double().cpu()) <= 2e-6 and rel(gw3, gw0.double().cpu()) <= 2e-6 and rel(gb3, gb0.double().cpu()) <= 2e-6

@@ -59,3 +59,19 @@ for (n, c, hw) in [(64, 48, 128), (6, 32, 256), (6, 16, 512), (16, 16, 512), (32
     row(f"head backward, three launches {n}x{c}@{hw}", timeit(three), (5 * p.numel()) * 4)
     if ops.gen_head_bwd_supported(c):
         row(f"head backward, fused {n}x{c}@{hw}", timeit(lambda: ops.gen_head_bwd(gm, mp, w, p, rn, gw, gb)), (2 * p.numel()) * 4)
+# the old head of a fading-in level: 1x1 weight gradient + transposed 1x1 accumulated into the conv's data gradient + PixelNorm backward,
+# against the fused launch with that data gradient as second input
+for (n, c, hw) in [(64, 64, 64), (6, 48, 128), (6, 32, 256)]:
+    p, gm, mp, gin = R(n, c, hw, hw), R(n, 2, hw, hw), torch.tanh(R(n, 2, hw, hw)), R(n, c, hw, hw)
+    rn = torch.rand(n, 1, hw, hw, device=dev, generator=g) + 0.5
+    w = R(2, c, 1, 1) * 0.1
+    gw, gb = torch.empty(2, c, 1, 1, device=dev), torch.empty(2, device=dev)
+    gacc = gin.clone()
+
+    def three_old():
+        ops.conv1x1_wgrad(p, gm, gw, gb, tanh_y=mp)
+        ops.conv1x1(gm, w, None, c, transposed=True, tanh_bwd_in=mp, out=gacc, accumulate=True)
+        return ops.pixelnorm_lrelu_bwd(gacc, p, rn, from_p=True)
+
+    row(f"old head backward, three launches {n}x{c}@{hw}", timeit(three_old), (5 * p.numel()) * 4)
+    row(f"old head backward, fused {n}x{c}@{hw}", timeit(lambda: ops.gen_head_bwd(gm, mp, w, p, rn, gw, gb, g_in=gin)), (3 * p.numel()) * 4)
