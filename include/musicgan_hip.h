@@ -80,6 +80,10 @@ size_t mg_winoups3x3_packed_floats(int Cin, int Cout, int dgrad);
 int mg_winoups3x3(const float* x, const float* up, const float* bias, float* y, float* p, float* rn, int N, int Cin, int Cout,
                   int Hin, int Win, int flags, float slope, mg_stream_t stream);
 int mg_winoups3x3_dgrad(const float* gy, const float* up, float* gx, int N, int Cin, int Cout, int Hin, int Win, mg_stream_t stream);
+/* mg_winoups3x3_dgrad with the PixelNorm + LeakyReLU backward of the layer below [generator.py:31-39, layers.py:11-17] in the epilogue:
+ * p (N,Cin,Hin,Win) that layer's normalised output, rn (N,1,Hin,Win) its 1/norm; gpre = lrelu'(p) rn (gx - p mean_c(gx p)). */
+int mg_winoups3x3_dgrad_pn(const float* gy, const float* up, const float* p, const float* rn, float* gpre, int N, int Cin, int Cout, int Hin,
+                           int Win, float slope, mg_stream_t stream);
 /* mg_winoups3x3 (LeakyReLU + PixelNorm) with the generator's 1x1 head [generator.py:118-126 ToMagnPhaseLayer] on the normalised
  * activation in the same epilogue: mp = tanh(hw p + hb), hw (2,Cout), hb (2) or NULL, mp (N,2,2Hin,2Win); p, rn as above, y optional. */
 int mg_winoups3x3_head_supported(int N, int Cin, int Cout, int Hin, int Win); /* mg_winoups3x3_supported and at most 48 out-channels */

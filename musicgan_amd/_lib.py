@@ -76,6 +76,7 @@ SIGNATURES = {
     "mg_winoups3x3_packed_floats": (c_size_t, [c_int, c_int, c_int]),
     "mg_winoups3x3": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "mg_winoups3x3_dgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "mg_winoups3x3_dgrad_pn": (c_int, [_P] * 5 + [c_int] * 5 + [c_float, _P]),
     "mg_winoups3x3_head_supported": (c_int, [c_int] * 5),
     "mg_winoups3x3_head": (c_int, [_P] * 9 + [c_int] * 5 + [c_float, _P]),
     "mg_upconv3x3_packed_floats": (c_size_t, [c_int, c_int]),

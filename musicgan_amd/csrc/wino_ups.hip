@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(64 * WU_NWAVE, 1) winoups_fwd(const WuArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------------ data gradient
-template <int NT>
+template <int NT, bool PNB>
 __global__ void __launch_bounds__(64 * WU_NWAVE, 1) winoups_dgrad(const WuArgs a) {
   extern __shared__ __attribute__((aligned(16))) float Us[];
   const int tid = threadIdx.x, lane = tid & 63, col = lane & 15, rq = lane >> 4;
@@ -431,12 +431,43 @@ __global__ void __launch_bounds__(64 * WU_NWAVE, 1) winoups_dgrad(const WuArgs a
     // gx(tile) = s^T M s: the factors of s are in the filters, so the low-res pixel is the plain sum of the nine accumulators
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)en * a.Cout * HWl, 0, a.Cout * HWl * 4, 0x00020000);
     const int lo = ((rq * 4) * HWl + col) * 4, so0 = (ety * a.Wl + 16 * ebx) * 4;
+    if constexpr (!PNB) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const f32x4 s = (((acc[0][t] + acc[1][t]) + (acc[2][t] + acc[3][t])) + ((acc[4][t] + acc[5][t]) + (acc[6][t] + acc[7][t]))) + acc[8][t];
+      for (int t = 0; t < NT; ++t) {
+        const f32x4 s = (((acc[0][t] + acc[1][t]) + (acc[2][t] + acc[3][t])) + ((acc[4][t] + acc[5][t]) + (acc[6][t] + acc[7][t]))) + acc[8][t];
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)s[g]), ry, lo, (t * 16 + g) * HWl * 4 + so0, 0);
+        for (int g = 0; g < 4; ++g)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)s[g]), ry, lo, (t * 16 + g) * HWl * 4 + so0, 0);
+      }
+    } else {
+      // PNB: the PixelNorm + LeakyReLU backward of the layer below (its normalised output a.p, 1/norm a.rn; elementwise.hip's from_p
+      // form) on the way out: all channels of the low-res pixel are in this wave -- the lane's NT x 4, the other three row groups
+      // 16 lanes apart -- so the gradient at the lower conv's pre-activation leaves instead of the gradient at its output
+      const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.p) + (size_t)en * a.Cout * HWl, 0,
+                                                                          a.Cout * HWl * 4, 0x00020000);
+      f32x4 s[NT], pv[NT];
+      float dot = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pv[t][g] = wu_i2f(__builtin_amdgcn_raw_buffer_load_b32(rp, lo, (t * 16 + g) * HWl * 4 + so0, 0));
+      const float r = a.rn[(size_t)en * HWl + (size_t)ety * a.Wl + 16 * ebx + col];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        s[t] = (((acc[0][t] + acc[1][t]) + (acc[2][t] + acc[3][t])) + ((acc[4][t] + acc[5][t]) + (acc[6][t] + acc[7][t]))) + acc[8][t];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dot = fmaf(s[t][g], pv[t][g], dot);
+      }
+      dot += __shfl_xor(dot, 16);
+      dot += __shfl_xor(dot, 32);
+      dot /= (float)a.Cout;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float o = mg_lrelu_mask(pv[t][g], a.slope) * r * (s[t][g] - pv[t][g] * dot);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), ry, lo, (t * 16 + g) * HWl * 4 + so0, 0);
+        }
     }
     if (w.item >= w.nitems) break;
   }
@@ -451,12 +482,12 @@ int wu_launch_fwd(const WuArgs& a, size_t lds, hipStream_t s) {
   MG_CHECK_LAUNCH("mg_winoups3x3");
   return MG_OK;
 }
-template <int NT>
+template <int NT, bool PNB = false>
 int wu_launch_dgrad(const WuArgs& a, size_t lds, hipStream_t s) {
   static MgPerDevice once;
   if (mg_first_use_on_device(once))
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&winoups_dgrad<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL((winoups_dgrad<NT>), dim3(a.G), dim3(64 * WU_NWAVE), lds, s, a);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&winoups_dgrad<NT, PNB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL((winoups_dgrad<NT, PNB>), dim3(a.G), dim3(64 * WU_NWAVE), lds, s, a);
   MG_CHECK_LAUNCH("mg_winoups3x3_dgrad");
   return MG_OK;
 }
@@ -534,6 +565,26 @@ extern "C" int mg_winoups3x3_head(const float* x, const float* up, const float* 
     case 1: return wu_launch_fwd<1, true, true>(a, lds, s);
     case 2: return wu_launch_fwd<2, true, true>(a, lds, s);
     default: return wu_launch_fwd<3, true, true>(a, lds, s);
+  }
+}
+
+// The data gradient with the PixelNorm + LeakyReLU backward of the layer below in the epilogue (generator.py:31-39 backward): p (N,Cin,
+// Hin,Win) that layer's normalised output, rn (N,1,Hin,Win) its 1/norm; gpre = lrelu'(p) rn (gx - p mean_c(gx p)).
+extern "C" int mg_winoups3x3_dgrad_pn(const float* gy, const float* up, const float* p, const float* rn, float* gpre, int N, int Cin, int Cout,
+                                      int Hin, int Win, float slope, mg_stream_t stream) {
+  MG_CHECK_ARG(gy && up && p && rn && gpre && wu_shape_ok(N, Cout, Cin, Hin, Win), "mg_winoups3x3_dgrad_pn: unsupported shape (N=%d %d<-%d %dx%d)",
+               N, Cin, Cout, Hin, Win);
+  WuArgs a;
+  a.x = gy; a.up = up; a.bias = nullptr; a.y = gpre; a.p = const_cast<float*>(p); a.rn = const_cast<float*>(rn); a.flags = 0; a.slope = slope;
+  a.hw = nullptr; a.hb = nullptr; a.mp = nullptr;
+  wu_fill(a, N, Cout, Cin, Hin, Win);
+  const size_t lds = (size_t)a.nchunk * (Cin / 16) * 9 * 512;
+  hipStream_t s = (hipStream_t)stream;
+  switch (Cin / 16) {
+    case 1: return wu_launch_dgrad<1, true>(a, lds, s);
+    case 2: return wu_launch_dgrad<2, true>(a, lds, s);
+    case 3: return wu_launch_dgrad<3, true>(a, lds, s);
+    default: return wu_launch_dgrad<4, true>(a, lds, s);
   }
 }
 

@@ -487,13 +487,19 @@ def gen_backward(W: GenWeights, ctx, g_out: torch.Tensor, cache: PackCache, sink
         gw2, acc = sink.slot(w2)
         gb2, _ = sink.slot(b2)
         ops.conv3x3_wgrad(p1, gpre2, gw2, gb2, ups=True, accumulate=acc, defer=defer)
+        small_tail = i == 1 and gen_head_ok(W, saved[0][0])
+        gpre1 = None
         if ops.winoups3x3_supported(p1.shape[0], ci, w2.shape[0], p1.shape[2], p1.shape[3], dgrad=True):
-            gp1 = ops.winoups3x3_dgrad(gpre2, cache.get_wu(w2, True), ci)  # 9-component Winograd form, block sums in the epilogue
+            if not small_tail and ops._head_fuse(1) and ops.fuse_ends():
+                # 9-component Winograd form, block sums AND the PixelNorm / LeakyReLU backward of conv 1 in the epilogue
+                gp1, gpre1 = None, ops.winoups3x3_dgrad_pn(gpre2, cache.get_wu(w2, True), p1, rn1, ci)
+            else:
+                gp1 = ops.winoups3x3_dgrad(gpre2, cache.get_wu(w2, True), ci)  # 9-component Winograd form, block sums in the epilogue
         elif ops.upconv3x3_dgrad_supported(p1.shape[2], p1.shape[3], gpre2.numel(), p1.shape[0]):
             gp1 = ops.upconv3x3_dgrad(gpre2, cache.get_up_dgrad(w2), ci)  # stride-2 4x4 form: no high-res intermediate
         else:
             gp1 = cache.conv_upsum(gpre2, w2, ci)
-        if i == 1 and gen_head_ok(W, saved[0][0]):
+        if small_tail:
             # the data-gradient chain of the generator's first three convs in one launch; their weight gradients from the
             # stored masked gradients
             z, rn1a, p1a, rn2a, p2a = saved[0]
@@ -518,7 +524,8 @@ def gen_backward(W: GenWeights, ctx, g_out: torch.Tensor, cache: PackCache, sink
                 gbt, _ = sink.slot(bt)
                 ops.conv3x3_wgrad(xi, gy, gwt, gbt, ups=ups, accumulate=acc, defer=defer)
             break
-        gpre1 = ops.pixelnorm_lrelu_bwd(gp1, p1, rn1, from_p=True)
+        if gpre1 is None:
+            gpre1 = ops.pixelnorm_lrelu_bwd(gp1, p1, rn1, from_p=True)
         gw1, acc = sink.slot(w1)
         gb1, _ = sink.slot(b1)
         ops.conv3x3_wgrad(xin, gpre1, gw1, gb1, accumulate=acc, defer=defer)

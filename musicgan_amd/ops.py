@@ -328,6 +328,18 @@ def winoups3x3_dgrad(gy, up, cin: int):
     return gx
 
 
+def winoups3x3_dgrad_pn(gy, up, p, rn, cin: int):
+    """winoups3x3_dgrad followed by the PixelNorm + LeakyReLU backward of the layer whose normalised output is p (rn: its 1/norm), in
+    the data-gradient kernel's epilogue: returns the gradient at that layer's pre-activation (N,Cin,H,W)."""
+    _chk(gy, up, p, rn)
+    n, cout, h2, w2 = gy.shape
+    assert p.shape == (n, cin, h2 // 2, w2 // 2)
+    gpre = torch.empty_like(p)
+    check(_lib.load().mg_winoups3x3_dgrad_pn(_p(gy), _p(up), _p(p), _p(rn), _p(gpre), n, cin, cout, h2 // 2, w2 // 2, SLOPE, _s()),
+          "mg_winoups3x3_dgrad_pn")
+    return gpre
+
+
 def pack_upconv3x3_dgrad(w: torch.Tensor) -> torch.Tensor:
     _chk(w)
     co, ci = w.shape[0], w.shape[1]

@@ -70,6 +70,12 @@ def test_data_gradient_matches_autograd(shape):
     gx = ops.winoups3x3_dgrad(gy.to(DEV), upd, ci)
     assert _rel(gx, x.grad) <= 3e-6
     assert torch.equal(gx, ops.winoups3x3_dgrad(gy.to(DEV), upd, ci))
+    # the same with the PixelNorm + LeakyReLU backward of the layer below in the epilogue
+    pl = torch.randn(n, ci, h, w, generator=g).to(DEV)
+    rnl = (torch.rand(n, 1, h, w, generator=g) + 0.5).to(DEV)
+    gpre = ops.winoups3x3_dgrad_pn(gy.to(DEV), upd, pl, rnl, ci)
+    ref = ops.pixelnorm_lrelu_bwd(gx, pl, rnl, from_p=True)
+    assert _rel(gpre, ref.double().cpu()) <= 2e-6
 
 
 def test_unsupported_shapes_are_refused():

@@ -50,6 +50,12 @@ def flops(name, a, k, res):
     if name == "upconv3x3":
         n, ci, h, w = a[0].shape
         return 18.0 * n * ci * a[3] * 4 * h * w * W
+    if name in ("winoups3x3", "winoups3x3_head"):  # 9 of 36 multiply-adds per output pixel and channel pair
+        n, ci, h, w = a[0].shape
+        return 18.0 * n * ci * a[3] * 4 * h * w * 0.25
+    if name == "winoups3x3_dgrad":
+        n, co, h2, w2 = a[0].shape
+        return 18.0 * n * a[2] * co * h2 * w2 * 0.25
     if name == "upconv3x3_dgrad":
         n, co, h2, w2 = a[0].shape
         return 18.0 * n * a[2] * co * h2 * w2 * W
@@ -108,7 +114,9 @@ def wrap(name, fn):
 _orig["wino_wgrad_supported"] = ops.wino_wgrad_supported
 for n in ("conv3x3", "conv3x3_fade", "conv3x3_small", "conv3x3_small_pn", "upconv3x3", "upconv3x3_dgrad", "conv3x3_wgrad", "conv1x1",
           "conv1x1_wgrad", "pixelnorm_fwd", "pixelnorm_lrelu_bwd", "upsample2x_fwd", "upsample2x_bwd", "avgpool2_fwd", "avgpool2_bwd",
-          "blend_lrelu_bwd", "lrelu_bwd", "axpby", "blend_up", "gp_interp", "sumsq_per_sample", "scale_per_sample"):
+          "blend_lrelu_bwd", "lrelu_bwd", "axpby", "blend_up", "gp_interp", "sumsq_per_sample", "scale_per_sample", "winoups3x3",
+          "winoups3x3_head", "winoups3x3_dgrad", "gen_head_bwd", "head_pair", "head_pair_from_mp", "stem_pair", "stem_pair_gx",
+          "blend_up_bwd", "gp_apply", "linear1_fwd", "linear1_bwd"):
     setattr(ops, n, wrap(n, getattr(ops, n)))
 
 # the slab reductions of a sweep's weight gradients are ONE launch for all its layers (WgradDefer.flush): a row of its own, `group`
@@ -148,6 +156,8 @@ print(f"# level {level} batch {batch}: {len(records)} distinct calls, per-call s
 print(f"# calls of >= {floor_us:.0f} us; bound = max(bytes / 8 TB/s, executed FLOP / 157.3 TF/s); D = critic update, G = generator update")
 print("# step op                  tensors (first two 4-D inputs)            cout flags                        calls  us/call  MB      GFLOP   bound us  x bound  (limit)")
 rows = sorted(records.items(), key=lambda kv: -kv[1][1] / kv[1][0])
+if os.environ.get("MG_BOUNDS_ORDER") == "program":  # the calls in the order the step makes them (first occurrence)
+    rows = list(records.items())
 over, listed = 0.0, 0.0
 for (ph, name, shp, flags), (cnt, ms, nbytes, fl) in rows:
     us = 1e3 * ms / cnt
