@@ -46,6 +46,7 @@ struct WuArgs {
   int flags;
   float slope;
   int nchunk, blocks_x, G;  // K / 8; Wl / 16; workgroups
+  int tile0, nt_total;      // data gradient: this launch computes out-channel tiles tile0 .. tile0 + NT - 1 of nt_total (Cout = 16 nt_total)
 };
 
 __device__ __forceinline__ f32x2 wu_sub(f32x2 a, f32x2 b) {
@@ -134,6 +135,17 @@ struct WuWalk {
     n += dn + c2;
   }
 };
+
+// the same for a launch that owns NT of nt_total tiles: per chunk a run of NT x 9 x 128 floats out of nt_total x 9 x 128
+__device__ __forceinline__ void wu_load_bank_tiles(float* Us, const float* up, int nchunk, int nt, int nt_total, int tile0, int tid) {
+  const int per = nt * 9 * 32;  // 16-byte pieces per chunk
+  f32x4* dst = reinterpret_cast<f32x4*>(Us);
+  for (int i = tid; i < nchunk * per; i += 64 * WU_NWAVE) {
+    const int ch = i / per, r = i - ch * per;
+    dst[i] = reinterpret_cast<const f32x4*>(up)[(size_t)(ch * nt_total + tile0) * 9 * 32 + r];
+  }
+  __syncthreads();
+}
 
 __device__ __forceinline__ void wu_load_bank(float* Us, const float* up, int n16, int tid) {
   const f32x4* src = reinterpret_cast<const f32x4*>(up);
@@ -348,7 +360,8 @@ __global__ void __launch_bounds__(64 * WU_NWAVE, 1) winoups_dgrad(const WuArgs a
   const int tid = threadIdx.x, lane = tid & 63, col = lane & 15, rq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int HWl = a.Hl * a.Wl, H = 2 * a.Hl, W = 2 * a.Wl, HW = H * W;
-  wu_load_bank(Us, a.up, a.nchunk * NT * 9 * 32, tid);
+  if (a.nt_total == NT) wu_load_bank(Us, a.up, a.nchunk * NT * 9 * 32, tid);
+  else wu_load_bank_tiles(Us, a.up, a.nchunk, NT, a.nt_total, a.tile0, tid);
   const unsigned us_addr = (unsigned)reinterpret_cast<size_t>(Us + lane * 2);  // (low 32 bits of a shared-aperture address = LDS offset)
   WuWalk w;
   w.init(blockIdx.x, a.G, a.N, a.Hl / WU_NWAVE, a.blocks_x);
@@ -437,7 +450,7 @@ __global__ void __launch_bounds__(64 * WU_NWAVE, 1) winoups_dgrad(const WuArgs a
         const f32x4 s = (((acc[0][t] + acc[1][t]) + (acc[2][t] + acc[3][t])) + ((acc[4][t] + acc[5][t]) + (acc[6][t] + acc[7][t]))) + acc[8][t];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)s[g]), ry, lo, (t * 16 + g) * HWl * 4 + so0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)s[g]), ry, lo, ((a.tile0 + t) * 16 + g) * HWl * 4 + so0, 0);
       }
     } else {
       // PNB: the PixelNorm + LeakyReLU backward of the layer below (its normalised output a.p, 1/norm a.rn; elementwise.hip's from_p
@@ -493,10 +506,13 @@ int wu_launch_dgrad(const WuArgs& a, size_t lds, hipStream_t s) {
 }
 
 // K input channels, Cout out-channels (of THIS kernel: the data gradient calls it with the layer's channels swapped)
-bool wu_shape_ok(int N, int K, int Cout, int Hl, int Wl) {
-  if (N <= 0 || K < 16 || Cout <= 0 || (K % 8) != 0 || (Cout % 16) != 0 || Cout > 64) return false;
+// tile_groups (data gradient without an epilogue over all channels): up to 6 out-channel tiles, five or six as two launches of <= 3 tiles
+// each (the input is read and transformed once per launch); otherwise all tiles -- at most four -- in one wave
+bool wu_shape_ok(int N, int K, int Cout, int Hl, int Wl, bool tile_groups = false) {
+  if (N <= 0 || K < 16 || Cout <= 0 || (K % 8) != 0 || (Cout % 16) != 0 || Cout > (tile_groups ? 96 : 64)) return false;
   if ((Wl % 16) != 0 || (Hl % WU_NWAVE) != 0) return false;
-  if ((size_t)(K / 8) * (Cout / 16) * 9 * 512 > 160 * 1024) return false;                       // the filter bank in LDS
+  const int nt_launch = Cout > 64 ? 3 : Cout / 16;
+  if ((size_t)(K / 8) * nt_launch * 9 * 512 > 160 * 1024) return false;                         // the filter bank of a launch in LDS
   if ((long long)(K > Cout ? K : Cout) * 4 * Hl * Wl * 16 >= (1ll << 31)) return false;         // 32-bit byte offsets inside an image
   return true;
 }
@@ -504,6 +520,7 @@ bool wu_shape_ok(int N, int K, int Cout, int Hl, int Wl) {
 void wu_fill(WuArgs& a, int N, int K, int Cout, int Hl, int Wl) {
   a.N = N; a.K = K; a.Cout = Cout; a.Hl = Hl; a.Wl = Wl;
   a.nchunk = K / 8;
+  a.tile0 = 0; a.nt_total = Cout / 16;
   a.blocks_x = Wl / 16;
   const int nitems = N * (Hl / WU_NWAVE) * a.blocks_x;
   int g = mg_cu_count() & ~7;
@@ -515,7 +532,7 @@ void wu_fill(WuArgs& a, int N, int K, int Cout, int Hl, int Wl) {
 
 extern "C" int mg_winoups3x3_supported(int N, int Cin, int Cout, int Hin, int Win, int dgrad) {
   // forward: Cin -> Cout on the up-sampled grid; data gradient: Cout (gy) -> Cin
-  return dgrad ? wu_shape_ok(N, Cout, Cin, Hin, Win) : wu_shape_ok(N, Cin, Cout, Hin, Win);
+  return dgrad ? wu_shape_ok(N, Cout, Cin, Hin, Win, true) : wu_shape_ok(N, Cin, Cout, Hin, Win);
 }
 
 extern "C" size_t mg_winoups3x3_packed_floats(int Cin, int Cout, int dgrad) { return pack_winoups_total(Cout, Cin, dgrad); }
@@ -590,18 +607,26 @@ extern "C" int mg_winoups3x3_dgrad_pn(const float* gy, const float* up, const fl
 
 extern "C" int mg_winoups3x3_dgrad(const float* gy, const float* up, float* gx, int N, int Cin, int Cout, int Hin, int Win,
                                    mg_stream_t stream) {
-  MG_CHECK_ARG(gy && up && gx && wu_shape_ok(N, Cout, Cin, Hin, Win), "mg_winoups3x3_dgrad: unsupported shape (N=%d %d<-%d %dx%d)", N, Cin,
+  MG_CHECK_ARG(gy && up && gx && wu_shape_ok(N, Cout, Cin, Hin, Win, true), "mg_winoups3x3_dgrad: unsupported shape (N=%d %d<-%d %dx%d)", N, Cin,
                Cout, Hin, Win);
   WuArgs a;
   a.x = gy; a.up = up; a.bias = nullptr; a.y = gx; a.p = nullptr; a.rn = nullptr; a.flags = 0; a.slope = 1.0f;
   a.hw = nullptr; a.hb = nullptr; a.mp = nullptr;
   wu_fill(a, N, Cout, Cin, Hin, Win);
-  const size_t lds = (size_t)a.nchunk * (Cin / 16) * 9 * 512;
   hipStream_t s = (hipStream_t)stream;
-  switch (Cin / 16) {
-    case 1: return wu_launch_dgrad<1>(a, lds, s);
-    case 2: return wu_launch_dgrad<2>(a, lds, s);
-    case 3: return wu_launch_dgrad<3>(a, lds, s);
-    default: return wu_launch_dgrad<4>(a, lds, s);
+  const int nt = Cin / 16;
+  auto lds = [&](int tiles) { return (size_t)a.nchunk * tiles * 9 * 512; };
+  if (nt > 4) {  // 80 / 96 input channels of the layer: tiles 0-2, then the other two or three
+    a.tile0 = 0;
+    int rc = wu_launch_dgrad<3>(a, lds(3), s);
+    if (rc != MG_OK) return rc;
+    a.tile0 = 3;
+    return nt == 5 ? wu_launch_dgrad<2>(a, lds(2), s) : wu_launch_dgrad<3>(a, lds(3), s);
+  }
+  switch (nt) {
+    case 1: return wu_launch_dgrad<1>(a, lds(1), s);
+    case 2: return wu_launch_dgrad<2>(a, lds(2), s);
+    case 3: return wu_launch_dgrad<3>(a, lds(3), s);
+    default: return wu_launch_dgrad<4>(a, lds(4), s);
   }
 }

@@ -490,7 +490,7 @@ def gen_backward(W: GenWeights, ctx, g_out: torch.Tensor, cache: PackCache, sink
         small_tail = i == 1 and gen_head_ok(W, saved[0][0])
         gpre1 = None
         if ops.winoups3x3_supported(p1.shape[0], ci, w2.shape[0], p1.shape[2], p1.shape[3], dgrad=True):
-            if not small_tail and ops._head_fuse(1) and ops.fuse_ends():
+            if not small_tail and ops.winoups3x3_dgrad_pn_supported(p1.shape[0], ci, w2.shape[0], p1.shape[2], p1.shape[3]):
                 # 9-component Winograd form, block sums AND the PixelNorm / LeakyReLU backward of conv 1 in the epilogue
                 gp1, gpre1 = None, ops.winoups3x3_dgrad_pn(gpre2, cache.get_wu(w2, True), p1, rn1, ci)
             else:

@@ -268,6 +268,12 @@ def winoups3x3_supported(n: int, cin: int, cout: int, hin: int, win: int, *, dgr
     csrc/wino_ups.hip (MG_WINOUPS=0: never -- the sub-pixel kernels then)."""
     if os.environ.get("MG_WINOUPS", "1") == "0":
         return False
+    if dgrad and cin > 64:
+        # 80 / 96 input channels: the data gradient as two launches of <= 3 tiles each.  Against the stride-2 kernel 107 -> 79 us
+        # (80<-64 @32 x64), 83 -> 50 (96<-80 @16 x64), 61 -> 44 (x32); below ~128 wave items (N x H/8 x W/16) the other route is the
+        # small-map conv + block sums, which wins there (24-35 us against 37-48): profiles/r06_ab_winoups.txt.  MG_WINOUPS_TILE_GROUPS=0: never
+        if os.environ.get("MG_WINOUPS_TILE_GROUPS", "1") == "0" or n * (hin // 8) * (win // 16) < 128:
+            return False
     return bool(_lib.load().mg_winoups3x3_supported(n, cin, cout, hin, win, int(dgrad)))
 
 
@@ -326,6 +332,11 @@ def winoups3x3_dgrad(gy, up, cin: int):
     gx = torch.empty((n, cin, h2 // 2, w2 // 2), dtype=torch.float32, device=gy.device)
     check(_lib.load().mg_winoups3x3_dgrad(_p(gy), _p(up), _p(gx), n, cin, cout, h2 // 2, w2 // 2, _s()), "mg_winoups3x3_dgrad")
     return gx
+
+
+def winoups3x3_dgrad_pn_supported(n: int, cin: int, cout: int, hin: int, win: int) -> bool:
+    """All `cin` channels of a low-res pixel in one wave (at most 64): the PixelNorm backward needs their sum."""
+    return cin <= 64 and _head_fuse(1) and fuse_ends() and winoups3x3_supported(n, cin, cout, hin, win, dgrad=True)
 
 
 def winoups3x3_dgrad_pn(gy, up, p, rn, cin: int):

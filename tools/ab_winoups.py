@@ -19,7 +19,8 @@ def timeit(fn, n=20):
 
 
 # (N, Cin, Cout, Hin): level 5 batch 64; levels 6 / 7 at batch 6 and 16
-cases = [(64, 64, 48, 64), (6, 64, 48, 64), (6, 48, 32, 128), (6, 32, 16, 256), (16, 32, 16, 256), (16, 48, 32, 128), (32, 64, 48, 64)]
+cases = [(64, 64, 48, 64), (6, 64, 48, 64), (6, 48, 32, 128), (6, 32, 16, 256), (16, 32, 16, 256), (16, 48, 32, 128), (32, 64, 48, 64),
+         (64, 80, 64, 32), (64, 96, 80, 16), (6, 80, 64, 32)]  # (the last three: data gradient only, in two launches of <= 3 tiles)
 print(" N  cin->cout @hin    fwd: sub-pixel  winoups   ratio | dgrad: stride-2  winoups   ratio   bound us (0.25 x direct FLOP / 157.3 TF/s)")
 for (n, ci, co, h) in cases:
     x, w, b = R(n, ci, h, h), R(co, ci, 3, 3) * 0.05, R(co)
@@ -27,7 +28,8 @@ for (n, ci, co, h) in cases:
     wp, up = ops.pack_upconv3x3(w), ops.pack_winoups3x3(w, False)
     wpd, upd = ops.pack_upconv3x3_dgrad(w), ops.pack_winoups3x3(w, True)
     t0 = timeit(lambda: ops.upconv3x3(x, wp, b, co, lrelu=True, pixnorm=True, want_y=False))
-    t1 = timeit(lambda: ops.winoups3x3(x, up, b, co, lrelu=True, pixnorm=True, want_y=False))
+    fwd_ok = ops.winoups3x3_supported(n, ci, co, h, h)
+    t1 = timeit(lambda: ops.winoups3x3(x, up, b, co, lrelu=True, pixnorm=True, want_y=False)) if fwd_ok else float("nan")
     d0 = timeit(lambda: ops.upconv3x3_dgrad(gy, wpd, ci)) if ops.upconv3x3_dgrad_supported(h, h, gy.numel(), n) else float("nan")
     d1 = timeit(lambda: ops.winoups3x3_dgrad(gy, upd, ci))
     bound = 18.0 * n * ci * co * 4 * h * h * 0.25 / 157.3e12 * 1e6
