@@ -225,7 +225,7 @@ int mg_conv1x1_wgrad(const float* x, const float* gy, const float* tanh_y, float
  *   (g - p mean_c(g p)) (N,C,H,W) = the gradient at the last conv's pre-activation (PixelNorm + LeakyReLU backward, rn (N,1,H,W) the
  *   stored 1/norm).  One read of p, one write of gpre.  g_in (optional, (N,C,H,W)): a second gradient arriving at p, added to g (the old
  *   head of a fading-in level: p is also the input of the last block's first conv, g_in that conv's data gradient).
- *   C in {16, 32, 48, 64}; ws: mg_gen_head_bwd_ws_floats(N, C, HW) floats. */
+ *   C in {16, 32, 48, 64}, or any multiple of 4 up to 128 on small maps (N H W <= 32 768); ws: mg_gen_head_bwd_ws_floats(N, C, HW) floats. */
 int mg_stem_pair(const float* x, const float* ws, const float* bs, const float* wo, const float* bo, float* h0, float* xp, float* o,
                  unsigned char* h0_mask, int N, int C0, int C1, int H, int W, int flags, float slope, mg_stream_t stream);
 int mg_stem_pair_gx(const float* gs, const float* ws, const float* go, const float* wo, float* gx, int N, int C0, int C1, int H, int W,
@@ -237,7 +237,8 @@ int mg_blend_up_bwd(const float* g, const float* coef, float ca, float cb, float
 /* mg_head_pair with mp given (written by mg_winoups3x3_head): old = tanh(wo xl + bo), out = a mp + b up2(old). */
 int mg_head_pair_from_mp(const float* mp, const float* xl, const float* wo, const float* bo, const float* coef, float ca, float cb,
                          float* old, float* out, int N, int Cl, int H, int W, mg_stream_t stream);
-int mg_gen_head_bwd_supported(int C, int Cout);
+int mg_gen_head_bwd_supported(int C, int Cout);                      /* C in {16, 32, 48, 64}: any size */
+int mg_gen_head_bwd_supported_at(int C, int Cout, int N, int HW);     /* ... or a multiple of 4 up to 128 on at most 32 768 pixels */
 size_t mg_gen_head_bwd_ws_floats(int N, int C, int HW);
 int mg_gen_head_bwd(const float* g_mp, const float* mp, const float* w, const float* p, const float* rn, const float* g_in, float* gpre,
                     float* gw, float* gb, float* ws, size_t ws_floats, int N, int C, int HW, float slope, int accumulate, mg_stream_t stream);

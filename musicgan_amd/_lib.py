@@ -132,6 +132,7 @@ SIGNATURES = {
     "mg_blend_up_bwd": (c_int, [_P, _P, c_float, c_float, _P, _P, c_int, c_int, c_int, _P]),
     "mg_head_pair_from_mp": (c_int, [_P] * 5 + [c_float, c_float, _P, _P] + [c_int] * 4 + [_P]),
     "mg_gen_head_bwd_supported": (c_int, [c_int, c_int]),
+    "mg_gen_head_bwd_supported_at": (c_int, [c_int, c_int, c_int, c_int]),
     "mg_gen_head_bwd_ws_floats": (c_size_t, [c_int, c_int, c_int]),
     "mg_gen_head_bwd": (c_int, [_P] * 10 + [c_size_t, c_int, c_int, c_int, c_float, c_int, _P]),
     "mg_channel_sum": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -391,6 +391,81 @@ __global__ void __launch_bounds__(NT) gen_head_bwd_k(const float* __restrict__ g
   }
 }
 
+// The same for ANY channel count up to 128 on small maps (the heads of levels 3 / 4: 80 .. 128 channels on 32x32 / 16x16): a workgroup takes
+// 64 pixels at a time (lane = pixel), its 4 waves split the channels (wave w: channels w, w + 4, ...: at most 32 each, p and gin of a
+// pixel in registers), the four partial dot products meet in LDS.  One pass, no parking; 2 C / 4 sums per lane.
+constexpr int GHS_MAXQ = 32;  // channels per wave
+template <bool GIN>
+__global__ void __launch_bounds__(256) gen_head_bwd_small_k(const float* __restrict__ gm, const float* __restrict__ mp, const float* __restrict__ w,
+                                                            const float* __restrict__ p, const float* __restrict__ rn,
+                                                            const float* __restrict__ gin, float* __restrict__ gpre, float* __restrict__ part,
+                                                            int N, int C, int HW, float slope) {
+  __shared__ float dots[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float s0[GHS_MAXQ], s1[GHS_MAXQ], sb0 = 0.f, sb1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < GHS_MAXQ; ++k) s0[k] = s1[k] = 0.f;
+  const size_t total = (size_t)N * HW;
+  for (size_t b0 = (size_t)blockIdx.x * 64; b0 < total; b0 += (size_t)gridDim.x * 64) {
+    const size_t i = b0 + lane;
+    const bool ok = i < total;
+    const int n = ok ? (int)(i / HW) : 0;
+    const int px = ok ? (int)(i - (size_t)n * HW) : 0;
+    const size_t fb = (size_t)n * 2 * HW + px, base = (size_t)n * C * HW + px;
+    const float m0 = ok ? mp[fb] : 0.f, m1 = ok ? mp[fb + HW] : 0.f;
+    const float t0 = ok ? gm[fb] * (1.f - m0 * m0) : 0.f, t1 = ok ? gm[fb + HW] * (1.f - m1 * m1) : 0.f;
+    const float r = ok ? rn[i] : 0.f;
+    if (wave == 0) {
+      sb0 += t0;
+      sb1 += t1;
+    }
+    float tv[GHS_MAXQ], gv[GHS_MAXQ];
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < GHS_MAXQ; ++k) {
+      const int c = wave + 4 * k;
+      const bool live = ok && c < C;
+      tv[k] = live ? p[base + (size_t)c * HW] : 0.f;
+      gv[k] = (GIN && live) ? gin[base + (size_t)c * HW] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < GHS_MAXQ; ++k) {
+      const int c = wave + 4 * k < C ? wave + 4 * k : 0;
+      gv[k] += fmaf(w[C + c], t1, w[c] * t0);
+      dot = fmaf(gv[k], tv[k], dot);
+      s0[k] = fmaf(t0, tv[k], s0[k]);
+      s1[k] = fmaf(t1, tv[k], s1[k]);
+    }
+    dots[wave][lane] = dot;
+    __syncthreads();
+    dot = (((dots[0][lane] + dots[1][lane]) + dots[2][lane]) + dots[3][lane]) / (float)C;
+#pragma unroll
+    for (int k = 0; k < GHS_MAXQ; ++k) {
+      const int c = wave + 4 * k;
+      if (ok && c < C) gpre[base + (size_t)c * HW] = mg_lrelu_mask(tv[k], slope) * r * (gv[k] - tv[k] * dot);
+    }
+    __syncthreads();  // (dots is rewritten in the next turn)
+  }
+  // per workgroup: row of 2 C + 2 partial sums in the layout of gen_head_bwd_k ([f][c], then the two bias sums)
+  const int per = 2 * C + 2;
+#pragma unroll
+  for (int k = 0; k < GHS_MAXQ; ++k) {
+    const float a0 = mg_wave_sum_to_lane63(s0[k]), a1 = mg_wave_sum_to_lane63(s1[k]);
+    const int c = wave + 4 * k;
+    if (lane == 63 && c < C) {
+      part[(size_t)blockIdx.x * per + c] = a0;
+      part[(size_t)blockIdx.x * per + C + c] = a1;
+    }
+  }
+  if (wave == 0) {
+    const float a0 = mg_wave_sum_to_lane63(sb0), a1 = mg_wave_sum_to_lane63(sb1);
+    if (lane == 63) {
+      part[(size_t)blockIdx.x * per + 2 * C] = a0;
+      part[(size_t)blockIdx.x * per + 2 * C + 1] = a1;
+    }
+  }
+}
+
 // gw (2, C) and gb (2) from the per-workgroup partials: one wave per output, lanes stride over the workgroups, a fixed shuffle tree
 __global__ void __launch_bounds__(256) gen_head_bwd_final_k(const float* __restrict__ part, int G, int C, float* __restrict__ gw,
                                                             float* __restrict__ gb, int accumulate) {
@@ -517,17 +592,44 @@ extern "C" int mg_blend_up_bwd(const float* g, const float* coef, float ca, floa
   return MG_OK;
 }
 
-extern "C" int mg_gen_head_bwd_supported(int C, int Cout) { return (Cout == 2 && (C == 16 || C == 32 || C == 48 || C == 64)) ? 1 : 0; }
+// the streaming form: C in {16, 32, 48, 64}; the small-map form: any C <= 128 that is a multiple of 4, up to 2^15 pixels
+static bool ghb_stream_ok(int C) { return C == 16 || C == 32 || C == 48 || C == 64; }
+static bool ghb_small_ok(int C, size_t pixels) { return C >= 4 && C <= 4 * GHS_MAXQ && (C % 4) == 0 && pixels <= (1u << 15); }
+static int ghb_small_grid(size_t pixels) {
+  size_t g = (pixels + 63) / 64;
+  const size_t cap = 2 * (size_t)mg_cu_count();
+  return (int)(g > cap ? cap : (g < 1 ? 1 : g));
+}
+
+extern "C" int mg_gen_head_bwd_supported(int C, int Cout) { return (Cout == 2 && ghb_stream_ok(C)) ? 1 : 0; }
+extern "C" int mg_gen_head_bwd_supported_at(int C, int Cout, int N, int HW) {
+  return (Cout == 2 && (ghb_stream_ok(C) || ghb_small_ok(C, (size_t)N * HW))) ? 1 : 0;
+}
 
 extern "C" size_t mg_gen_head_bwd_ws_floats(int N, int C, int HW) {
-  return (size_t)gen_head_bwd_grid(C, (size_t)N * HW, true) * (2 * C + 2);  // (the larger of the two forms' grids)
+  const size_t pixels = (size_t)N * HW;
+  const size_t g = ghb_stream_ok(C) ? (size_t)gen_head_bwd_grid(C, pixels, true) : (size_t)ghb_small_grid(pixels);
+  return g * (2 * C + 2);
 }
 
 extern "C" int mg_gen_head_bwd(const float* g_mp, const float* mp, const float* w, const float* p, const float* rn, const float* g_in,
                                float* gpre, float* gw, float* gb, float* ws, size_t ws_floats, int N, int C, int HW, float slope,
                                int accumulate, mg_stream_t stream) {
   MG_CHECK_ARG(g_mp && mp && w && p && rn && gpre && gw && gb && ws && N > 0 && HW > 0, "mg_gen_head_bwd: bad arguments");
-  MG_CHECK_ARG(mg_gen_head_bwd_supported(C, 2), "mg_gen_head_bwd: C = %d (16, 32, 48 or 64)", C);
+  MG_CHECK_ARG(mg_gen_head_bwd_supported_at(C, 2, N, HW), "mg_gen_head_bwd: C = %d (16, 32, 48, 64; any multiple of 4 up to 128 on <= 32 768 pixels)", C);
+  if (!ghb_stream_ok(C)) {
+    const int G = ghb_small_grid((size_t)N * HW);
+    MG_CHECK_ARG(ws_floats >= (size_t)G * (2 * C + 2), "mg_gen_head_bwd: workspace of %zu floats, needs %zu", ws_floats, (size_t)G * (2 * C + 2));
+    hipStream_t s = (hipStream_t)stream;
+    if (g_in != nullptr)
+      hipLaunchKernelGGL(gen_head_bwd_small_k<true>, dim3(G), dim3(256), 0, s, g_mp, mp, w, p, rn, g_in, gpre, ws, N, C, HW, slope);
+    else
+      hipLaunchKernelGGL(gen_head_bwd_small_k<false>, dim3(G), dim3(256), 0, s, g_mp, mp, w, p, rn, g_in, gpre, ws, N, C, HW, slope);
+    MG_CHECK_LAUNCH("mg_gen_head_bwd(small)");
+    hipLaunchKernelGGL(gen_head_bwd_final_k, dim3((2 * C + 2 + 3) / 4), dim3(256), 0, s, ws, G, C, gw, gb, accumulate);
+    MG_CHECK_LAUNCH("mg_gen_head_bwd(final)");
+    return MG_OK;
+  }
   const int G = gen_head_bwd_grid(C, (size_t)N * HW, g_in != nullptr);
   MG_CHECK_ARG(ws_floats >= (size_t)G * (2 * C + 2), "mg_gen_head_bwd: workspace of %zu floats, needs %zu", ws_floats, (size_t)G * (2 * C + 2));
   hipStream_t s = (hipStream_t)stream;

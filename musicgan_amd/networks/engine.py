@@ -461,7 +461,8 @@ def gen_backward(W: GenWeights, ctx, g_out: torch.Tensor, cache: PackCache, sink
     gb, _ = sink.slot(W.head[1])
     last = len(W.blocks) - 1
     gpre_head = None
-    if ops.gen_head_bwd_supported(x_last.shape[1], W.head[0].shape[0]) and saved[last][4] is x_last:
+    if ops.gen_head_bwd_supported(x_last.shape[1], W.head[0].shape[0], x_last.shape[0], x_last.shape[2] * x_last.shape[3]) \
+            and saved[last][4] is x_last:
         # the head's weight gradient, its data gradient and the PixelNorm / LeakyReLU backward of the last conv: one pass over p
         gpre_head = ops.gen_head_bwd(g_mp, mp, W.head[0], x_last, saved[last][3], gw, gb, accumulate=acc)
         g = None
@@ -531,7 +532,8 @@ def gen_backward(W: GenWeights, ctx, g_out: torch.Tensor, cache: PackCache, sink
         ops.conv3x3_wgrad(xin, gpre1, gw1, gb1, accumulate=acc, defer=defer)
         if i > 0:
             g = cache.conv(gpre1, w1, True, None, ci)
-            if g_old is not None and i == last and ops.gen_head_bwd_supported(xin.shape[1], W.old_head[0].shape[0]) \
+            if g_old is not None and i == last and ops.gen_head_bwd_supported(xin.shape[1], W.old_head[0].shape[0], xin.shape[0],
+                                                                              xin.shape[2] * xin.shape[3]) \
                     and saved[last - 1][4] is xin:
                 old_pending = True  # (handled at the top of the next turn)
             elif g_old is not None and i == last:

@@ -763,9 +763,14 @@ def blend_up_bwd(g, a: float, b: float, coef=None):
     return gx, gy
 
 
-def gen_head_bwd_supported(c: int, cout: int = 2) -> bool:
-    """The generator head's backward + the PixelNorm / LeakyReLU backward in front of it as one launch (MG_FUSE_ENDS=0: never)."""
-    return fuse_ends() and _head_fuse(1) and bool(_lib.load().mg_gen_head_bwd_supported(int(c), int(cout)))
+def gen_head_bwd_supported(c: int, cout: int = 2, n: int = 0, hw: int = 0) -> bool:
+    """The generator head's backward + the PixelNorm / LeakyReLU backward in front of it as one launch (MG_FUSE_ENDS=0: never).
+    With (n, hw) given: also the small-map form (any channel count up to 128 on at most 32 768 pixels)."""
+    if not (fuse_ends() and _head_fuse(1)):
+        return False
+    if n > 0 and hw > 0:
+        return bool(_lib.load().mg_gen_head_bwd_supported_at(int(c), int(cout), int(n), int(hw)))
+    return bool(_lib.load().mg_gen_head_bwd_supported(int(c), int(cout)))
 
 
 def gen_head_bwd(g_mp, mp, w, p, rn, gw, gb, *, accumulate=False, slope: float = SLOPE, g_in=None):

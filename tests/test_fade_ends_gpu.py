@@ -179,7 +179,8 @@ def test_update_with_fused_ends_equals_the_separate_kernels(level, batch, monkey
         assert abs(v - grads["1"][2][k]) <= 1e-5 * max(1.0, abs(v)), k
 
 
-@pytest.mark.parametrize("shape", [(3, 48, 16, 24), (2, 64, 8, 8), (5, 32, 32, 16), (2, 16, 64, 64), (1, 48, 128, 128)])
+@pytest.mark.parametrize("shape", [(3, 48, 16, 24), (2, 64, 8, 8), (5, 32, 32, 16), (2, 16, 64, 64), (1, 48, 128, 128), (8, 80, 32, 32),
+                                   (3, 96, 16, 16), (2, 128, 4, 4), (5, 20, 8, 12), (32, 112, 8, 8)])
 def test_gen_head_bwd_matches_the_three_launches_and_autograd(shape):
     """mg_gen_head_bwd (head weight / data gradient + PixelNorm / LeakyReLU backward of the block in front, one pass) against the
     three launches it replaces and against fp64 autograd of tanh(conv1x1(PixelNorm(LeakyReLU(y)))) -- generator.py:31-39, 118-126."""
@@ -197,7 +198,7 @@ def test_gen_head_bwd_matches_the_three_launches_and_autograd(shape):
     pd, mpd, gd, wd = p.detach().float().to(DEV), mp.detach().float().to(DEV), g_mp.float().to(DEV), wt.detach().float().to(DEV)
     rn = (1.0 / torch.sqrt((a * a).mean(dim=1, keepdim=True) + 1e-8)).detach().float().to(DEV)
     gw, gb = torch.full((2, c, 1, 1), 3.0, device=DEV), torch.full((2,), 3.0, device=DEV)
-    assert ops.gen_head_bwd_supported(c)
+    assert ops.gen_head_bwd_supported(c, 2, n, h * w)
     gpre = ops.gen_head_bwd(gd, mpd, wd, pd, rn, gw, gb)
     rel = lambda got, ref: float((got.double().cpu() - ref).abs().max() / ref.abs().max())
     assert rel(gpre, y.grad) <= 5e-6 and rel(gw, wt.grad) <= 5e-6 and rel(gb, bt.grad) <= 5e-6
@@ -209,7 +210,7 @@ def test_gen_head_bwd_matches_the_three_launches_and_autograd(shape):
     assert rel(gpre, gpre0.double().cpu()) <= 2e-6 and rel(gw, gw0.double().cpu()) <= 2e-6 and rel(gb, gb0.double().cpu()) <= 2e-6
     gpre2 = ops.gen_head_bwd(gd, mpd, wd, pd, rn, gw, gb, accumulate=True)
     assert torch.equal(gpre, gpre2) and rel(gw, 2 * wt.grad) <= 5e-6 and rel(gb, 2 * bt.grad) <= 5e-6
-    assert not ops.gen_head_bwd_supported(40) and not ops.gen_head_bwd_supported(48, 3)
+    assert not ops.gen_head_bwd_supported(40) and not ops.gen_head_bwd_supported(48, 3) and not ops.gen_head_bwd_supported(80, 2, 64, 64 * 64)
     # a second gradient arriving at p (the old head of a fading-in level)
     g_in = torch.randn(n, c, h, w, generator=g).to(DEV)
     gw3, gb3 = torch.empty_like(gw), torch.empty_like(gb)
