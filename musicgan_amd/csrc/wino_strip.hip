@@ -30,6 +30,7 @@
 // third rule: 16-byte buffer stores with a scalar soffset need a wait state before their data registers are overwritten (below).
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "mg_common.h"
 #include "pack_kernels.h"
@@ -63,6 +64,24 @@ __device__ __forceinline__ int clamp01(int v) { return v < 0 ? 0 : (v > 1 ? 1 : 
 __device__ __forceinline__ float sel_bits(int t, float x, float y) {
   return __builtin_bit_cast(float, (t & f2i(x)) | (~t & f2i(y)));
 }
+
+template <class F, int... Is>
+__device__ __forceinline__ void sk_static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void sk_static_for(F&& f) {
+  sk_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+// 16 bytes of LDS at byte address addr + OFF as ONE ds_read_b128 the compiler does not schedule or count (sk_wait before the first use)
+template <int OFF>
+__device__ __forceinline__ f32x4 sk_lds128(unsigned addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+__device__ __forceinline__ void sk_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void sk_tie(f32x4& v) { asm volatile("" : "+v"(v)); }
 
 // KIND (StripKind) and POOL (SK_ACT / SK_MASKF: also write the pooled tensor) are compile-time: with the epilogue selected by a
 // run-time branch the block loop has a control-flow join behind stores whose number the compiler cannot count, and gfx9 has ONE
@@ -207,19 +226,31 @@ __device__ __forceinline__ void strip_body(const WinoArgs& a, const int ct0, con
   };
 
   // `first_`: the block's first chunk starts its sums from the zero constant (no 64 x NIW register clears per block)
+  // The filters of component pair cp + 1 are REQUESTED before the MFMAs of pair cp are issued and waited for after them: the reads are
+  // inline assembly (outside hipcc's s_waitcnt bookkeeping: sk_wait + the register ties below), fenced against the scheduler, which
+  // otherwise moves them down to just above their first use -- an LDS round trip in front of every group of MFMAs.
+  const unsigned us_lane = (unsigned)reinterpret_cast<size_t>(Us + lane * 4);  // (low 32 bits of a shared-aperture address = LDS offset)
   auto mfma_chunk = [&](int ch, auto first_) __attribute__((always_inline)) {
     constexpr bool FIRST = decltype(first_)::value;
-    const float* ub = Us + (ch * NLDS) * 2048 + lane * 4;
+    const unsigned ub = us_lane + (unsigned)(ch * NLDS) * 8192u;
     f32x4 bv[2][NIW];
+    sk_static_for<NIW>([&](auto ni_) __attribute__((always_inline)) {
+      constexpr int ni = decltype(ni_)::value;
+      bv[0][ni] = sk_lds128<ni * 8192>(ub);
+    });
+    sk_static_for<8>([&](auto cp_) __attribute__((always_inline)) {
+      constexpr int cp = decltype(cp_)::value;
+      constexpr int cur = cp & 1, nxt = cur ^ 1;
+      sk_wait();
 #pragma unroll
-    for (int ni = 0; ni < NIW; ++ni) bv[0][ni] = *reinterpret_cast<const f32x4*>(ub + ni * 2048);
-#pragma unroll
-    for (int cp = 0; cp < 8; ++cp) {
-      const int cur = cp & 1, nxt = cur ^ 1;
-      if (cp + 1 < 8) {
-#pragma unroll
-        for (int ni = 0; ni < NIW; ++ni) bv[nxt][ni] = *reinterpret_cast<const f32x4*>(ub + ni * 2048 + (cp + 1) * 256);
+      for (int ni = 0; ni < NIW; ++ni) sk_tie(bv[cur][ni]);
+      if constexpr (cp + 1 < 8) {
+        sk_static_for<NIW>([&](auto ni_) __attribute__((always_inline)) {
+          constexpr int ni = decltype(ni_)::value;
+          bv[nxt][ni] = sk_lds128<ni * 8192 + (cp + 1) * 1024>(ub);
+        });
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -229,7 +260,8 @@ __device__ __forceinline__ void strip_body(const WinoArgs& a, const int ct0, con
             const f32x4 c0 = (FIRST && ks == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[2 * cp + par][ni];
             acc[2 * cp + par][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[cur][ni][ks * 2 + par], V[ks][cp][par], c0, 0, 0, 0);
           }
-    }
+      __builtin_amdgcn_sched_barrier(0);
+    });
   };
 
   // ------------------------------------------------------------------ epilogue pieces
