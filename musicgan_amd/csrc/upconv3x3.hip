@@ -13,12 +13,23 @@
 // Same skeleton as conv3x3.hip: implicit GEMM on v_mfma_f32_16x16x4_f32, a wave = 16 low-res pixels x 4 phases x all output
 // channels (64 output pixels, PixelNorm reduction inside the wave), 8-channel chunks through LDS with issue-early/write-late
 // register prefetch, weights pre-packed as the LDS image [chunk][16 = phase*4 + a*2 + b][8][16*ceil(Cout/16)].
+#include <type_traits>
+#include <utility>
+
 #include "mg_common.h"
 #include "pack_kernels.h"
 
 namespace {
 
 constexpr int CC = 8;
+template <class F, int... Is>
+__device__ __forceinline__ void up_static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void up_static_for(F&& f) {
+  up_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 constexpr float PN_EPS = 1e-8f;
 constexpr int UP_NIN = 8;  // halo positions per thread in flight (plane <= 256)
 
@@ -133,33 +144,52 @@ __global__ void __launch_bounds__(256) upconv3x3_mfma(const UpArgs a) {
       }
     }
   };
-  auto compute_chunk = [&]() {
+  // One group = one low-res neighbour (dy, dx) and k-step: its pixel value and the weights of the 1 / 2 / 4 phases that read it.  The
+  // operands of group g + 1 are requested BEFORE the MFMAs of group g are issued (two register sets, scheduling fences): left to the
+  // scheduler every pair of MFMAs sat behind its own ds_read + s_waitcnt lgkmcnt(0) (an LDS round trip per two MFMAs).
+  constexpr int NG = 9 * (CC / 4);
+  float gav[2];
+  float gwb[2][4][NI];
+  auto load_group = [&](auto g_, auto s_) __attribute__((always_inline)) {
+    constexpr int g = decltype(g_)::value, S = decltype(s_)::value;
+    constexpr int tp = g / (CC / 4), ks = g % (CC / 4), dy = tp / 3, dx = tp % 3;
+    gav[S] = in_t[pix_off + ks * 4 * a.ch_stride + dy * a.TWp + dx];
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
+    for (int py = 0; py < 2; ++py)
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int tap = dy * a.TWp + dx;  // low-res neighbour (y + dy - 1, x + dx - 1)
+      for (int px = 0; px < 2; ++px) {
+        const int ta = dy - py, tb = dx - px;  // tap of this phase that reads the neighbour, if any
+        if (ta >= 0 && ta <= 1 && tb >= 0 && tb <= 1) {
+          const int wrow = ((py * 2 + px) * 4 + ta * 2 + tb) * CC + ks * 4;
 #pragma unroll
-        for (int ks = 0; ks < CC / 4; ++ks) {
-          const float av = in_t[pix_off + ks * 4 * a.ch_stride + tap];
-#pragma unroll
-          for (int py = 0; py < 2; ++py) {
-#pragma unroll
-            for (int px = 0; px < 2; ++px) {
-              const int ta = dy - py, tb = dx - px;  // tap of this phase that reads the neighbour, if any
-              if (ta >= 0 && ta <= 1 && tb >= 0 && tb <= 1) {
-                const int wrow = ((py * 2 + px) * 4 + ta * 2 + tb) * CC + ks * 4;
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                  const float bvv = w_t[(wrow + rq) * OPL + ni * 16 + col];
-                  acc[py * 2 + px][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bvv, acc[py * 2 + px][ni], 0, 0, 0);
-                }
-              }
-            }
-          }
+          for (int ni = 0; ni < NI; ++ni) gwb[S][py * 2 + px][ni] = w_t[(wrow + rq) * OPL + ni * 16 + col];
         }
       }
-    }
+  };
+  auto mfma_group = [&](auto g_, auto s_) __attribute__((always_inline)) {
+    constexpr int g = decltype(g_)::value, S = decltype(s_)::value;
+    constexpr int tp = g / (CC / 4), dy = tp / 3, dx = tp % 3;
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+      for (int px = 0; px < 2; ++px) {
+        const int ta = dy - py, tb = dx - px;
+        if (ta >= 0 && ta <= 1 && tb >= 0 && tb <= 1) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[py * 2 + px][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(gav[S], gwb[S][py * 2 + px][ni], acc[py * 2 + px][ni], 0, 0, 0);
+        }
+      }
+  };
+  auto compute_chunk = [&]() __attribute__((always_inline)) {
+    load_group(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    up_static_for<NG>([&](auto g_) __attribute__((always_inline)) {
+      constexpr int g = decltype(g_)::value;
+      if constexpr (g + 1 < NG) load_group(std::integral_constant<int, g + 1>{}, std::integral_constant<int, (g + 1) & 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_group(g_, std::integral_constant<int, g & 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+    });
   };
 
   __syncthreads();
@@ -394,6 +424,8 @@ __global__ void __launch_bounds__(256) downconv4x4s2_mfma(const DownArgs a) {
       }
     }
   };
+  // (measured: requesting the operands of the next tap / k-step group ahead of the MFMAs, as upconv3x3_mfma does, is 3 % SLOWER here --
+  // ten MFMAs per group already cover the reads: 107 -> 111 us at 80<-64 @32 x64)
   auto compute_chunk = [&]() {
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
