@@ -604,7 +604,8 @@ __device__ __forceinline__ void strip_body(const WinoArgs& a, const int ct0, con
 // count) -- that row runs the ONE-tile body on the two-tile filter image (no MFMAs, no epilogue for the padding tile) and gets fewer
 // workgroups, in proportion to its work.
 template <int NIW, int NWAVE, int KIND, bool POOL>
-__global__ void __launch_bounds__(64 * NWAVE, 1) wino3x3_strip(const WinoArgs a) {
+// (one tile per wave: at most 168 registers, i.e. three waves per SIMD -- except the un-pooling and PixelNorm epilogues, which do not fit)
+__global__ void __launch_bounds__(64 * NWAVE, (NIW == 1 && KIND != SK_UNPOOL && KIND != SK_PN) ? 3 : 1) wino3x3_strip(const WinoArgs a) {
   const int g_full = a.TBW, g_pad = a.TBH, nrows = a.lgTBW;
   const int row = ((int)blockIdx.x < (nrows - (g_pad ? 1 : 0)) * g_full) ? (int)blockIdx.x / g_full : nrows - 1;
   const int wg = (int)blockIdx.x - row * g_full;
